@@ -1,0 +1,147 @@
+/* rgbd_recon_hip.h -- C ABI of the MI355X-native TSDF fusion core (librgbd_recon_hip.so).
+ *
+ * Drop-in boundary for the per-frame hot path of rgbd-recon: everything
+ * kinect::ReconIntegration (framework/reconstruction/recon_integration.hpp:35-103) does on the GL
+ * thread -- integrate(), drawF() = drawDepthLimits() + draw() + fillColors(), the brick-occupancy
+ * bookkeeping and the setters -- behind plain C entry points.  No C++ or torch types cross this line.
+ *
+ * Conventions
+ *   - every call returns 0 on success, a negative tsdf_status otherwise; tsdf_last_error() gives text.
+ *     Nothing throws or aborts across the boundary (reference: exceptions/exit/assert).
+ *   - a context is single-threaded; all device work is queued on ONE HIP stream (own, or adopted with
+ *     tsdf_set_stream) and is asynchronous until tsdf_sync() or a download.
+ *   - host pointers unless the name says `_dev`; matrices are 16 floats column-major exactly as
+ *     glGetFloatv(GL_MODELVIEW_MATRIX / GL_PROJECTION_MATRIX) returns them (recon_integration.cpp:183,197).
+ *   - volumes are x-fastest, z-outermost (calibration_volume.hpp:57-59, volume_sampler.cpp:39-45);
+ *     images are row-major, bottom row first (GL window coordinates), layers outermost.
+ *   - GL implicit state of the reference becomes explicit arguments (SURVEY.md §8b "implicit inputs").
+ */
+#ifndef RGBD_RECON_HIP_H
+#define RGBD_RECON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSDF_MAX_STREAMS 16   /* reference hard-codes 5 (tsdf_integration.vs:13); configs c3/c4 need 8 */
+#define TSDF_MAX_LODS 20      /* tsdf_inpaint.fs:11-12 uniform uvec2[20] */
+
+typedef struct tsdf_ctx tsdf_ctx;
+
+typedef enum tsdf_status {
+  TSDF_OK = 0,
+  TSDF_ERR_INVALID_ARGUMENT = -1,
+  TSDF_ERR_HIP = -2,           /* a hip* call failed; message in tsdf_last_error */
+  TSDF_ERR_NO_DEVICE = -3,
+  TSDF_ERR_STATE = -4,         /* call order violated (e.g. integrate before calibration upload) */
+  TSDF_ERR_OUT_OF_MEMORY = -5
+} tsdf_status;
+
+/* Replaces the constructor arguments ReconIntegration(cfs, cv, bbox, limit, size)
+ * (recon_integration.cpp:30-60) plus what it pulls out of CalibrationFiles (stream count, image sizes,
+ * reconstruction.cpp:14-22) and the window size it is resize()d to (:482-500). */
+typedef struct tsdf_config {
+  uint32_t struct_size;     /* = sizeof(tsdf_config) */
+  float bbox_min[3], bbox_max[3];
+  float voxel_size;         /* used when res[0] == 0: res = ceil(bbox / voxel_size)   (:340-344) */
+  uint32_t res[3];          /* explicit TSDF resolution (benchmark configs), overrides voxel_size */
+  float brick_size[3];      /* world units; the reference has one scalar (:53, :462-472); snapped to whole voxels */
+  float limit;              /* TSDF truncation, also the raymarch step basis (tsdf_raymarch.fs:34) */
+  uint32_t num_streams;
+  uint32_t depth_w, depth_h;   /* depth/quality/silhouette arrays (NetKinectArray.cpp:159-178) */
+  uint32_t color_w, color_h;   /* colour array (NetKinectArray.cpp:147-157) */
+  uint32_t view_w, view_h;     /* viewport (resize(), :482-500) */
+  int32_t device;              /* HIP device ordinal */
+  /* multi-GPU Z-slab partition: this context owns voxel planes [slab_z0, slab_z1);
+   * 0,0 = the whole volume.  Both must be multiples of 8 (storage tile) unless 0 / res_z. */
+  uint32_t slab_z0, slab_z1;
+} tsdf_config;
+
+/* ---- lifetime / errors ------------------------------------------------------------------------- */
+int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out);
+int32_t tsdf_destroy(tsdf_ctx* ctx);
+const char* tsdf_last_error(const tsdf_ctx* ctx);   /* ctx may be NULL: error of the last failed tsdf_create */
+int32_t tsdf_set_stream(tsdf_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL: back to own) */
+int32_t tsdf_sync(tsdf_ctx* ctx);
+
+/* ---- inputs ------------------------------------------------------------------------------------ */
+/* CalibVolumes textures (CalibVolumes.cpp:64-80,132-144): per stream the inverse LUT cv_xyz_inv (RGBA32F,
+ * unit 30+i), the colour LUT cv_uv (RG32F, unit 10+2i) and the forward LUT cv_xyz (RGB32F, unit 9+2i).
+ * uv / xyz may be NULL when raymarch colouring / brick marking are not used. */
+int32_t tsdf_set_calibration(tsdf_ctx* ctx, uint32_t stream,
+                             const float* xyz_inv_rgba, const uint32_t res_inv[3],
+                             const float* uv_rg, const uint32_t res_uv[3],
+                             const float* xyz_rgb, const uint32_t res_xyz[3]);
+/* NetKinectArray's processed arrays on texture units 1,2,3,5 (NetKinectArray.cpp:428-449):
+ * depth RG32F [N][H][W][2] (r = normalised depth), quality R32F, silhouette R32F, colour RGB8 [N][Hc][Wc][3].
+ * colour may be NULL (keeps the previous one).  Normals (unit 4) are not read by the path
+ * (GRAD_NORMALS, tsdf_raymarch.fs:46). */
+int32_t tsdf_upload_frame(tsdf_ctx* ctx, const float* depth_rg, const float* quality,
+                          const float* silhouette, const uint8_t* colour_rgb);
+
+/* ---- brick occupancy: clearOccupiedBricks / mark_brick / updateOccupiedBricks -------------------- */
+int32_t tsdf_clear_bricks(tsdf_ctx* ctx);                       /* recon_integration.cpp:271-277 */
+int32_t tsdf_mark_bricks(tsdf_ctx* ctx);                        /* pre_normal.fs:22-33 -> inc_bricks.glsl:40-58 */
+/* recon_integration.cpp:430-445 without the GPU->CPU->GPU round trip; ratio may be NULL (no sync) */
+int32_t tsdf_update_occupied(tsdf_ctx* ctx, float* ratio);
+
+/* ---- the path ---------------------------------------------------------------------------------- */
+int32_t tsdf_integrate(tsdf_ctx* ctx);                          /* integrate(), :242-269 */
+/* drawF() up to and including draw(): drawDepthLimits() when space skipping and bricks are on (:154-156),
+ * then the raymarch (:176-240) into the hole-filling pyramid level 0 or the framebuffer. */
+int32_t tsdf_raymarch(tsdf_ctx* ctx, const float modelview[16], const float projection[16]);
+int32_t tsdf_fill_colors(tsdf_ctx* ctx);                        /* fillColors(), :279-338 */
+/* drawF(): tsdf_raymarch + (colour filling on ? tsdf_fill_colors : nothing), :151-174 */
+int32_t tsdf_draw_f(tsdf_ctx* ctx, const float modelview[16], const float projection[16]);
+
+/* ---- setters mirroring recon_integration.hpp:43-49,57 and reconstruction.hpp:20-23 --------------- */
+int32_t tsdf_set_tsdf_limit(tsdf_ctx* ctx, float limit);
+int32_t tsdf_set_use_bricks(tsdf_ctx* ctx, int32_t active);
+int32_t tsdf_set_space_skip(tsdf_ctx* ctx, int32_t active);
+int32_t tsdf_set_color_filling(tsdf_ctx* ctx, int32_t active);
+int32_t tsdf_set_min_voxels_per_brick(tsdf_ctx* ctx, uint32_t n);
+int32_t tsdf_set_brick_size(tsdf_ctx* ctx, const float size[3]);
+int32_t tsdf_set_shade_mode(tsdf_ctx* ctx, int32_t mode);      /* UBO 1 g_shade_mode, shading.glsl:14-21 */
+int32_t tsdf_resize(tsdf_ctx* ctx, uint32_t width, uint32_t height);
+
+/* ---- getters ----------------------------------------------------------------------------------- */
+int32_t tsdf_get_resolution(const tsdf_ctx* ctx, uint32_t res[3], uint32_t res_bricks[3], float brick_size[3]);
+int32_t tsdf_num_bricks(const tsdf_ctx* ctx, uint32_t* n);
+int32_t tsdf_occupied_ratio(tsdf_ctx* ctx, float* ratio);      /* occupiedRatio(), :478-480; synchronises */
+int32_t tsdf_num_lods(const tsdf_ctx* ctx, uint32_t* n);       /* ViewLod::numLods, view_lod.cpp:25 */
+
+/* ---- downloads / uploads of intermediate state (the reference never reads these back; tests do) -- */
+int32_t tsdf_download_volume(tsdf_ctx* ctx, float* tsdf);                       /* [rz][ry][rx] */
+int32_t tsdf_upload_volume(tsdf_ctx* ctx, const float* tsdf);
+int32_t tsdf_download_bricks(tsdf_ctx* ctx, uint32_t* counters, uint8_t* occupied_flags);
+int32_t tsdf_upload_brick_counters(tsdf_ctx* ctx, const uint32_t* counters);
+/* raymarch target level 0: rgba [h][w][4], depth [h][w], nsamples [h][w], depth peels [h][w][4]; any may be NULL */
+int32_t tsdf_download_image(tsdf_ctx* ctx, float* rgba, float* depth, float* nsamples, float* peels);
+int32_t tsdf_upload_image(tsdf_ctx* ctx, const float* rgba, const float* depth);
+int32_t tsdf_download_framebuffer(tsdf_ctx* ctx, float* rgba, float* depth);    /* output of fillColors */
+int32_t tsdf_download_atlas(tsdf_ctx* ctx, float* rgba, float* depth);          /* [h][1.5w] pyramid atlas */
+
+/* ---- multi-GPU hooks (one context per rank; the collective itself is the caller's: RCCL) ---------- */
+/* Halo = whole storage tile layers (8 voxel planes) next to the slab faces; sizes in bytes per face. */
+int32_t tsdf_halo_info(const tsdf_ctx* ctx, uint32_t* layers, uint64_t* bytes_per_face);
+/* copy this slab's lowest / highest `layers` tile layers into device buffers (either may be NULL) */
+int32_t tsdf_halo_pack_dev(tsdf_ctx* ctx, void* lo_face_dev, void* hi_face_dev);
+/* fill the halo below / above the slab from the neighbours' faces (NULL: keep) */
+int32_t tsdf_halo_unpack_dev(tsdf_ctx* ctx, const void* below_dev, const void* above_dev);
+/* partial image of this slab: [rgba 16 B | depth 4 B | nsamples 4 B] planar, 24 * w * h bytes */
+int32_t tsdf_export_partial_dev(tsdf_ctx* ctx, void* dst_dev);
+/* nearest-hit select over n gathered partial images into this context's raymarch target */
+int32_t tsdf_composite_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n);
+
+/* ---- timers: the reference's TimerDatabase names: "2integrate", "3recon", "draw",
+ * "holefill", "brickdraw", plus "bricks" (clear + mark + update).
+ * "2integrate" brackets exactly the integrate kernel launch, "draw" exactly the raymarch kernel -------------------------------------------------------------- */
+int32_t tsdf_enable_timers(tsdf_ctx* ctx, int32_t active);
+int32_t tsdf_timer_ms(tsdf_ctx* ctx, const char* name, float* last_ms);   /* synchronises on that timer */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBD_RECON_HIP_H */

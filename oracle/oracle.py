@@ -1,0 +1,215 @@
+"""ctypes front-end of the CPU oracle (oracle/tsdf_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (rgbd-recon_amd/) never imports this module.
+PARITY UNPINNED (see the header of tsdf_oracle.cpp).
+
+Method names follow kinect::ReconIntegration (framework/reconstruction/recon_integration.hpp:38-64).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libtsdf_oracle.so")
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("voxel_size", C.c_float),
+                ("res", C.c_uint32 * 3), ("brick_size", C.c_float * 3), ("limit", C.c_float),
+                ("num_streams", C.c_uint32), ("depth_w", C.c_uint32), ("depth_h", C.c_uint32),
+                ("color_w", C.c_uint32), ("color_h", C.c_uint32), ("view_w", C.c_uint32), ("view_h", C.c_uint32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.orc_create.restype = C.c_void_p
+        L.orc_update_occupied.restype = C.c_float
+        L.orc_num_bricks.restype = C.c_uint32
+        L.orc_num_occupied.restype = C.c_uint32
+        L.orc_tsdf.restype = C.POINTER(C.c_float)
+        L.orc_tex2d_nearest.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class OracleRecon:
+    def __init__(self, scene, res=None, voxel_size=0.01, brick_size=0.1, limit=0.01, view=(1280, 720)):
+        L = lib()
+        cfg = OrcConfig()
+        cfg.bbox_min[:] = [float(x) for x in scene["bbox_min"]]
+        cfg.bbox_max[:] = [float(x) for x in scene["bbox_max"]]
+        cfg.voxel_size = voxel_size
+        cfg.res[:] = list(res) if res is not None else [0, 0, 0]
+        bs = [brick_size] * 3 if np.isscalar(brick_size) else list(brick_size)
+        assert all(b > 0 for b in bs)
+        cfg.brick_size[:] = bs
+        cfg.limit = limit
+        cfg.num_streams = scene["n"]
+        cfg.depth_w, cfg.depth_h = scene["width"], scene["height"]
+        cfg.color_w, cfg.color_h = scene["color_width"], scene["color_height"]
+        cfg.view_w, cfg.view_h = view
+        self._L = L
+        self._c = C.c_void_p(L.orc_create(C.byref(cfg)))
+        self.scene = scene
+        self.view = tuple(view)
+        res3, rb3, b3, nl = (C.c_uint32 * 3)(), (C.c_uint32 * 3)(), (C.c_float * 3)(), C.c_uint32()
+        L.orc_get_layout(self._c, res3, rb3, b3, C.byref(nl))
+        self.res, self.res_bricks, self.brick_size, self.num_lods = tuple(res3), tuple(rb3), tuple(b3), nl.value
+        self._keep = []
+        for i in range(scene["n"]):
+            inv, uv, xyz = _f32(scene["cv_xyz_inv"][i]), _f32(scene["cv_uv"][i]), _f32(scene["cv_xyz"][i])
+            self._keep += [inv, uv, xyz]
+            ri = (C.c_uint32 * 3)(*[int(x) for x in scene["inv_res"]])
+            rl = (C.c_uint32 * 3)(*[int(x) for x in scene["lut_res"]])
+            L.orc_set_calibration(self._c, i, _p(inv), ri, _p(uv), rl, _p(xyz), rl)
+        self.upload_frame(scene)
+        self.flags = dict(use_bricks=1, skip_space=1, fill_holes=1, min_voxels=10, shade_mode=0)
+        self._apply_flags()
+
+    def __del__(self):
+        if getattr(self, "_c", None):
+            self._L.orc_destroy(self._c)
+            self._c = None
+
+    def upload_frame(self, scene):
+        d, q, s, col = _f32(scene["depth"]), _f32(scene["quality"]), _f32(scene["silhouette"]), np.ascontiguousarray(scene["color"], np.uint8)
+        self._frame = (d, q, s, col)
+        self._L.orc_set_frame(self._c, _p(d), _p(q), _p(s), _p(col, C.c_uint8))
+
+    def _apply_flags(self):
+        f = self.flags
+        self._L.orc_set_flags(self._c, f["use_bricks"], f["skip_space"], f["fill_holes"], f["min_voxels"], f["shade_mode"])
+
+    # --- reference operator surface
+    def setUseBricks(self, a): self.flags["use_bricks"] = int(a); self._apply_flags()
+    def setSpaceSkip(self, a): self.flags["skip_space"] = int(a); self._apply_flags()
+    def setColorFilling(self, a): self.flags["fill_holes"] = int(a); self._apply_flags()
+    def setMinVoxelsPerBrick(self, n): self.flags["min_voxels"] = int(n); self._apply_flags()
+    def setShadeMode(self, m): self.flags["shade_mode"] = int(m); self._apply_flags()
+    def setTsdfLimit(self, v): self._L.orc_set_limit(self._c, C.c_float(v))
+    def clearOccupiedBricks(self): self._L.orc_clear_occupied(self._c)
+    def markBricks(self): self._L.orc_mark_bricks(self._c)
+    def updateOccupiedBricks(self): return self._L.orc_update_occupied(self._c)
+    def integrate(self): self._L.orc_integrate(self._c)
+
+    def draw(self, mv, proj):
+        self._L.orc_draw(self._c, _p(_f32(mv)), _p(_f32(proj)))
+
+    def fillColors(self): self._L.orc_fill_colors(self._c)
+
+    def drawF(self, mv, proj):
+        self.draw(mv, proj)
+        if self.flags["fill_holes"]:
+            self.fillColors()
+
+    # --- downloads
+    def numBricks(self): return self._L.orc_num_bricks(self._c)
+
+    def counters(self):
+        a = np.zeros(self.numBricks(), np.uint32)
+        self._L.orc_get_counters(self._c, _p(a, C.c_uint32))
+        return a
+
+    def set_counters(self, a):
+        a = np.ascontiguousarray(a, np.uint32)
+        assert a.size == self.numBricks()
+        self._L.orc_set_counters(self._c, _p(a, C.c_uint32))
+
+    def occupied(self):
+        a = np.zeros(self._L.orc_num_occupied(self._c), np.uint32)
+        if a.size:
+            self._L.orc_get_occupied(self._c, _p(a, C.c_uint32))
+        return a
+
+    def brick_ranges(self):
+        a = np.zeros((self.numBricks(), 6), np.uint32)
+        self._L.orc_get_brick_ranges(self._c, _p(a, C.c_uint32))
+        return a
+
+    def tsdf(self):
+        n = self.res[0] * self.res[1] * self.res[2]
+        return np.ctypeslib.as_array(self._L.orc_tsdf(self._c), shape=(n,)).reshape(self.res[2], self.res[1], self.res[0]).copy()
+
+    def set_tsdf(self, v):
+        v = _f32(v)
+        assert v.size == self.res[0] * self.res[1] * self.res[2]
+        self._L.orc_set_tsdf(self._c, _p(v))
+
+    def view_images(self):
+        w, h = self.view
+        rgba, d, ns, pe = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w, 4), np.float32)
+        self._L.orc_get_view(self._c, _p(rgba), _p(d), _p(ns), _p(pe))
+        return rgba, d, ns, pe
+
+    def set_view_images(self, rgba, depth):
+        self._L.orc_set_view(self._c, _p(_f32(rgba)), _p(_f32(depth)))
+
+    def framebuffer(self):
+        w, h = self.view
+        rgba, d = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32)
+        self._L.orc_get_framebuffer(self._c, _p(rgba), _p(d))
+        return rgba, d
+
+    def atlas(self):
+        w, h = self.view
+        aw = int(np.float32(w) * np.float32(1.5))
+        rgba, d = np.zeros((h, aw, 4), np.float32), np.zeros((h, aw), np.float32)
+        self._L.orc_get_atlas(self._c, _p(rgba), _p(d))
+        return rgba, d
+
+    def lod_tables(self):
+        off, res = np.zeros((self.num_lods, 2), np.uint32), np.zeros((self.num_lods, 2), np.uint32)
+        self._L.orc_get_lod_tables(self._c, _p(off, C.c_uint32), _p(res, C.c_uint32))
+        return off, res
+
+    def view_matrices(self, mv, proj):
+        out = np.zeros(35, np.float32)
+        self._L.orc_view_matrices(self._c, _p(_f32(mv)), _p(_f32(proj)), _p(out))
+        return out[:16].copy(), out[16:32].copy(), out[32:35].copy()
+
+
+# --- sampling primitives (unit tests)
+def tex3d(t, u, v, w):
+    t = _f32(t)
+    nz, ny, nx, nc = t.shape
+    out = np.zeros(nc, np.float32)
+    lib().orc_tex3d(_p(t), nc, (C.c_uint32 * 3)(nx, ny, nz), C.c_float(u), C.c_float(v), C.c_float(w), _p(out))
+    return out
+
+
+def tex2d_linear(t, layer, u, v):
+    t = _f32(t)
+    nl, h, w, nc = t.shape
+    out = np.zeros(nc, np.float32)
+    lib().orc_tex2d_linear(_p(t), nc, w, h, layer, C.c_float(u), C.c_float(v), _p(out))
+    return out
+
+
+def tex2d_nearest(t, layer, u, v, ch=0):
+    t = _f32(t)
+    nl, h, w, nc = t.shape
+    return lib().orc_tex2d_nearest(_p(t), nc, w, h, layer, C.c_float(u), C.c_float(v), ch)

@@ -1,0 +1,14 @@
+"""rgbd-recon_amd -- MI355X-native TSDF fusion core behind rgbd-recon's ReconIntegration surface.
+
+  csrc/      hand-written HIP kernels (gfx950) + the C ABI of include/rgbd_recon_hip.h
+  host/      C++ adapter with the reference's class/method names (drop-in for the GL operator)
+  binding.py ctypes binding + Python mirror of the operator (used by tests/, bench.py)
+  scene.py   synthetic calibrated RGB-D scene (harness input)
+  multigpu.py  Z-slab partition driver: one process per GPU, torch.distributed (RCCL) exchange
+
+The directory name carries a hyphen (project naming); import it as ``rgbd_recon_amd`` (alias module at
+the repository root) or with importlib.
+"""
+from .binding import (ReconIntegrationHip, TsdfConfig, TsdfError, build_library, declared_symbols,  # noqa: F401
+                      load_library, LIB_PATH, HEADER_PATH)
+from . import scene  # noqa: F401

@@ -1,0 +1,263 @@
+"""ctypes binding of librgbd_recon_hip.so (include/rgbd_recon_hip.h) and a Python mirror of the
+reference operator surface, ``kinect::ReconIntegration``
+(framework/reconstruction/recon_integration.hpp:35-103): same method names, same call order
+(source/kinect_client.cpp:569-599,614), GL implicit state passed explicitly.
+
+There is NO CPU fallback: if the HIP library is missing or no device is visible the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "librgbd_recon_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "rgbd_recon_hip.h")
+
+TSDF_MAX_STREAMS = 16
+
+
+class TsdfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"tsdf error {code}: {msg}")
+        self.code = code
+
+
+class TsdfConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+                ("voxel_size", C.c_float), ("res", C.c_uint32 * 3), ("brick_size", C.c_float * 3),
+                ("limit", C.c_float), ("num_streams", C.c_uint32), ("depth_w", C.c_uint32), ("depth_h", C.c_uint32),
+                ("color_w", C.c_uint32), ("color_h", C.c_uint32), ("view_w", C.c_uint32), ("view_h", C.c_uint32),
+                ("device", C.c_int32), ("slab_z0", C.c_uint32), ("slab_z1", C.c_uint32)]
+
+
+def build_library():
+    """hipcc cross-compiles gfx950 without a GPU."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc")])
+
+
+def declared_symbols():
+    """Every entry point include/rgbd_recon_hip.h declares."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsdf_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.tsdf_last_error.restype = C.c_char_p
+        L.tsdf_last_error.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class ReconIntegrationHip:
+    """HIP drop-in for kinect::ReconIntegration.  `scene` supplies what CalibrationFiles / CalibVolumes /
+    NetKinectArray hold in the reference (rgbd-recon_amd/scene.py layout)."""
+
+    def __init__(self, scene, res=None, voxel_size=0.01, brick_size=0.1, limit=0.01, view=(1280, 720),
+                 device=0, slab=(0, 0), upload=True):
+        self._L = load_library()
+        self._c = None
+        cfg = TsdfConfig()
+        cfg.struct_size = C.sizeof(TsdfConfig)
+        cfg.bbox_min[:] = [float(x) for x in scene["bbox_min"]]
+        cfg.bbox_max[:] = [float(x) for x in scene["bbox_max"]]
+        cfg.voxel_size = voxel_size
+        cfg.res[:] = list(res) if res is not None else [0, 0, 0]
+        cfg.brick_size[:] = [brick_size] * 3 if np.isscalar(brick_size) else list(brick_size)
+        cfg.limit = limit
+        cfg.num_streams = scene["n"]
+        cfg.depth_w, cfg.depth_h = scene["width"], scene["height"]
+        cfg.color_w, cfg.color_h = scene["color_width"], scene["color_height"]
+        cfg.view_w, cfg.view_h = view
+        cfg.device = device
+        cfg.slab_z0, cfg.slab_z1 = slab
+        ctx = C.c_void_p()
+        rc = self._L.tsdf_create(C.byref(cfg), C.byref(ctx))
+        if rc != 0:
+            raise TsdfError(rc, self._L.tsdf_last_error(None).decode())
+        self._c = ctx
+        self.view = tuple(view)
+        self.n = scene["n"]
+        r3, b3, s3 = (C.c_uint32 * 3)(), (C.c_uint32 * 3)(), (C.c_float * 3)()
+        self._ck(self._L.tsdf_get_resolution(self._c, r3, b3, s3))
+        self.res, self.res_bricks, self.brick_size = tuple(r3), tuple(b3), tuple(s3)
+        n = C.c_uint32()
+        self._ck(self._L.tsdf_num_lods(self._c, C.byref(n)))
+        self.num_lods = n.value
+        if upload:
+            self.set_calibration(scene)
+            self.upload_frame(scene)
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise TsdfError(rc, self._L.tsdf_last_error(self._c).decode())
+
+    def close(self):
+        if self._c:
+            self._L.tsdf_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_ptr):
+        self._ck(self._L.tsdf_set_stream(self._c, C.c_void_p(hip_stream_ptr)))
+
+    def sync(self):
+        self._ck(self._L.tsdf_sync(self._c))
+
+    def set_calibration(self, scene):
+        ri = (C.c_uint32 * 3)(*[int(x) for x in scene["inv_res"]])
+        rl = (C.c_uint32 * 3)(*[int(x) for x in scene["lut_res"]])
+        for i in range(self.n):
+            self._ck(self._L.tsdf_set_calibration(self._c, i, _fp(_f32(scene["cv_xyz_inv"][i])), ri,
+                                                  _fp(_f32(scene["cv_uv"][i])), rl, _fp(_f32(scene["cv_xyz"][i])), rl))
+
+    def upload_frame(self, scene):
+        col = np.ascontiguousarray(scene["color"], np.uint8)
+        self._ck(self._L.tsdf_upload_frame(self._c, _fp(_f32(scene["depth"])), _fp(_f32(scene["quality"])),
+                                           _fp(_f32(scene["silhouette"])), col.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    # ------------------------------------------------------------------ reference operator surface
+    def clearOccupiedBricks(self): self._ck(self._L.tsdf_clear_bricks(self._c))
+    def markBricks(self): self._ck(self._L.tsdf_mark_bricks(self._c))
+
+    def updateOccupiedBricks(self, want_ratio=True):
+        if not want_ratio:
+            self._ck(self._L.tsdf_update_occupied(self._c, None))
+            return None
+        r = C.c_float()
+        self._ck(self._L.tsdf_update_occupied(self._c, C.byref(r)))
+        return r.value
+
+    def integrate(self): self._ck(self._L.tsdf_integrate(self._c))
+    def draw(self, mv, proj): self._ck(self._L.tsdf_raymarch(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
+    def fillColors(self): self._ck(self._L.tsdf_fill_colors(self._c))
+    def drawF(self, mv, proj): self._ck(self._L.tsdf_draw_f(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
+    def setTsdfLimit(self, v): self._ck(self._L.tsdf_set_tsdf_limit(self._c, C.c_float(v)))
+    def setUseBricks(self, a): self._ck(self._L.tsdf_set_use_bricks(self._c, int(a)))
+    def setSpaceSkip(self, a): self._ck(self._L.tsdf_set_space_skip(self._c, int(a)))
+    def setColorFilling(self, a): self._ck(self._L.tsdf_set_color_filling(self._c, int(a)))
+    def setMinVoxelsPerBrick(self, n): self._ck(self._L.tsdf_set_min_voxels_per_brick(self._c, int(n)))
+    def setShadeMode(self, m): self._ck(self._L.tsdf_set_shade_mode(self._c, int(m)))
+
+    def setBrickSize(self, size):
+        s = (C.c_float * 3)(*([size] * 3 if np.isscalar(size) else list(size)))
+        self._ck(self._L.tsdf_set_brick_size(self._c, s))
+        r3, b3, s3 = (C.c_uint32 * 3)(), (C.c_uint32 * 3)(), (C.c_float * 3)()
+        self._ck(self._L.tsdf_get_resolution(self._c, r3, b3, s3))
+        self.res_bricks, self.brick_size = tuple(b3), tuple(s3)
+
+    def resize(self, w, h):
+        self._ck(self._L.tsdf_resize(self._c, w, h))
+        self.view = (w, h)
+        n = C.c_uint32()
+        self._ck(self._L.tsdf_num_lods(self._c, C.byref(n)))
+        self.num_lods = n.value
+
+    def occupiedRatio(self):
+        r = C.c_float()
+        self._ck(self._L.tsdf_occupied_ratio(self._c, C.byref(r)))
+        return r.value
+
+    def getBrickSize(self): return self.brick_size
+
+    def numBricks(self):
+        n = C.c_uint32()
+        self._ck(self._L.tsdf_num_bricks(self._c, C.byref(n)))
+        return n.value
+
+    # ------------------------------------------------------------------ state transfer (tests, harness)
+    def tsdf(self):
+        out = np.empty((self.res[2], self.res[1], self.res[0]), np.float32)
+        self._ck(self._L.tsdf_download_volume(self._c, _fp(out)))
+        return out
+
+    def set_tsdf(self, v):
+        v = _f32(v)
+        assert v.size == self.res[0] * self.res[1] * self.res[2]
+        self._ck(self._L.tsdf_upload_volume(self._c, _fp(v)))
+
+    def bricks(self):
+        n = self.numBricks()
+        cnt, fl = np.empty(n, np.uint32), np.empty(n, np.uint8)
+        self._ck(self._L.tsdf_download_bricks(self._c, cnt.ctypes.data_as(C.POINTER(C.c_uint32)), fl.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return cnt, fl
+
+    def set_counters(self, a):
+        a = np.ascontiguousarray(a, np.uint32)
+        assert a.size == self.numBricks()
+        self._ck(self._L.tsdf_upload_brick_counters(self._c, a.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+    def view_images(self):
+        w, h = self.view
+        rgba, d, ns, pe = np.empty((h, w, 4), np.float32), np.empty((h, w), np.float32), np.empty((h, w), np.float32), np.empty((h, w, 4), np.float32)
+        self._ck(self._L.tsdf_download_image(self._c, _fp(rgba), _fp(d), _fp(ns), _fp(pe)))
+        return rgba, d, ns, pe
+
+    def set_view_images(self, rgba, depth):
+        self._ck(self._L.tsdf_upload_image(self._c, _fp(_f32(rgba)), _fp(_f32(depth))))
+
+    def framebuffer(self):
+        w, h = self.view
+        rgba, d = np.empty((h, w, 4), np.float32), np.empty((h, w), np.float32)
+        self._ck(self._L.tsdf_download_framebuffer(self._c, _fp(rgba), _fp(d)))
+        return rgba, d
+
+    def atlas(self):
+        w, h = self.view
+        aw = int(np.float32(w) * np.float32(1.5))
+        rgba, d = np.empty((h, aw, 4), np.float32), np.empty((h, aw), np.float32)
+        self._ck(self._L.tsdf_download_atlas(self._c, _fp(rgba), _fp(d)))
+        return rgba, d
+
+    # ------------------------------------------------------------------ timers / multi-GPU hooks
+    def enable_timers(self, on=True): self._ck(self._L.tsdf_enable_timers(self._c, int(on)))
+
+    def timer_ms(self, name):
+        ms = C.c_float()
+        self._ck(self._L.tsdf_timer_ms(self._c, name.encode(), C.byref(ms)))
+        return ms.value
+
+    def halo_info(self):
+        layers, nbytes = C.c_uint32(), C.c_uint64()
+        self._ck(self._L.tsdf_halo_info(self._c, C.byref(layers), C.byref(nbytes)))
+        return layers.value, nbytes.value
+
+    def halo_pack_dev(self, lo_ptr, hi_ptr):
+        self._ck(self._L.tsdf_halo_pack_dev(self._c, C.c_void_p(lo_ptr), C.c_void_p(hi_ptr)))
+
+    def halo_unpack_dev(self, below_ptr, above_ptr):
+        self._ck(self._L.tsdf_halo_unpack_dev(self._c, C.c_void_p(below_ptr), C.c_void_p(above_ptr)))
+
+    def export_partial_dev(self, dst_ptr):
+        self._ck(self._L.tsdf_export_partial_dev(self._c, C.c_void_p(dst_ptr)))
+
+    def composite_dev(self, gathered_ptr, n):
+        self._ck(self._L.tsdf_composite_dev(self._c, C.c_void_p(gathered_ptr), int(n)))

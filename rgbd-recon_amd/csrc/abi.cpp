@@ -1,0 +1,725 @@
+// C-ABI implementation (include/rgbd_recon_hip.h): host-side state of the HIP TSDF core.
+// Mirrors the host logic of kinect::ReconIntegration (framework/reconstruction/recon_integration.cpp):
+// setVoxelSize/setBrickSize/divideBox (:340-406,:462-472), draw() matrix set-up (:182-205),
+// ViewLod::setResolution (framework/rendering/view_lod.cpp:24-50), the per-frame call order of
+// source/kinect_client.cpp:569-599,614.  All device work goes to one HIP stream.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "tsdf_common.hpp"
+
+using namespace rr;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct Timer { hipEvent_t a = nullptr, b = nullptr; bool recorded = false; };
+
+struct BrickRange { uint32_t lo[3], hi[3]; };
+}  // namespace
+
+struct tsdf_ctx {
+  tsdf_config cfg{};
+  std::string err;
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  // volume
+  int res[3]{};
+  float vox[3]{};
+  Volume vol{};
+  int halo_layers = 0;
+  // bricks
+  float brick_req[3]{};          // requested size (setBrickSize argument)
+  Bricks br{};
+  std::vector<BrickRange> ranges;
+  uint16_t* d_vox_first[3]{};
+  uint8_t* d_vox_count[3]{};
+  uint32_t min_voxels = 10;      // recon_integration.cpp:59
+  uint32_t* h_num_occupied = nullptr;   // pinned
+  // calibration + frame
+  StreamTable luts{};
+  std::vector<void*> lut_allocs;
+  bool have_calib[TSDF_MAX_STREAMS]{};
+  FrameImages frame{};
+  float* d_stage_depth = nullptr; float* d_stage_q = nullptr; float* d_stage_s = nullptr; uint8_t* d_stage_col = nullptr;
+  bool have_frame = false;
+  // view
+  int vw = 0, vh = 0;
+  Atlas atlas{};
+  float4* d_peels = nullptr; float* d_nsamples = nullptr;
+  float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
+  float* d_linear = nullptr;     // scratch for volume up/download
+  // flags (recon_integration.cpp:54-57)
+  bool fill_holes = true, use_bricks = true, skip_space = true;
+  int shade_mode = 0;
+  bool timers_on = false;
+  std::map<std::string, Timer> timers;
+};
+
+#define CHECK_CTX(c) do { if (!(c)) return TSDF_ERR_INVALID_ARGUMENT; } while (0)
+#define FAIL(c, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (c)->err = _b; return (code); } while (0)
+#define HIP_TRY(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { FAIL(c, _e == hipErrorOutOfMemory ? TSDF_ERR_OUT_OF_MEMORY : TSDF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
+
+namespace {
+
+// ---- small double-precision matrix kit (column-major), results rounded once to float
+void mat_mul_d(const double* a, const double* b, double* o) {
+  double r[16];
+  for (int c = 0; c < 4; ++c)
+    for (int row = 0; row < 4; ++row) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[k * 4 + row] * b[c * 4 + k];
+      r[c * 4 + row] = s;
+    }
+  memcpy(o, r, sizeof(r));
+}
+// Gauss-Jordan with partial pivoting on [M | I]
+bool mat_inv_d(const double* m, double* o) {
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) { a[r][c] = m[c * 4 + r]; a[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+    if (a[piv][col] == 0.0) return false;
+    if (piv != col) for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[col][k]);
+    const double inv = 1.0 / a[col][col];
+    for (int k = 0; k < 8; ++k) a[col][k] *= inv;
+    for (int r = 0; r < 4; ++r) if (r != col) {
+      const double f = a[r][col];
+      if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[col][k];
+    }
+  }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) o[c * 4 + r] = a[r][4 + c];
+  return true;
+}
+Mat4 to_mat4(const double* d) { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (float)d[i]; return r; }
+
+void release_view(tsdf_ctx* c) {
+  hipFree(c->atlas.color); hipFree(c->atlas.depth); hipFree(c->d_peels); hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
+  c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
+}
+void release_bricks(tsdf_ctx* c) {
+  hipFree(c->br.counters); hipFree(c->br.flags); hipFree(c->br.num_occupied);
+  c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr;
+  for (int a = 0; a < 3; ++a) { hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); c->d_vox_first[a] = nullptr; c->d_vox_count[a] = nullptr; }
+}
+
+// ViewLod::setResolution, view_lod.cpp:24-50; resize(), recon_integration.cpp:482-500
+int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
+  if (w < 2 || h < 2 || w > 16384 || h > 16384) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "view size %ux%u out of range", w, h);
+  release_view(c);
+  c->vw = (int)w; c->vh = (int)h;
+  Atlas& A = c->atlas;
+  A.num_lods = 1 + (int)floorf(log2f((float)std::min(w, h)));
+  if (A.num_lods > TSDF_MAX_LODS) A.num_lods = TSDF_MAX_LODS;
+  A.aw = (int)((float)w * 1.5f);
+  A.h = (int)h;
+  int ox = (int)w, oy = (int)h;
+  for (int i = 0; i < TSDF_MAX_LODS; ++i) { A.off[i][0] = A.off[i][1] = A.res[i][0] = A.res[i][1] = 0; }
+  for (int i = 0; i < A.num_lods; ++i) {
+    A.res[i][0] = (int)floorf((float)w / powf(2.0f, (float)i));
+    A.res[i][1] = (int)floorf((float)h / powf(2.0f, (float)i));
+    if (i > 0) { oy -= A.res[i][1]; A.off[i][0] = ox; A.off[i][1] = oy; }
+  }
+  const size_t na = (size_t)A.aw * A.h, nv = (size_t)w * h;
+  HIP_TRY(c, hipMalloc(&A.color, na * sizeof(float4)));
+  HIP_TRY(c, hipMalloc(&A.depth, na * sizeof(float)));
+  HIP_TRY(c, hipMalloc(&c->d_peels, nv * sizeof(float4)));
+  HIP_TRY(c, hipMalloc(&c->d_nsamples, nv * sizeof(float)));
+  HIP_TRY(c, hipMalloc(&c->d_fb_c, nv * sizeof(float4)));
+  HIP_TRY(c, hipMalloc(&c->d_fb_d, nv * sizeof(float)));
+  // the atlas starts as ViewLod::enable() leaves it (colour (0,1,0,0), depth 1); regions no kernel writes keep that
+  launch_clear_image(c->stream, A.color, A.depth, na, make_float4(0.0f, 1.0f, 0.0f, 0.0f), 1.0f);
+  launch_clear_image(c->stream, c->d_fb_c, c->d_fb_d, nv, make_float4(0, 0, 0, 0), 1.0f);
+  HIP_TRY(c, hipMemsetAsync(c->d_peels, 0, nv * sizeof(float4), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_nsamples, 0, nv * sizeof(float), c->stream));
+  return TSDF_OK;
+}
+
+// setBrickSize + divideBox, recon_integration.cpp:462-472, :360-406, with the per-brick voxel lists of
+// VolumeSampler::containedVoxels (volume_sampler.cpp:50-62) kept as per-axis ranges.
+int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
+  for (int a = 0; a < 3; ++a) if (!(req[a] > 0.0f)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "brick size must be > 0");
+  release_bricks(c);
+  memcpy(c->brick_req, req, sizeof(float) * 3);
+  Bricks& B = c->br;
+  const float bmin[3] = {c->cfg.bbox_min[0], c->cfg.bbox_min[1], c->cfg.bbox_min[2]};
+  float ext[3];
+  for (int a = 0; a < 3; ++a) {
+    ext[a] = c->cfg.bbox_max[a] - c->cfg.bbox_min[a];
+    B.size[a] = c->vox[a] * roundf(req[a] / c->vox[a]);                 // :463
+    if (!(B.size[a] > 0.0f)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "brick size %g rounds to zero voxels", req[a]);
+    B.bbox_min[a] = bmin[a];
+  }
+  // the three nested while loops of divideBox() are separable: per axis, the sequence of brick starts
+  std::vector<float> starts[3];
+  for (int a = 0; a < 3; ++a) {
+    float s = bmin[a];
+    while (ext[a] - s + bmin[a] > 0.0f) {                               // :366-368
+      starts[a].push_back(s);
+      s += B.size[a];                                                   // :373,:379,:385
+      if (starts[a].size() > 65535) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "more than 65535 bricks along one axis");
+    }
+    B.res[a] = (int)starts[a].size();
+  }
+  B.n = B.res[0] * B.res[1] * B.res[2];
+  // containedVoxels(): for (v = pos/step; v < (pos+size)/step; ++v), all in float
+  std::vector<uint16_t> first[3];
+  std::vector<uint8_t> count[3];
+  for (int a = 0; a < 3; ++a) {
+    const float step = 1.0f / (float)c->res[a];
+    first[a].assign(c->res[a], 0); count[a].assign(c->res[a], 0);
+    for (size_t b = 0; b < starts[a].size(); ++b) {
+      const float bs = std::min(B.size[a], ext[a] - starts[a][b] + bmin[a]);   // :369 glm::min(brick, size - start + min)
+      const float pos = (starts[a][b] - bmin[a]) / ext[a], sz = bs / ext[a];   // :371
+      unsigned v = (unsigned)(pos / step);
+      for (; (float)v < (pos + sz) / step; ++v) {
+        if (v >= (unsigned)c->res[a]) break;
+        if (count[a][v] == 0) first[a][v] = (uint16_t)b;
+        if (count[a][v] == 255 || (unsigned)first[a][v] + count[a][v] != b) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "degenerate brick/voxel overlap on axis %d", a);
+        count[a][v]++;
+      }
+    }
+    HIP_TRY(c, hipMalloc(&c->d_vox_first[a], c->res[a] * sizeof(uint16_t)));
+    HIP_TRY(c, hipMalloc(&c->d_vox_count[a], c->res[a] * sizeof(uint8_t)));
+    HIP_TRY(c, hipMemcpy(c->d_vox_first[a], first[a].data(), c->res[a] * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_vox_count[a], count[a].data(), c->res[a] * sizeof(uint8_t), hipMemcpyHostToDevice));
+    B.vox_first[a] = c->d_vox_first[a];
+    B.vox_count[a] = c->d_vox_count[a];
+  }
+  HIP_TRY(c, hipMalloc(&B.counters, (size_t)B.n * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&B.flags, (size_t)B.n));
+  HIP_TRY(c, hipMalloc(&B.num_occupied, sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(B.counters, 0, (size_t)B.n * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(B.flags, 0, (size_t)B.n));
+  HIP_TRY(c, hipMemset(B.num_occupied, 0, sizeof(uint32_t)));
+  return TSDF_OK;
+}
+
+void timer_begin(tsdf_ctx* c, const char* name) {
+  if (!c->timers_on) return;
+  Timer& t = c->timers[name];
+  if (!t.a) { hipEventCreate(&t.a); hipEventCreate(&t.b); }
+  hipEventRecord(t.a, c->stream);
+}
+void timer_end(tsdf_ctx* c, const char* name) {
+  if (!c->timers_on) return;
+  Timer& t = c->timers[name];
+  if (!t.a) return;
+  hipEventRecord(t.b, c->stream);
+  t.recorded = true;
+}
+
+// draw() matrix block, recon_integration.cpp:182-205 (+ vol_to_world :66-72)
+bool make_view_params(const tsdf_ctx* c, const float* mv16, const float* pr16, ViewParams* P) {
+  double mv[16], pr[16], v2w[16] = {0}, sc[16] = {0}, tr[16] = {0}, t0[16], t1[16];
+  for (int i = 0; i < 16; ++i) { mv[i] = mv16[i]; pr[i] = pr16[i]; }
+  for (int a = 0; a < 3; ++a) {
+    v2w[a * 5] = (double)(c->cfg.bbox_max[a] - c->cfg.bbox_min[a]);    // float subtraction like :66-68
+    v2w[12 + a] = c->cfg.bbox_min[a];
+  }
+  v2w[15] = 1.0;
+  memcpy(P->mv.m, mv16, 64); memcpy(P->proj.m, pr16, 64);
+  if (!mat_inv_d(v2w, t0)) return false;
+  P->v2w_inv = to_mat4(t0);
+  double mvi[16];
+  if (!mat_inv_d(mv, mvi)) return false;
+  P->mv_inv = to_mat4(mvi);
+  sc[0] = c->vw * 0.5; sc[5] = c->vh * 0.5; sc[10] = 0.5; sc[15] = 1.0;                  // :187-191
+  tr[0] = tr[5] = tr[10] = tr[15] = 1.0; tr[12] = tr[13] = tr[14] = 1.0;                 // :184-186
+  mat_mul_d(tr, pr, t0); mat_mul_d(sc, t0, t1);
+  if (!mat_inv_d(t1, t0)) return false;
+  P->img_to_eye = to_mat4(t0);                                                            // :192-194
+  double m[16], mi[16], mit[16];
+  mat_mul_d(mv, v2w, m);
+  P->mv_v2w = to_mat4(m);
+  if (!mat_inv_d(m, mi)) return false;
+  for (int col = 0; col < 4; ++col) for (int r = 0; r < 4; ++r) mit[col * 4 + r] = mi[r * 4 + col];
+  P->normal = to_mat4(mit);                                                               // :199
+  double mvt[16];
+  for (int col = 0; col < 4; ++col) for (int r = 0; r < 4; ++r) mvt[col * 4 + r] = mv[r * 4 + col];
+  P->glnormal_inv = to_mat4(mvt);                    // inverse(inverseTranspose(MV)), shading.glsl:65
+  // camera position: inverse(MV) * (0,0,0,1), then inverse(vol_to_world) * that, in fp32 on rounded matrices (:202-205)
+  const Mat4& I = P->mv_inv;
+  const float cw[4] = {I.m[12], I.m[13], I.m[14], I.m[15]};
+  for (int a = 0; a < 3; ++a) P->cam_world[a] = cw[a];
+  const Mat4& W = P->v2w_inv;
+  for (int r = 0; r < 3; ++r) P->cam_vol[r] = W.m[r] * cw[0] + W.m[4 + r] * cw[1] + W.m[8 + r] * cw[2] + W.m[12 + r] * cw[3];
+  P->w = c->vw; P->h = c->vh;
+  P->shade_mode = c->shade_mode;
+  P->skip = (c->skip_space && c->use_bricks) ? 1 : 0;                                     // :154, :510-513
+  return true;
+}
+
+RayTarget ray_target(tsdf_ctx* c) {
+  RayTarget R{};
+  if (c->fill_holes) { R.color = c->atlas.color; R.depth = c->atlas.depth; R.stride = c->atlas.aw; R.clear[0] = 0; R.clear[1] = 1; R.clear[2] = 0; R.clear[3] = 0; }
+  else { R.color = c->d_fb_c; R.depth = c->d_fb_d; R.stride = c->vw; R.clear[0] = R.clear[1] = R.clear[2] = R.clear[3] = 0; }
+  R.nsamples = c->d_nsamples;
+  R.peels = c->d_peels;
+  return R;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tsdf_last_error(const tsdf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
+  if (!cfg || !out) { g_create_error = "null argument"; return TSDF_ERR_INVALID_ARGUMENT; }
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(tsdf_config)) { g_create_error = "tsdf_config.struct_size mismatch"; return TSDF_ERR_INVALID_ARGUMENT; }
+  if (cfg->num_streams < 1 || cfg->num_streams > TSDF_MAX_STREAMS) { g_create_error = "num_streams out of range"; return TSDF_ERR_INVALID_ARGUMENT; }
+  if (!(cfg->limit > 0.0f)) { g_create_error = "limit must be > 0"; return TSDF_ERR_INVALID_ARGUMENT; }
+  for (int a = 0; a < 3; ++a)
+    if (!(cfg->bbox_max[a] > cfg->bbox_min[a])) { g_create_error = "empty bounding box"; return TSDF_ERR_INVALID_ARGUMENT; }
+  if (cfg->depth_w < 1 || cfg->depth_h < 1 || cfg->color_w < 1 || cfg->color_h < 1) { g_create_error = "image size must be >= 1"; return TSDF_ERR_INVALID_ARGUMENT; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible (the HIP path has no CPU fallback)"; return TSDF_ERR_NO_DEVICE; }
+  if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return TSDF_ERR_INVALID_ARGUMENT; }
+  tsdf_ctx* c = new tsdf_ctx();
+  c->cfg = *cfg;
+  c->device = cfg->device;
+  auto fail = [&](int32_t code) { g_create_error = c->err; tsdf_destroy(c); return code; };
+  if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(TSDF_ERR_HIP); }
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
+  c->stream = c->own_stream;
+  // setVoxelSize(), :340-347
+  for (int a = 0; a < 3; ++a) {
+    const float ext = cfg->bbox_max[a] - cfg->bbox_min[a];
+    if (cfg->res[0] == 0) {
+      if (!(cfg->voxel_size > 0.0f)) { c->err = "voxel_size must be > 0 when res is not given"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+      c->res[a] = (int)ceilf(ext / cfg->voxel_size);
+      c->vox[a] = cfg->voxel_size;
+    } else {
+      c->res[a] = (int)cfg->res[a];
+      c->vox[a] = ext / (float)cfg->res[a];
+    }
+    if (c->res[a] < 1 || c->res[a] > 4096) { c->err = "volume resolution out of range [1, 4096]"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+  }
+  Volume& V = c->vol;
+  for (int a = 0; a < 3; ++a) V.res[a] = c->res[a];
+  V.ntx = (c->res[0] + 7) / 8; V.nty = (c->res[1] + 7) / 8;
+  const int ntz = (c->res[2] + 7) / 8;
+  V.limit = cfg->limit;
+  uint32_t z0 = cfg->slab_z0, z1 = cfg->slab_z1;
+  if (z0 == 0 && z1 == 0) z1 = (uint32_t)c->res[2];
+  if (z1 > (uint32_t)c->res[2] || z0 >= z1 || (z0 % 8) != 0 || (z1 % 8 != 0 && z1 != (uint32_t)c->res[2])) { c->err = "slab range must be tile (8) aligned and inside the volume"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+  V.own_tz0 = (int)z0 / 8; V.own_tz1 = ((int)z1 + 7) / 8;
+  // trilinear + gradient taps reach limit/2 (in unit-cube z) + one voxel past a slab face
+  c->halo_layers = (int)ceilf((cfg->limit * 0.5f * (float)c->res[2] + 2.0f) / 8.0f);
+  const bool whole = (V.own_tz0 == 0 && V.own_tz1 == ntz);
+  V.tz0 = whole ? 0 : std::max(0, V.own_tz0 - c->halo_layers);
+  V.tz1 = whole ? ntz : std::min(ntz, V.own_tz1 + c->halo_layers);
+  if (!whole && V.own_tz1 - V.own_tz0 < c->halo_layers) { c->err = "slab thinner than its halo"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+  const size_t nvox = (size_t)(V.tz1 - V.tz0) * V.nty * V.ntx * TILE_VOX;
+  int32_t rc;
+  auto tryhip = [&](hipError_t e, const char* what) -> int32_t {
+    if (e == hipSuccess) return TSDF_OK;
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? TSDF_ERR_OUT_OF_MEMORY : TSDF_ERR_HIP;
+  };
+  if ((rc = tryhip(hipMalloc(&V.data, nvox * sizeof(float)), "hipMalloc(volume)"))) return fail(rc);
+  launch_fill_u32(c->stream, (uint32_t*)V.data, 0u, nvox);
+  if ((rc = tryhip(hipHostMalloc((void**)&c->h_num_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc"))) return fail(rc);
+  *c->h_num_occupied = 0;
+  if ((rc = setup_bricks(c, cfg->brick_size))) return fail(rc);
+  // frame images
+  FrameImages& F = c->frame;
+  F.w = (int)cfg->depth_w; F.h = (int)cfg->depth_h; F.cw = (int)cfg->color_w; F.ch = (int)cfg->color_h;
+  const size_t np = (size_t)cfg->num_streams * F.w * F.h, nc = (size_t)cfg->num_streams * F.cw * F.ch;
+  if ((rc = tryhip(hipMalloc((void**)&F.dqs, np * sizeof(float4)), "hipMalloc(frame)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc((void**)&F.color, nc * sizeof(uchar4)), "hipMalloc(colour)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&c->d_stage_depth, np * 8), "hipMalloc(stage)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&c->d_stage_q, np * 4), "hipMalloc(stage)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&c->d_stage_s, np * 4), "hipMalloc(stage)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&c->d_stage_col, nc * 3), "hipMalloc(stage)"))) return fail(rc);
+  hipMemsetAsync((void*)F.color, 0, nc * sizeof(uchar4), c->stream);
+  c->luts.n = (int)cfg->num_streams;
+  if ((rc = setup_view(c, cfg->view_w, cfg->view_h))) return fail(rc);
+  if ((rc = tryhip(hipStreamSynchronize(c->stream), "hipStreamSynchronize"))) return fail(rc);
+  *out = c;
+  return TSDF_OK;
+}
+
+int32_t tsdf_destroy(tsdf_ctx* c) {
+  CHECK_CTX(c);
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  release_view(c); release_bricks(c);
+  hipFree(c->vol.data); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
+  hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
+  for (void* p : c->lut_allocs) hipFree(p);
+  if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
+  for (auto& kv : c->timers) { if (kv.second.a) hipEventDestroy(kv.second.a); if (kv.second.b) hipEventDestroy(kv.second.b); }
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  delete c;
+  return TSDF_OK;
+}
+
+int32_t tsdf_set_stream(tsdf_ctx* c, void* s) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return TSDF_OK;
+}
+int32_t tsdf_sync(tsdf_ctx* c) { CHECK_CTX(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return TSDF_OK; }
+
+int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const uint32_t ri[3], const float* uv, const uint32_t ru[3], const float* xyz, const uint32_t rx[3]) {
+  CHECK_CTX(c);
+  if (i >= c->cfg.num_streams) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "stream %u out of range", i);
+  if (!inv || !ri) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_xyz_inv is required");
+  HIP_TRY(c, hipSetDevice(c->device));
+  StreamLut& L = c->luts.s[i];
+  auto vol_n = [](const uint32_t r[3]) { return (size_t)r[0] * r[1] * r[2]; };
+  for (int a = 0; a < 3; ++a) if (ri[a] < 1 || ri[a] > 2048) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "LUT resolution out of range");
+  float4* d_inv = nullptr;
+  HIP_TRY(c, hipMalloc(&d_inv, vol_n(ri) * sizeof(float4)));
+  c->lut_allocs.push_back(d_inv);
+  HIP_TRY(c, hipMemcpy(d_inv, inv, vol_n(ri) * sizeof(float4), hipMemcpyHostToDevice));
+  L.inv = d_inv; for (int a = 0; a < 3; ++a) L.inv_res[a] = (int)ri[a];
+  if (uv) {
+    if (!ru) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_uv resolution missing");
+    float2* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, vol_n(ru) * sizeof(float2)));
+    c->lut_allocs.push_back(d);
+    HIP_TRY(c, hipMemcpy(d, uv, vol_n(ru) * sizeof(float2), hipMemcpyHostToDevice));
+    L.uv = d; for (int a = 0; a < 3; ++a) L.uv_res[a] = (int)ru[a];
+  }
+  if (xyz) {
+    if (!rx) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_xyz resolution missing");
+    const size_t n = vol_n(rx);
+    std::vector<float> padded(n * 4);
+    for (size_t k = 0; k < n; ++k) { padded[4 * k] = xyz[3 * k]; padded[4 * k + 1] = xyz[3 * k + 1]; padded[4 * k + 2] = xyz[3 * k + 2]; padded[4 * k + 3] = 0.0f; }
+    float4* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, n * sizeof(float4)));
+    c->lut_allocs.push_back(d);
+    HIP_TRY(c, hipMemcpy(d, padded.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    L.xyz = d; for (int a = 0; a < 3; ++a) L.xyz_res[a] = (int)rx[a];
+  }
+  c->have_calib[i] = true;
+  return TSDF_OK;
+}
+
+int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour) {
+  CHECK_CTX(c);
+  if (!depth_rg || !quality || !silhouette) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "depth, quality and silhouette are required");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const FrameImages& F = c->frame;
+  const size_t np = (size_t)c->cfg.num_streams * F.w * F.h, nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_depth, depth_rg, np * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_q, quality, np * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_s, silhouette, np * 4, hipMemcpyHostToDevice, c->stream));
+  launch_pack_frame(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, np);
+  if (colour) {
+    HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
+    launch_pack_color(c->stream, c->d_stage_col, (uchar4*)F.color, nc);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->have_frame = true;
+  return TSDF_OK;
+}
+
+static int32_t require_inputs(tsdf_ctx* c, bool need_xyz, bool need_uv) {
+  if (!c->have_frame) FAIL(c, TSDF_ERR_STATE, "no frame uploaded (tsdf_upload_frame)");
+  for (uint32_t i = 0; i < c->cfg.num_streams; ++i) {
+    if (!c->have_calib[i]) FAIL(c, TSDF_ERR_STATE, "stream %u has no calibration (tsdf_set_calibration)", i);
+    if (need_xyz && !c->luts.s[i].xyz) FAIL(c, TSDF_ERR_STATE, "stream %u has no cv_xyz volume", i);
+    if (need_uv && !c->luts.s[i].uv) FAIL(c, TSDF_ERR_STATE, "stream %u has no cv_uv volume", i);
+  }
+  return TSDF_OK;
+}
+
+int32_t tsdf_clear_bricks(tsdf_ctx* c) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  timer_begin(c, "bricks");
+  HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, (size_t)c->br.n * sizeof(uint32_t), c->stream));
+  return TSDF_OK;
+}
+int32_t tsdf_mark_bricks(tsdf_ctx* c) {
+  CHECK_CTX(c);
+  int32_t rc = require_inputs(c, true, false);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  launch_mark_bricks(c->stream, c->luts, c->frame, c->br);
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  launch_update_occupied(c->stream, c->br, c->min_voxels);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->h_num_occupied, c->br.num_occupied, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  timer_end(c, "bricks");
+  if (ratio) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *ratio = (float)*c->h_num_occupied / (float)c->br.n;               // :440
+  }
+  return TSDF_OK;
+}
+int32_t tsdf_occupied_ratio(tsdf_ctx* c, float* ratio) {
+  CHECK_CTX(c);
+  if (!ratio) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *ratio = (float)*c->h_num_occupied / (float)c->br.n;
+  return TSDF_OK;
+}
+
+int32_t tsdf_integrate(tsdf_ctx* c) {
+  CHECK_CTX(c);
+  int32_t rc = require_inputs(c, false, false);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  timer_begin(c, "2integrate");
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->use_bricks ? 1 : 0);
+  timer_end(c, "2integrate");
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+
+static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool outer_timer) {
+  if (!mv || !pr) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "null matrix");
+  int32_t rc = require_inputs(c, false, c->shade_mode != 3);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  ViewParams P;
+  if (!make_view_params(c, mv, pr, &P)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "singular modelview / projection matrix");
+  if (outer_timer) timer_begin(c, "3recon");
+  if (P.skip) {
+    timer_begin(c, "brickdraw");
+    launch_depth_limits(c->stream, P, c->br, c->d_peels);
+    timer_end(c, "brickdraw");
+  }
+  const bool partial = !(c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
+  timer_begin(c, "draw");
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, ray_target(c), partial ? 1 : 0);
+  timer_end(c, "draw");
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+int32_t tsdf_raymarch(tsdf_ctx* c, const float* mv, const float* pr) {
+  CHECK_CTX(c);
+  int32_t rc = raymarch_impl(c, mv, pr, true);
+  if (rc == TSDF_OK) timer_end(c, "3recon");
+  return rc;
+}
+int32_t tsdf_fill_colors(tsdf_ctx* c) {
+  CHECK_CTX(c);
+  if (!c->fill_holes) FAIL(c, TSDF_ERR_STATE, "colour filling is off: the raymarch did not render into the pyramid");
+  HIP_TRY(c, hipSetDevice(c->device));
+  timer_begin(c, "holefill");
+  for (int i = 1; i < c->atlas.num_lods; ++i) launch_inpaint_level(c->stream, c->atlas, i - 1);
+  launch_colorfill(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d);
+  timer_end(c, "holefill");
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+int32_t tsdf_draw_f(tsdf_ctx* c, const float* mv, const float* pr) {
+  CHECK_CTX(c);
+  int32_t rc = raymarch_impl(c, mv, pr, true);
+  if (rc) return rc;
+  if (c->fill_holes && (rc = tsdf_fill_colors(c))) return rc;
+  timer_end(c, "3recon");
+  return TSDF_OK;
+}
+
+// ---- setters
+int32_t tsdf_set_tsdf_limit(tsdf_ctx* c, float limit) {
+  CHECK_CTX(c);
+  if (!(limit > 0.0f)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit must be > 0");
+  const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
+  if (!whole && (int)ceilf((limit * 0.5f * (float)c->res[2] + 2.0f) / 8.0f) > c->halo_layers) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit needs a wider slab halo than this context allocated");
+  c->vol.limit = limit;
+  return TSDF_OK;
+}
+int32_t tsdf_set_use_bricks(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->use_bricks = a != 0; return TSDF_OK; }
+int32_t tsdf_set_space_skip(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->skip_space = a != 0; return TSDF_OK; }
+int32_t tsdf_set_color_filling(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->fill_holes = a != 0; return TSDF_OK; }
+int32_t tsdf_set_min_voxels_per_brick(tsdf_ctx* c, uint32_t n) { CHECK_CTX(c); c->min_voxels = n; return TSDF_OK; }
+int32_t tsdf_set_shade_mode(tsdf_ctx* c, int32_t m) {
+  CHECK_CTX(c);
+  if (m < 0 || m > 3) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "shade mode must be 0..3");
+  c->shade_mode = m;
+  return TSDF_OK;
+}
+int32_t tsdf_set_brick_size(tsdf_ctx* c, const float size[3]) {
+  CHECK_CTX(c);
+  if (!size) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return setup_bricks(c, size);
+}
+int32_t tsdf_resize(tsdf_ctx* c, uint32_t w, uint32_t h) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int32_t rc = setup_view(c, w, h);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSDF_OK;
+}
+
+// ---- getters
+int32_t tsdf_get_resolution(const tsdf_ctx* c, uint32_t res[3], uint32_t rb[3], float bs[3]) {
+  CHECK_CTX(c);
+  for (int a = 0; a < 3; ++a) { if (res) res[a] = (uint32_t)c->res[a]; if (rb) rb[a] = (uint32_t)c->br.res[a]; if (bs) bs[a] = c->br.size[a]; }
+  return TSDF_OK;
+}
+int32_t tsdf_num_bricks(const tsdf_ctx* c, uint32_t* n) { CHECK_CTX(c); if (!n) return TSDF_ERR_INVALID_ARGUMENT; *n = (uint32_t)c->br.n; return TSDF_OK; }
+int32_t tsdf_num_lods(const tsdf_ctx* c, uint32_t* n) { CHECK_CTX(c); if (!n) return TSDF_ERR_INVALID_ARGUMENT; *n = (uint32_t)c->atlas.num_lods; return TSDF_OK; }
+
+// ---- downloads / uploads
+static int32_t need_linear(tsdf_ctx* c) {
+  if (!c->d_linear) HIP_TRY(c, hipMalloc(&c->d_linear, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float)));
+  return TSDF_OK;
+}
+int32_t tsdf_download_volume(tsdf_ctx* c, float* out) {
+  CHECK_CTX(c);
+  if (!out) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t rc = need_linear(c);
+  if (rc) return rc;
+  launch_volume_to_linear(c->stream, c->vol, c->d_linear);
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_linear, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSDF_OK;
+}
+int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
+  CHECK_CTX(c);
+  if (!in) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t rc = need_linear(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_linear, in, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  launch_volume_from_linear(c->stream, c->vol, c->d_linear);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSDF_OK;
+}
+int32_t tsdf_download_bricks(tsdf_ctx* c, uint32_t* counters, uint8_t* flags) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (counters) HIP_TRY(c, hipMemcpy(counters, c->br.counters, (size_t)c->br.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (flags) HIP_TRY(c, hipMemcpy(flags, c->br.flags, (size_t)c->br.n, hipMemcpyDeviceToHost));
+  return TSDF_OK;
+}
+int32_t tsdf_upload_brick_counters(tsdf_ctx* c, const uint32_t* counters) {
+  CHECK_CTX(c);
+  if (!counters) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(c->br.counters, counters, (size_t)c->br.n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return TSDF_OK;
+}
+int32_t tsdf_download_image(tsdf_ctx* c, float* rgba, float* depth, float* ns, float* peels) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const RayTarget R = ray_target(c);
+  const size_t w = (size_t)c->vw, h = (size_t)c->vh;
+  if (rgba) HIP_TRY(c, hipMemcpy2D(rgba, w * 16, R.color, (size_t)R.stride * 16, w * 16, h, hipMemcpyDeviceToHost));
+  if (depth) HIP_TRY(c, hipMemcpy2D(depth, w * 4, R.depth, (size_t)R.stride * 4, w * 4, h, hipMemcpyDeviceToHost));
+  if (ns) HIP_TRY(c, hipMemcpy(ns, c->d_nsamples, w * h * 4, hipMemcpyDeviceToHost));
+  if (peels) HIP_TRY(c, hipMemcpy(peels, c->d_peels, w * h * 16, hipMemcpyDeviceToHost));
+  return TSDF_OK;
+}
+int32_t tsdf_upload_image(tsdf_ctx* c, const float* rgba, const float* depth) {
+  CHECK_CTX(c);
+  if (!rgba || !depth) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const RayTarget R = ray_target(c);
+  const size_t w = (size_t)c->vw, h = (size_t)c->vh;
+  HIP_TRY(c, hipMemcpy2D(R.color, (size_t)R.stride * 16, rgba, w * 16, w * 16, h, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy2D(R.depth, (size_t)R.stride * 4, depth, w * 4, w * 4, h, hipMemcpyHostToDevice));
+  return TSDF_OK;
+}
+int32_t tsdf_download_framebuffer(tsdf_ctx* c, float* rgba, float* depth) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)c->vw * c->vh;
+  if (rgba) HIP_TRY(c, hipMemcpy(rgba, c->d_fb_c, n * 16, hipMemcpyDeviceToHost));
+  if (depth) HIP_TRY(c, hipMemcpy(depth, c->d_fb_d, n * 4, hipMemcpyDeviceToHost));
+  return TSDF_OK;
+}
+int32_t tsdf_download_atlas(tsdf_ctx* c, float* rgba, float* depth) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)c->atlas.aw * c->atlas.h;
+  if (rgba) HIP_TRY(c, hipMemcpy(rgba, c->atlas.color, n * 16, hipMemcpyDeviceToHost));
+  if (depth) HIP_TRY(c, hipMemcpy(depth, c->atlas.depth, n * 4, hipMemcpyDeviceToHost));
+  return TSDF_OK;
+}
+
+// ---- multi-GPU hooks
+int32_t tsdf_halo_info(const tsdf_ctx* c, uint32_t* layers, uint64_t* bytes) {
+  CHECK_CTX(c);
+  if (layers) *layers = (uint32_t)c->halo_layers;
+  if (bytes) *bytes = (uint64_t)c->halo_layers * c->vol.nty * c->vol.ntx * TILE_VOX * sizeof(float);
+  return TSDF_OK;
+}
+int32_t tsdf_halo_pack_dev(tsdf_ctx* c, void* lo, void* hi) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const Volume& V = c->vol;
+  const size_t layer = (size_t)V.nty * V.ntx * TILE_VOX, n = (size_t)c->halo_layers * layer * sizeof(float);
+  if (lo) HIP_TRY(c, hipMemcpyAsync(lo, V.data + (size_t)(V.own_tz0 - V.tz0) * layer, n, hipMemcpyDeviceToDevice, c->stream));
+  if (hi) HIP_TRY(c, hipMemcpyAsync(hi, V.data + (size_t)(V.own_tz1 - c->halo_layers - V.tz0) * layer, n, hipMemcpyDeviceToDevice, c->stream));
+  return TSDF_OK;
+}
+int32_t tsdf_halo_unpack_dev(tsdf_ctx* c, const void* below, const void* above) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const Volume& V = c->vol;
+  const size_t layer = (size_t)V.nty * V.ntx * TILE_VOX;
+  if (below && V.tz0 < V.own_tz0) {
+    const int have = V.own_tz0 - V.tz0;        // < halo_layers only at the volume boundary: take the top `have` layers
+    HIP_TRY(c, hipMemcpyAsync(V.data, (const float*)below + (size_t)(c->halo_layers - have) * layer, (size_t)have * layer * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (above && V.tz1 > V.own_tz1) {
+    const int have = V.tz1 - V.own_tz1;
+    HIP_TRY(c, hipMemcpyAsync(V.data + (size_t)(V.own_tz1 - V.tz0) * layer, above, (size_t)have * layer * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  }
+  return TSDF_OK;
+}
+int32_t tsdf_export_partial_dev(tsdf_ctx* c, void* dst) {
+  CHECK_CTX(c);
+  if (!dst) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  launch_export_partial(c->stream, ray_target(c), c->vw, c->vh, dst);
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+int32_t tsdf_composite_dev(tsdf_ctx* c, const void* gathered, uint32_t n) {
+  CHECK_CTX(c);
+  if (!gathered || n < 1) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  launch_composite(c->stream, gathered, (int)n, ray_target(c), c->vw, c->vh);
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+
+// ---- timers
+int32_t tsdf_enable_timers(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->timers_on = a != 0; return TSDF_OK; }
+int32_t tsdf_timer_ms(tsdf_ctx* c, const char* name, float* ms) {
+  CHECK_CTX(c);
+  if (!name || !ms) return TSDF_ERR_INVALID_ARGUMENT;
+  auto it = c->timers.find(name);
+  if (it == c->timers.end() || !it->second.recorded) FAIL(c, TSDF_ERR_STATE, "timer '%s' has not run", name);
+  HIP_TRY(c, hipEventSynchronize(it->second.b));
+  HIP_TRY(c, hipEventElapsedTime(ms, it->second.a, it->second.b));
+  return TSDF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// K3 + K4 (+ K5' fused away): the hole-filling pyramid of fillColors(), recon_integration.cpp:279-338.
+//
+// The reference ping-pongs two 1.5w x h atlases: after the raymarch and after every pyramid level it
+// re-renders the whole atlas into a w-wide "squeezed" copy (framebuffer_transfer.fs:13-17, 10 full-screen
+// passes at 1280x720) and tsdf_inpaint.fs reads that copy with a 2/3 x-scale.  Here there is ONE atlas
+// and no copy: inpaint composes the squeeze mapping analytically (squeezed column s holds atlas column
+// floor(1.5 (s + .5))), and reproduces what the freshly cleared copy would contain for texels that were
+// not written yet.  Results are identical to the two-atlas sequence.
+#include "sampling.hpp"
+
+namespace rr {
+
+struct Texel { float4 c; float d; };
+
+// texelFetch from the squeezed copy S as it exists while level `lod + 1` is being built
+__device__ __forceinline__ Texel fetch_squeezed(const Atlas& A, int w, int lod, int s, int y) {
+  Texel t;
+  if (s < 0 || y < 0 || s >= A.aw || y >= A.h) {          // out-of-range texelFetch -> 0 (Appendix A)
+    t.c = make_float4(0, 0, 0, 0); t.d = 0.0f;
+    return t;
+  }
+  t.c = make_float4(0.0f, 1.0f, 0.0f, 0.0f); t.d = 1.0f;  // ViewLod::enable clear, view_lod.cpp:75-81
+  if (s >= w) return t;                                   // only the w-wide viewport of S is written
+  const float tu = ((float)s + 0.5f) / (float)w, tv = ((float)y + 0.5f) / (float)A.h;   // pass_TexCoord
+  const int c = (int)(tu * (float)A.aw), sy = (int)(tv * (float)A.h);                   // ivec2(pass_TexCoord * resolution_tex)
+  if (c >= w && !(lod >= 1 && sy >= A.off[lod][1])) return t;   // pyramid levels > lod: still cleared in the reference
+  if (c >= A.aw || sy >= A.h) { t.c = make_float4(0, 0, 0, 0); t.d = 0.0f; return t; }
+  const size_t o = (size_t)sy * A.aw + c;
+  t.c = A.color[o]; t.d = A.depth[o];
+  return t;
+}
+
+// tsdf_inpaint.fs:34-89 -- one thread per pixel of level lod + 1
+__global__ __launch_bounds__(256) void k_inpaint_level(Atlas A, int w, int lod) {
+  const int rx = A.res[lod + 1][0], ry = A.res[lod + 1][1], ox = A.off[lod + 1][0], oy = A.off[lod + 1][1];
+  const int lx0 = blockIdx.x * 16 + (threadIdx.x & 15), ly0 = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (lx0 >= rx || ly0 >= ry) return;
+  const int fx = ox + lx0, fy = oy + ly0;                 // gl_FragCoord (pixel_center_integer)
+  const float tcx = ((float)fx - (float)ox) / (float)rx, tcy = ((float)fy - (float)oy) / (float)ry;   // :37
+  const int lx = (int)((float)A.off[lod][0] + (float)A.res[lod][0] * tcx);                           // to_lod_pos, :30-32
+  const int ly = (int)((float)A.off[lod][1] + (float)A.res[lod][1] * tcy);
+  const int pxi = (int)((float)lx * (float)(2.0 / 3.0)), pyi = (int)((float)ly * 1.0f);               // :38
+  float depth_av = 0.0f;
+  int num = 0;
+  float4 smp[16];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      Texel t = fetch_squeezed(A, w, lod, pxi + x - 1, pyi + y - 1);                                  // :45-47
+      if (t.c.w <= 0.0f) t.c.x = -1.0f;
+      else { depth_av += t.d; ++num; }
+      smp[x + y * 4] = make_float4(t.c.x, t.c.y, t.c.z, t.d);
+    }
+  const size_t o = (size_t)fy * A.aw + fx;
+  if (num == 0) {                                                                                      // :59-68
+    const Texel t = fetch_squeezed(A, w, lod, pxi, pyi);
+    A.depth[o] = t.d;
+    A.color[o] = (t.d < 1.0f) ? make_float4(0.0f, 0.0f, 0.0f, -1.0f) : make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+    return;
+  }
+  depth_av /= (float)num;
+  float tr = 0.0f, tg = 0.0f, tb = 0.0f, td = 0.0f, tw = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (smp[i].x >= 0.0f && smp[i].w >= depth_av) {
+      tr += smp[i].x * 1.0f; tg += smp[i].y * 1.0f; tb += smp[i].z * 1.0f; td += smp[i].w * 1.0f; tw += 1.0f;
+    }
+  A.color[o] = make_float4(tr / tw, tg / tw, tb / tw, 1.0f);
+  A.depth[o] = td / tw;
+}
+void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod) {
+  const int w = A.res[0][0];
+  dim3 grid((A.res[lod + 1][0] + 15) / 16, (A.res[lod + 1][1] + 15) / 16);
+  hipLaunchKernelGGL(k_inpaint_level, grid, dim3(256), 0, st, A, w, lod);
+}
+
+__device__ __forceinline__ int mirror_idx(int i, int n) {   // GL_MIRRORED_REPEAT, view_lod.cpp:52-53
+  const int p = 2 * n;
+  const int m = ((i % p) + p) % p;
+  return m < n ? m : p - 1 - m;
+}
+__device__ __forceinline__ float4 atlas_bilinear(const Atlas& A, float u, float v) {
+  const float fx = u * (float)A.aw - 0.5f, fy = v * (float)A.h - 0.5f;
+  const float x0f = floorf(fx), y0f = floorf(fy);
+  const float ax = fx - x0f, ay = fy - y0f;
+  const int x0 = mirror_idx((int)x0f, A.aw), x1 = mirror_idx((int)x0f + 1, A.aw);
+  const int y0 = mirror_idx((int)y0f, A.h), y1 = mirror_idx((int)y0f + 1, A.h);
+  const float4 t00 = A.color[(size_t)y0 * A.aw + x0], t10 = A.color[(size_t)y0 * A.aw + x1];
+  const float4 t01 = A.color[(size_t)y1 * A.aw + x0], t11 = A.color[(size_t)y1 * A.aw + x1];
+  return make_float4(lerpf(lerpf(t00.x, t10.x, ax), lerpf(t01.x, t11.x, ax), ay), lerpf(lerpf(t00.y, t10.y, ax), lerpf(t01.y, t11.y, ax), ay),
+                     lerpf(lerpf(t00.z, t10.z, ax), lerpf(t01.z, t11.z, ax), ay), lerpf(lerpf(t00.w, t10.w, ax), lerpf(t01.w, t11.w, ax), ay));
+}
+__device__ __forceinline__ Texel fetch_atlas(const Atlas& A, int x, int y) {
+  Texel t;
+  if (x < 0 || y < 0 || x >= A.aw || y >= A.h) { t.c = make_float4(0, 0, 0, 0); t.d = 0.0f; return t; }
+  t.c = A.color[(size_t)y * A.aw + x]; t.d = A.depth[(size_t)y * A.aw + x];
+  return t;
+}
+
+// tsdf_colorfill.fs:30-55 with depth func LESS against the cleared framebuffer (:313)
+__global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4* __restrict__ fb_c, float* __restrict__ fb_d) {
+  const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (px >= w || py >= h) return;
+  const float tcx = (float)px / (float)A.res[0][0], tcy = (float)py / (float)A.res[0][1];             // :32
+  float4 out = make_float4(0, 0, 0, 0);
+  int level = 0;
+  for (; level < A.num_lods; ++level) {                                                               // :36-40
+    const int cx = (int)((float)A.off[level][0] + (float)A.res[level][0] * tcx);
+    const int cy = (int)((float)A.off[level][1] + (float)A.res[level][1] * tcy);
+    out = fetch_atlas(A, cx, cy).c;
+    if (out.w > 0.0f) break;
+  }
+  if (level > 0) {                                                                                    // :42-51
+    const float ptx = ((float)px + 0.5f) / (float)w, pty = ((float)py + 0.5f) / (float)h;
+    float p[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                          // to_lod_pos2(level + 1), (level + 2); slots past num_lods are zero
+      const int l = level + 1 + k;
+      const bool in = l < A.num_lods;
+      const int o0 = in ? A.off[l][0] : 0, o1 = in ? A.off[l][1] : 0, r0 = in ? A.res[l][0] : 0, r1 = in ? A.res[l][1] : 0;
+      p[k][0] = fminf(fmaxf((float)o0 + (float)r0 * ptx, (float)o0 + 0.5f), (float)(o0 + r0) - 0.5f);
+      p[k][1] = fminf(fmaxf((float)o1 + (float)r1 * pty, (float)o1 + 0.5f), (float)(o1 + r1) - 0.5f);
+    }
+    const float rix = 1.0f / (float)A.aw, riy = 1.0f / (float)A.h;                                    // resolution_inv, :497
+    const float4 c1 = atlas_bilinear(A, p[0][0] * rix, p[0][1] * riy);
+    const float4 c2 = atlas_bilinear(A, p[1][0] * rix, p[1][1] * riy);
+    const float w1 = sqrtf(ptx * ptx + pty * pty);                                                    // :47 (Appendix C.7)
+    const float w2 = 1.0f - w1;
+    out = make_float4((c1.x * w1 + c2.x * w2) / (w1 + w2), (c1.y * w1 + c2.y * w2) / (w1 + w2),
+                      (c1.z * w1 + c2.z * w2) / (w1 + w2), (c1.w * w1 + c2.w * w2) / (w1 + w2));
+  }
+  const float d0 = fetch_atlas(A, (int)((float)A.off[0][0] + (float)A.res[0][0] * tcx), (int)((float)A.off[0][1] + (float)A.res[0][1] * tcy)).d;   // :54
+  const size_t o = (size_t)py * w + px;
+  const bool pass = d0 < 1.0f;                                                                        // GL_LESS vs cleared depth
+  fb_c[o] = pass ? out : make_float4(0, 0, 0, 0);
+  fb_d[o] = pass ? d0 : 1.0f;
+}
+void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth) {
+  dim3 grid((w + 15) / 16, (h + 15) / 16);
+  hipLaunchKernelGGL(k_colorfill, grid, dim3(256), 0, st, A, w, h, fb_color, fb_depth);
+}
+
+__global__ __launch_bounds__(256) void k_clear_image(float4* __restrict__ c, float* __restrict__ d, size_t n, float4 cv, float dv) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    c[i] = cv;
+    d[i] = dv;
+  }
+}
+void launch_clear_image(hipStream_t st, float4* color, float* depth, size_t n, float4 c, float d) {
+  size_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_clear_image, dim3((unsigned)g), dim3(256), 0, st, color, depth, n, c, d);
+}
+
+}  // namespace rr

@@ -1,0 +1,118 @@
+// Device-side GL sampling semantics (OpenGL 4.4 §8.14 with the reference's sampler state,
+// SURVEY.md Appendix A): manual fp32 filtering from plain HBM buffers, never hipTextureObject
+// filtering (fixed-point weights would break parity).  lerp(a,b,t) = a + (b-a)*t, x then y then z.
+// The translation unit is built with -ffp-contract=off: every rounding stays where it is written.
+#pragma once
+#include "tsdf_common.hpp"
+
+namespace rr {
+
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+struct Axis { int i0, i1; float a; };
+// LINEAR + CLAMP_TO_EDGE along one axis: f = u*n - 0.5, i0 = floor(f), weight = fract
+__device__ __forceinline__ Axis axis_linear(float u, int n) {
+  float f = u * (float)n - 0.5f;
+  float fl = floorf(f);
+  Axis r;
+  r.a = f - fl;
+  int i = (int)fminf(fmaxf(fl, -1.0f), (float)n);
+  r.i0 = clampi(i, 0, n - 1);
+  r.i1 = clampi(i + 1, 0, n - 1);
+  return r;
+}
+__device__ __forceinline__ int axis_nearest(float u, int n) {
+  float f = floorf(u * (float)n);
+  return clampi((int)fminf(fmaxf(f, -1.0f), (float)n), 0, n - 1);
+}
+
+__device__ __forceinline__ float3 lerp3(float4 a, float4 b, float t) {
+  return make_float3(lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t));
+}
+__device__ __forceinline__ float3 lerp3(float3 a, float3 b, float t) {
+  return make_float3(lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t));
+}
+
+// texture(sampler3D RGBA32F, p).xyz
+__device__ __forceinline__ float3 tex3d_rgba_xyz(const float4* __restrict__ t, const int* res, float u, float v, float w) {
+  const Axis X = axis_linear(u, res[0]), Y = axis_linear(v, res[1]), Z = axis_linear(w, res[2]);
+  const size_t r00 = ((size_t)Z.i0 * res[1] + Y.i0) * res[0], r10 = ((size_t)Z.i0 * res[1] + Y.i1) * res[0];
+  const size_t r01 = ((size_t)Z.i1 * res[1] + Y.i0) * res[0], r11 = ((size_t)Z.i1 * res[1] + Y.i1) * res[0];
+  const float3 c00 = lerp3(t[r00 + X.i0], t[r00 + X.i1], X.a);
+  const float3 c10 = lerp3(t[r10 + X.i0], t[r10 + X.i1], X.a);
+  const float3 c01 = lerp3(t[r01 + X.i0], t[r01 + X.i1], X.a);
+  const float3 c11 = lerp3(t[r11 + X.i0], t[r11 + X.i1], X.a);
+  return lerp3(lerp3(c00, c10, Y.a), lerp3(c01, c11, Y.a), Z.a);
+}
+// texture(sampler3D RG32F, p).xy
+__device__ __forceinline__ float2 tex3d_rg(const float2* __restrict__ t, const int* res, float u, float v, float w) {
+  const Axis X = axis_linear(u, res[0]), Y = axis_linear(v, res[1]), Z = axis_linear(w, res[2]);
+  const size_t r00 = ((size_t)Z.i0 * res[1] + Y.i0) * res[0], r10 = ((size_t)Z.i0 * res[1] + Y.i1) * res[0];
+  const size_t r01 = ((size_t)Z.i1 * res[1] + Y.i0) * res[0], r11 = ((size_t)Z.i1 * res[1] + Y.i1) * res[0];
+  float2 a = t[r00 + X.i0], b = t[r00 + X.i1];
+  const float2 c00 = make_float2(lerpf(a.x, b.x, X.a), lerpf(a.y, b.y, X.a));
+  a = t[r10 + X.i0]; b = t[r10 + X.i1];
+  const float2 c10 = make_float2(lerpf(a.x, b.x, X.a), lerpf(a.y, b.y, X.a));
+  a = t[r01 + X.i0]; b = t[r01 + X.i1];
+  const float2 c01 = make_float2(lerpf(a.x, b.x, X.a), lerpf(a.y, b.y, X.a));
+  a = t[r11 + X.i0]; b = t[r11 + X.i1];
+  const float2 c11 = make_float2(lerpf(a.x, b.x, X.a), lerpf(a.y, b.y, X.a));
+  return make_float2(lerpf(lerpf(c00.x, c10.x, Y.a), lerpf(c01.x, c11.x, Y.a), Z.a),
+                     lerpf(lerpf(c00.y, c10.y, Y.a), lerpf(c01.y, c11.y, Y.a), Z.a));
+}
+
+// The 2x2 footprint of the packed {depth, quality, silhouette} image at (u, v) of layer i.
+struct Dqs { float4 t00, t10, t01, t11; float ax, ay; int nx, ny, x0, x1, y0, y1; };
+__device__ __forceinline__ Dqs dqs_fetch(const FrameImages& F, int layer, float u, float v) {
+  const Axis X = axis_linear(u, F.w), Y = axis_linear(v, F.h);
+  const float4* __restrict__ b = F.dqs + (size_t)layer * F.w * F.h;
+  Dqs r;
+  r.t00 = b[(size_t)Y.i0 * F.w + X.i0]; r.t10 = b[(size_t)Y.i0 * F.w + X.i1];
+  r.t01 = b[(size_t)Y.i1 * F.w + X.i0]; r.t11 = b[(size_t)Y.i1 * F.w + X.i1];
+  r.ax = X.a; r.ay = Y.a;
+  r.x0 = X.i0; r.x1 = X.i1; r.y0 = Y.i0; r.y1 = Y.i1;
+  r.nx = axis_nearest(u, F.w); r.ny = axis_nearest(v, F.h);
+  return r;
+}
+__device__ __forceinline__ float dqs_silhouette(const Dqs& d) {   // LINEAR R32F
+  return lerpf(lerpf(d.t00.z, d.t10.z, d.ax), lerpf(d.t01.z, d.t11.z, d.ax), d.ay);
+}
+__device__ __forceinline__ float dqs_quality(const Dqs& d) {      // LINEAR R32F
+  return lerpf(lerpf(d.t00.y, d.t10.y, d.ax), lerpf(d.t01.y, d.t11.y, d.ax), d.ay);
+}
+// NEAREST RG32F .r: the nearest texel floor(u*n) is always one of the bilinear pair {i0, i1}
+// (i0 = floor(u*n - .5)), also after clamping, so it is picked from the footprint already in registers.
+__device__ __forceinline__ float dqs_depth(const Dqs& d) {
+  const bool xr = (d.nx != d.x0), yr = (d.ny != d.y0);
+  const float lo = xr ? d.t10.x : d.t00.x, hi = xr ? d.t11.x : d.t01.x;
+  return yr ? hi : lo;
+}
+
+// TSDF R32F, LINEAR + CLAMP_TO_EDGE, tile-major storage
+__device__ __forceinline__ size_t vol_index(const Volume& V, int x, int y, int z) {
+  const size_t tile = ((size_t)((z >> 3) - V.tz0) * V.nty + (y >> 3)) * V.ntx + (x >> 3);
+  return (tile << 9) + ((z & 7) << 6) + ((y & 7) << 3) + (x & 7);
+}
+__device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) {
+  const Axis X = axis_linear(u, V.res[0]), Y = axis_linear(v, V.res[1]), Z = axis_linear(w, V.res[2]);
+  const float* __restrict__ t = V.data;
+  const float c00 = lerpf(t[vol_index(V, X.i0, Y.i0, Z.i0)], t[vol_index(V, X.i1, Y.i0, Z.i0)], X.a);
+  const float c10 = lerpf(t[vol_index(V, X.i0, Y.i1, Z.i0)], t[vol_index(V, X.i1, Y.i1, Z.i0)], X.a);
+  const float c01 = lerpf(t[vol_index(V, X.i0, Y.i0, Z.i1)], t[vol_index(V, X.i1, Y.i0, Z.i1)], X.a);
+  const float c11 = lerpf(t[vol_index(V, X.i0, Y.i1, Z.i1)], t[vol_index(V, X.i1, Y.i1, Z.i1)], X.a);
+  return lerpf(lerpf(c00, c10, Y.a), lerpf(c01, c11, Y.a), Z.a);
+}
+
+__device__ __forceinline__ float4 mat_mul(const Mat4& a, float x, float y, float z, float w) {
+  return make_float4(a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w,
+                     a.m[1] * x + a.m[5] * y + a.m[9] * z + a.m[13] * w,
+                     a.m[2] * x + a.m[6] * y + a.m[10] * z + a.m[14] * w,
+                     a.m[3] * x + a.m[7] * y + a.m[11] * z + a.m[15] * w);
+}
+__device__ __forceinline__ float3 normalize3(float3 a) {
+  const float s = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+  return make_float3(a.x * s, a.y * s, a.z * s);
+}
+
+}  // namespace rr

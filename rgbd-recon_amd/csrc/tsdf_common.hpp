@@ -1,0 +1,95 @@
+// Shared host/device declarations of the HIP TSDF core (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rgbd_recon_hip.h"
+
+namespace rr {
+
+constexpr int TILE = 8;            // storage tile edge: the TSDF lives in HBM as 8x8x8 tiles of 2 KiB
+constexpr int TILE_VOX = 512;
+
+// One calibrated stream: its three LUT volumes (CalibVolumes.cpp:64-80,132-144)
+struct StreamLut {
+  const float4* inv;   // cv_xyz_inv RGBA32F
+  const float2* uv;    // cv_uv      RG32F
+  const float4* xyz;   // cv_xyz     RGB32F padded to 16 B texels on upload
+  int inv_res[3], uv_res[3], xyz_res[3];
+};
+struct StreamTable {
+  StreamLut s[TSDF_MAX_STREAMS];
+  int n;
+};
+
+// Per-frame images as resident in HBM: one 16-B texel {depth.r, quality, silhouette, 0} per depth pixel
+// (the three arrays are always fetched at the same coordinate, tsdf_integration.vs:32-50) and RGBA8 colour.
+struct FrameImages {
+  const float4* dqs;      // [N][H][W]
+  const uchar4* color;    // [N][Hc][Wc]
+  int w, h, cw, ch;
+};
+
+// TSDF volume, tile-major: tile (tx,ty,tz) at ((tz - tz0) * nty + ty) * ntx + tx, voxel (x&7,y&7,z&7) inside
+struct Volume {
+  float* data;
+  int res[3];          // logical resolution
+  int ntx, nty;        // tiles per axis (x, y); z tiles stored: [tz0, tz1)
+  int tz0, tz1;        // stored tile layers (owned slab + halo)
+  int own_tz0, own_tz1;  // owned tile layers (integrated by this context)
+  float limit;
+};
+
+// Occupancy bricks (inc_bricks.glsl:10-20) plus the voxel -> brick tables that restate
+// VolumeSampler::containedVoxels (volume_sampler.cpp:50-62): along axis a voxel v lies in bricks
+// [first[a][v], first[a][v] + count[a][v]).
+struct Bricks {
+  uint32_t* counters;       // per brick
+  uint8_t* flags;           // counter >= min_voxels (recon_integration.cpp:436)
+  uint32_t* num_occupied;   // device scalar
+  const uint16_t* vox_first[3];
+  const uint8_t* vox_count[3];
+  int res[3];               // brick grid
+  int n;
+  float size[3];            // world brick size
+  float bbox_min[3];
+};
+
+struct Mat4 { float m[16]; };   // column-major
+struct ViewParams {
+  Mat4 mv, proj, mv_inv, v2w_inv, img_to_eye, normal, mv_v2w, glnormal_inv;
+  float cam_vol[3], cam_world[3];
+  int w, h;
+  int shade_mode;
+  int skip;
+};
+
+// ViewLod atlas (view_lod.cpp:24-61)
+struct Atlas {
+  float4* color;
+  float* depth;
+  int aw, h;          // atlas size (1.5 w, h)
+  int num_lods;
+  int off[TSDF_MAX_LODS][2];
+  int res[TSDF_MAX_LODS][2];
+};
+
+// launchers (one per kernel family, defined in the .hip files)
+void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, size_t n);
+void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);
+void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
+void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B);
+void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels);
+void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, int use_bricks);
+void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
+void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* linear);
+void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels);
+struct RayTarget { float4* color; float* depth; int stride; float* nsamples; const float4* peels; float clear[4]; };
+void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial);
+void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod);
+void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth);
+void launch_clear_image(hipStream_t st, float4* color, float* depth, size_t n, float4 c, float d);
+void launch_export_partial(hipStream_t st, const RayTarget& R, int w, int h, void* dst);
+void launch_composite(hipStream_t st, const void* gathered, int n, const RayTarget& R, int w, int h);
+
+}  // namespace rr

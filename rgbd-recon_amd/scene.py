@@ -1,0 +1,203 @@
+"""Synthetic calibrated RGB-D scene (harness input, not part of the hot path).
+
+The reference ships no calibration or stream fixtures, so tests, bench.py and
+smoke() all feed the path from this closed-form generator:
+
+* N pinhole depth cameras on a circle (radius 2.5 m, height 1.1 m) looking at (0, 1.1, 0)
+* forward LUT  ``cv_xyz``     RGB32F  (u, v, d_norm)   -> world xyz   (framework/calibration/CalibVolumes.cpp:132-144)
+* colour LUT   ``cv_uv``      RG32F   identity on (u, v)
+* inverse LUT  ``cv_xyz_inv`` RGBA32F unit-cube voxel -> (u, v, d_norm, 1), (-1,-1,-1,-1) outside the
+  frustum (framework/calibration/calibration_inverter.cpp:87-101)
+* per stream images in the formats NetKinectArray hands to the path (framework/NetKinectArray.cpp:159-188):
+  depth RG32F (r = normalised depth, 0 = invalid), quality R32F, silhouette R32F, normals RGB32F, colour RGB8
+
+All LUT volumes are x-fastest (calibration_volume.hpp:57-59).  Everything is computed in float64
+and rounded once to float32.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BBOX_MIN = np.array([-1.0, 0.0, -1.0])   # source/kinect_client.cpp:206-207 default bbox
+BBOX_MAX = np.array([1.0, 2.2, 1.0])
+DEPTH_MIN, DEPTH_MAX = 0.5, 4.5          # calibration_inverter.cpp:113, pre_morph.fs:32-33
+
+SPHERE_C = np.array([0.0, 1.1, 0.0])
+SPHERE_R = 0.45
+BOX_C = np.array([0.5, 0.4, 0.3])
+BOX_H = 0.15
+
+
+# ----------------------------------------------------------------------------- matrices
+def look_at(eye, target, up=(0.0, 1.0, 0.0)) -> np.ndarray:
+    """gluLookAt; returns a 4x4 (row, col) float64 matrix."""
+    eye = np.asarray(eye, np.float64)
+    f = np.asarray(target, np.float64) - eye
+    f /= np.linalg.norm(f)
+    s = np.cross(f, np.asarray(up, np.float64))
+    s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    m = np.eye(4)
+    m[0, :3], m[1, :3], m[2, :3] = s, u, -f
+    m[:3, 3] = -m[:3, :3] @ eye
+    return m
+
+
+def perspective(fovy_deg, aspect, near, far) -> np.ndarray:
+    """gluPerspective (source/kinect_client.cpp:100 uses 50 deg, 0.1, 200)."""
+    f = 1.0 / np.tan(np.radians(fovy_deg) * 0.5)
+    m = np.zeros((4, 4))
+    m[0, 0] = f / aspect
+    m[1, 1] = f
+    m[2, 2] = (far + near) / (near - far)
+    m[2, 3] = 2.0 * far * near / (near - far)
+    m[3, 2] = -1.0
+    return m
+
+
+def gl_flat(m: np.ndarray) -> np.ndarray:
+    """4x4 (row, col) -> 16 floats column-major, as glGetFloatv(GL_*_MATRIX) returns them."""
+    return np.ascontiguousarray(m.T, dtype=np.float32).reshape(16)
+
+
+def default_view(view_w=1280, view_h=720):
+    """Benchmark view of SURVEY.md §8d: eye (0,1.1,3) -> (0,1.1,0), 50 deg, 0.1..200."""
+    mv = look_at((0.0, 1.1, 3.0), (0.0, 1.1, 0.0))
+    pr = perspective(50.0, view_w / float(view_h), 0.1, 200.0)
+    return gl_flat(mv), gl_flat(pr)
+
+
+# ----------------------------------------------------------------------------- cameras
+class Camera:
+    def __init__(self, k, n, width, height, focal):
+        a = 2.0 * np.pi * k / n
+        self.pos = np.array([2.5 * np.cos(a), 1.1, 2.5 * np.sin(a)])
+        fwd = np.array([0.0, 1.1, 0.0]) - self.pos
+        self.fwd = fwd / np.linalg.norm(fwd)
+        r = np.cross(self.fwd, [0.0, 1.0, 0.0])
+        self.right = r / np.linalg.norm(r)
+        self.up = np.cross(self.right, self.fwd)
+        self.w, self.h, self.f = width, height, focal
+        self.cx, self.cy = width * 0.5, height * 0.5
+
+    def unproject(self, u, v, d):
+        """normalised (u, v) and metric z-depth d -> world xyz (broadcasting)."""
+        a = (u * self.w - self.cx) / self.f
+        b = (v * self.h - self.cy) / self.f
+        return (self.pos + d[..., None] * (self.fwd + a[..., None] * self.right + b[..., None] * self.up))
+
+    def project(self, x):
+        """world xyz [...,3] -> (u, v, d)."""
+        rel = x - self.pos
+        d = rel @ self.fwd
+        with np.errstate(divide="ignore", invalid="ignore"):
+            a = (rel @ self.right) / d
+            b = (rel @ self.up) / d
+        return (self.cx + self.f * a) / self.w, (self.cy + self.f * b) / self.h, d
+
+
+def _ray_sphere(o, d):
+    oc = o - SPHERE_C
+    b = np.einsum("...k,...k->...", oc, d)
+    c = np.einsum("...k,...k->...", oc, oc) - SPHERE_R ** 2
+    a = np.einsum("...k,...k->...", d, d)
+    disc = b * b - a * c
+    t = np.where(disc >= 0, (-b - np.sqrt(np.maximum(disc, 0))) / a, np.inf)
+    return np.where(t > 0, t, np.inf)
+
+
+def _ray_box(o, d):
+    lo, hi = BOX_C - BOX_H, BOX_C + BOX_H
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        t0 = (lo - o) * inv
+        t1 = (hi - o) * inv
+    tn = np.minimum(t0, t1)
+    tf = np.maximum(t0, t1)
+    tmin = tn.max(-1)
+    tmax = tf.min(-1)
+    axis = tn.argmax(-1)
+    hit = (tmin <= tmax) & (tmin > 0)
+    return np.where(hit, tmin, np.inf), axis
+
+
+def make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128, seed=1234,
+               color_width=None, color_height=None):
+    """Returns a dict of contiguous numpy arrays (see module docstring for formats)."""
+    rng = np.random.default_rng(seed)
+    focal = 570.0 * width / 640.0
+    cw = color_width or width
+    ch = color_height or height
+    cams = [Camera(k, n_streams, width, height, focal) for k in range(n_streams)]
+    out = dict(n=n_streams, width=width, height=height, color_width=cw, color_height=ch,
+               bbox_min=BBOX_MIN.astype(np.float32), bbox_max=BBOX_MAX.astype(np.float32),
+               depth_limits=np.array([DEPTH_MIN, DEPTH_MAX], np.float32),
+               lut_res=np.array([lut_res] * 3, np.uint32), inv_res=np.array([inv_res] * 3, np.uint32))
+
+    # ---- LUTs (texel centres at (i + .5) / n, x fastest)
+    c = (np.arange(lut_res) + 0.5) / lut_res
+    dn, vv, uu = np.meshgrid(c, c, c, indexing="ij")             # [z=d][y=v][x=u]
+    ci = (np.arange(inv_res) + 0.5) / inv_res
+    wz, wy, wx = np.meshgrid(ci, ci, ci, indexing="ij")
+    world = BBOX_MIN + np.stack([wx, wy, wz], -1) * (BBOX_MAX - BBOX_MIN)
+    xyz, uvl, inv = [], [], []
+    for cam in cams:
+        xyz.append(cam.unproject(uu, vv, DEPTH_MIN + dn * (DEPTH_MAX - DEPTH_MIN)).reshape(-1, 3))
+        uvl.append(np.stack([uu, vv], -1).reshape(-1, 2))
+        u, v, d = cam.project(world)
+        dnorm = (d - DEPTH_MIN) / (DEPTH_MAX - DEPTH_MIN)
+        ok = (u >= 0) & (u <= 1) & (v >= 0) & (v <= 1) & (dnorm >= 0) & (dnorm <= 1)
+        val = np.stack([u, v, dnorm, np.ones_like(u)], -1)
+        val[~ok] = -1.0
+        inv.append(val.reshape(-1, 4))
+    out["cv_xyz"] = np.ascontiguousarray(np.stack(xyz), np.float32)
+    out["cv_uv"] = np.ascontiguousarray(np.stack(uvl), np.float32)
+    out["cv_xyz_inv"] = np.ascontiguousarray(np.stack(inv), np.float32)
+
+    # ---- per-stream images
+    py, px = np.meshgrid(np.arange(height) + 0.5, np.arange(width) + 0.5, indexing="ij")
+    depth = np.zeros((n_streams, height, width, 2), np.float32)
+    quality = np.zeros((n_streams, height, width), np.float32)
+    silhouette = np.zeros((n_streams, height, width), np.float32)
+    normals = np.zeros((n_streams, height, width, 3), np.float32)
+    color = np.zeros((n_streams, ch, cw, 3), np.uint8)
+    noise = rng.integers(0, 4, size=(n_streams, ch, cw, 3), dtype=np.uint8)
+    for k, cam in enumerate(cams):
+        a = (px - cam.cx) / cam.f
+        b = (py - cam.cy) / cam.f
+        dirs = cam.fwd + a[..., None] * cam.right + b[..., None] * cam.up      # z-depth parametrised
+        o = np.broadcast_to(cam.pos, dirs.shape)
+        ts = _ray_sphere(o, dirs)
+        tb, axis = _ray_box(o, dirs)
+        t = np.minimum(ts, tb)
+        hit = np.isfinite(t)
+        tt = np.where(hit, t, 0.0)
+        p = o + tt[..., None] * dirs
+        nrm_s = (p - SPHERE_C) / SPHERE_R
+        nrm_b = np.zeros_like(p)
+        sgn = -np.sign(np.take_along_axis(dirs, axis[..., None], -1))[..., 0]
+        np.put_along_axis(nrm_b, axis[..., None], sgn[..., None], -1)
+        nrm = np.where((ts <= tb)[..., None], nrm_s, nrm_b)
+        inside = np.all((p >= BBOX_MIN) & (p <= BBOX_MAX), -1)
+        dnorm = (tt - DEPTH_MIN) / (DEPTH_MAX - DEPTH_MIN)                     # t is z-depth here
+        valid = hit & inside & (dnorm > 0) & (dnorm < 1)
+        to_cam = -dirs / np.linalg.norm(dirs, axis=-1, keepdims=True)
+        cos_t = np.clip(np.einsum("...k,...k->...", nrm, to_cam), 0.0, 1.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = np.clip(cos_t ** 2 / (6.5 * dnorm), 0.05, 4.0)                 # shape of pre_quality.fs:107-114
+        depth[k, ..., 0] = np.where(valid, dnorm, 0.0)
+        quality[k] = np.where(valid, q, 0.0)
+        silhouette[k] = valid.astype(np.float32)
+        normals[k] = np.where(valid[..., None], nrm, 0.0)
+        # colour camera == depth camera (cv_uv identity); resample to the colour resolution
+        cyi = np.minimum((np.arange(ch) + 0.5) / ch * height, height - 1).astype(int)
+        cxi = np.minimum((np.arange(cw) + 0.5) / cw * width, width - 1).astype(int)
+        pc = p[cyi][:, cxi]
+        vc = valid[cyi][:, cxi]
+        cell = np.floor(pc / 0.1).astype(np.int64).sum(-1) & 1
+        base = np.where(cell[..., None] == 1, np.array([200, 60, 40]), np.array([40, 90, 200]))
+        base = base + (np.array([0, 8 * (k + 1), 0]))                          # per-stream tint
+        col = np.where(vc[..., None], base, 16) + noise[k]
+        color[k] = np.clip(col, 0, 255).astype(np.uint8)
+    out.update(depth=depth, quality=quality, silhouette=silhouette, normals=normals, color=color)
+    return out

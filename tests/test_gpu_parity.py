@@ -1,0 +1,183 @@
+"""-m gpu parity tests: every stage of the HIP path, called through the C ABI, against the CPU oracle on
+identical seeded inputs (SURVEY.md §8c tolerances).
+
+Tolerances (written here, once):
+  TSDF      |a-b| <= 1e-3 * max(|a|, |b|, limit), NaN == NaN          (north_star: 1e-3 relative)
+  counters  bit-exact (uint atomics are order independent)
+  depth     1e-4 abs; colour 1e-3 abs; hit mask identical up to a stated fraction of pixels
+"""
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleRecon
+
+pytestmark = pytest.mark.gpu
+
+LIMIT = 0.04          # coarse volumes need a wider band than the reference's 0.01 to hold a surface
+RES = (64, 64, 64)
+BRICK = [2.0 / 8, 2.2 / 8, 2.0 / 8]
+VIEW = (160, 90)
+
+
+def tsdf_close(a, b, limit, rtol=1e-3):
+    both_nan = np.isnan(a) & np.isnan(b)
+    tol = rtol * np.maximum(np.maximum(np.abs(a), np.abs(b)), limit)
+    with np.errstate(invalid="ignore"):
+        ok = (np.abs(a - b) <= tol) | both_nan
+    return ok
+
+
+def make_pair(rr, scene, **kw):
+    args = dict(res=RES, brick_size=BRICK, limit=LIMIT, view=VIEW)
+    args.update(kw)
+    return rr.ReconIntegrationHip(scene, **args), OracleRecon(scene, **args)
+
+
+def run_bricks(o):
+    o.clearOccupiedBricks()
+    o.markBricks()
+    return o.updateOccupiedBricks()
+
+
+def test_mark_and_update_bricks_bit_exact(rr, small_scene):
+    hip, orc = make_pair(rr, small_scene)
+    assert hip.res == orc.res and hip.res_bricks == orc.res_bricks
+    np.testing.assert_array_equal(np.float32(hip.brick_size), np.float32(orc.brick_size))
+    r_hip, r_orc = run_bricks(hip), run_bricks(orc)
+    cnt, flags = hip.bricks()
+    np.testing.assert_array_equal(cnt, orc.counters())
+    occ = np.zeros(orc.numBricks(), np.uint8)
+    occ[orc.occupied()] = 1
+    np.testing.assert_array_equal(flags, occ)
+    assert r_hip == pytest.approx(r_orc, abs=0) and r_orc > 0
+
+
+@pytest.mark.parametrize("use_bricks", [False, True])
+def test_integrate_matches_oracle(rr, small_scene, use_bricks):
+    hip, orc = make_pair(rr, small_scene)
+    for o in (hip, orc):
+        o.setUseBricks(use_bricks)
+        run_bricks(o)
+        o.integrate()
+    a, b = hip.tsdf(), orc.tsdf()
+    ok = tsdf_close(a, b, LIMIT)
+    assert ok.all(), f"{(~ok).sum()} of {ok.size} voxels outside 1e-3 relative"
+    # the same fp32 operations in the same order: expect bit equality, report if not
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    print(f"bit-identical voxels: {same.mean():.6f}; surface band voxels: {(np.abs(b) < LIMIT).mean():.4f}")
+    assert (np.abs(b) < LIMIT).sum() > 1000      # the test volume really contains a surface band
+
+
+def test_integrate_non_tile_aligned_resolution(rr, small_scene):
+    """res not a multiple of the 8^3 storage tile, bricks not aligned with tiles (reference default is 10 voxels)."""
+    kw = dict(res=(50, 55, 50), brick_size=[0.2, 0.2, 0.2])
+    hip, orc = make_pair(rr, small_scene, **kw)
+    assert hip.res_bricks == orc.res_bricks
+    for o in (hip, orc):
+        run_bricks(o)
+        o.integrate()
+    ok = tsdf_close(hip.tsdf(), orc.tsdf(), LIMIT)
+    assert ok.all()
+
+
+def test_reference_style_voxel_size_constructor(rr, small_scene):
+    """ReconIntegration(cfs, cv, bbox, limit, voxel_size) path: res = ceil(bbox / voxel), brick snapped (recon_integration.cpp:340-344,463)."""
+    kw = dict(res=None, voxel_size=0.04, brick_size=0.21)
+    hip, orc = make_pair(rr, small_scene, **kw)
+    assert hip.res == orc.res and hip.res_bricks == orc.res_bricks
+    np.testing.assert_array_equal(np.float32(hip.brick_size), np.float32(orc.brick_size))
+    for o in (hip, orc):
+        run_bricks(o)
+        o.integrate()
+    assert tsdf_close(hip.tsdf(), orc.tsdf(), LIMIT).all()
+
+
+def image_report(name, a, b, atol):
+    with np.errstate(invalid="ignore"):
+        bad = ~((np.abs(a - b) <= atol) | (np.isnan(a) & np.isnan(b)))
+    return bad, f"{name}: {bad.sum()} / {bad.size} beyond {atol}"
+
+
+@pytest.mark.parametrize("skip_space", [False, True])
+@pytest.mark.parametrize("shade_mode", [0, 1, 3])
+def test_raymarch_matches_oracle(rr, small_scene, skip_space, shade_mode):
+    hip, orc = make_pair(rr, small_scene)
+    mv, pr = rr.scene.default_view(*VIEW)
+    for o in (hip, orc):
+        o.setSpaceSkip(skip_space)
+        o.setShadeMode(shade_mode)
+        run_bricks(o)
+        o.integrate()
+    # isolate the raymarch: both sides march the oracle's volume
+    hip.set_tsdf(orc.tsdf())
+    hip.draw(mv, pr)
+    orc.draw(mv, pr)
+    ha, hd, hn, hp = hip.view_images()
+    oa, od, on, op = orc.view_images()
+    if skip_space:
+        bad, msg = image_report("depth peels", hp[..., :3], op[..., :3], 1e-6)
+        assert bad.mean() <= 2e-3, msg
+    hit_h, hit_o = hd < 1.0, od < 1.0
+    assert hit_o.sum() > 300
+    mism = (hit_h != hit_o).mean()
+    assert mism <= 2e-3, f"hit mask differs on {mism:.5f} of the pixels"
+    both = hit_h & hit_o
+    bad, msg = image_report("depth", hd[both], od[both], 1e-4)
+    assert bad.mean() <= 2e-3, msg
+    bad, msg = image_report("colour", ha[both], oa[both], 1e-3)
+    assert bad.mean() <= 5e-3, msg
+    bad, msg = image_report("nsamples", hn, on, 0.0027 * 0.5)
+    assert bad.mean() <= 2e-3, msg
+
+
+def test_fill_colors_matches_two_atlas_reference_sequence(rr, small_scene):
+    """K3/K4 alone: identical level-0 input (the oracle's raymarch output, holes included) on both sides; the HIP
+    single-atlas analytic squeeze must equal the literal two-atlas ping-pong of fillColors()."""
+    hip, orc = make_pair(rr, small_scene)
+    mv, pr = rr.scene.default_view(*VIEW)
+    run_bricks(orc)
+    orc.integrate()
+    orc.draw(mv, pr)
+    rgba, depth, _, _ = orc.view_images()
+    assert (rgba[..., 3] < 0).any() and (rgba[..., 3] > 0).any()     # holes (alpha -1) and valid pixels both present
+    hip.set_view_images(rgba, depth)
+    hip.fillColors()
+    orc.fillColors()
+    ac, ad = hip.atlas()
+    oc, od = orc.atlas()
+    np.testing.assert_array_equal(ad, od)
+    np.testing.assert_array_equal(ac, oc)
+    fc, fd = hip.framebuffer()
+    gc, gd = orc.framebuffer()
+    np.testing.assert_array_equal(fd, gd)
+    np.testing.assert_allclose(fc, gc, rtol=0, atol=1e-6)
+
+
+def test_full_frame_call_order(rr, small_scene):
+    """process_textures() -> integrate() -> drawF() as in source/kinect_client.cpp:569-599,614."""
+    hip, orc = make_pair(rr, small_scene)
+    mv, pr = rr.scene.default_view(*VIEW)
+    for o in (hip, orc):
+        run_bricks(o)
+        o.integrate()
+        o.drawF(mv, pr)
+    fc, fd = hip.framebuffer()
+    gc, gd = orc.framebuffer()
+    assert ((fd < 1) != (gd < 1)).mean() <= 2e-3
+    both = (fd < 1) & (gd < 1)
+    assert both.sum() > 300
+    assert (np.abs(fd[both] - gd[both]) > 1e-4).mean() <= 2e-3
+    with np.errstate(invalid="ignore"):
+        assert (np.abs(fc[both] - gc[both]) > 2e-3).mean() <= 1e-2
+    assert hip.occupiedRatio() == pytest.approx(orc.updateOccupiedBricks(), abs=0)
+
+
+def test_errors_are_codes_not_crashes(rr, small_scene):
+    with pytest.raises(rr.TsdfError):
+        rr.ReconIntegrationHip(small_scene, res=RES, brick_size=[0.0, 0.1, 0.1], limit=LIMIT, view=VIEW)
+    hip = rr.ReconIntegrationHip(small_scene, res=RES, brick_size=BRICK, limit=LIMIT, view=VIEW, upload=False)
+    with pytest.raises(rr.TsdfError) as e:
+        hip.integrate()                      # no calibration / frame yet
+    assert e.value.code == -4
+    with pytest.raises(rr.TsdfError):
+        hip.setShadeMode(7)
