@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of integrate() + drawF() on the synthetic scene of SURVEY.md §8d.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one frame of the reference's per-frame call order (source/kinect_client.cpp:569-599,614):
+clearOccupiedBricks -> mark_brick (K6) -> updateOccupiedBricks -> integrate (K0+K1) -> drawF
+(K5 depth limits, K2 raymarch, K3/K4 hole filling), with the frame images already resident in HBM.
+N > 1 slab-partitions the SAME volume over the ranks (strong scaling) with an RCCL halo all-gather
+before the raymarch and a nearest-hit gather of the partial images (rgbd-recon_amd/multigpu.py).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on (512^3 x 4 streams, cull + inpaint)
+    "c2": dict(res=(512, 512, 512), streams=4, use_bricks=True, skip_space=True, fill_holes=True,
+               name="512^3 TSDF x 4 streams 640x480, 1280x720 view, brick cull (8^3-voxel bricks) + inpaint"),
+    # BASELINE.json configs[1]
+    "c1": dict(res=(256, 256, 256), streams=4, use_bricks=False, skip_space=False, fill_holes=False,
+               name="256^3 TSDF x 4 streams 640x480, 1280x720 view, dense integrate + raymarch"),
+}
+VIEW = (1280, 720)
+LUT = 128
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(cfg, n_streams, world):
+    """BASELINE.md §3 / SURVEY.md §8d dense byte counts, per launch of each kernel on ONE rank."""
+    V = cfg["res"][0] * cfg["res"][1] * cfg["res"][2] // world
+    L = LUT ** 3 // world
+    P = 640 * 480
+    R = VIEW[0] * VIEW[1]
+    integrate = 4 * V + n_streams * 16 * L + n_streams * 16 * P
+    raymarch = 4 * V + 24 * R + n_streams * 15 * P
+    inpaint = 67 * R
+    return dict(integrate=integrate, raymarch=raymarch, inpaint=inpaint)
+
+
+def cpu_baseline(scene, cfg, limit, brick):
+    """The oracle (kind "port": the reference has no CPU path) on a bounded sample of the
+    same workload: the full integrate() of the configuration, and drawF() on a 640x360 window of the
+    1280x720 view (1/4 of the rays), scaled by 4."""
+    from oracle.oracle import OracleRecon
+    import rgbd_recon_amd as rr
+    cores = os.cpu_count() or 1
+    sv = (640, 360)
+    o = OracleRecon(scene, res=cfg["res"], brick_size=brick, limit=limit, view=sv)
+    o.setUseBricks(cfg["use_bricks"]); o.setSpaceSkip(cfg["skip_space"]); o.setColorFilling(cfg["fill_holes"])
+    mv, pr = rr.scene.default_view(*sv)
+    t0 = time.perf_counter()
+    o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks()
+    o.integrate()
+    t1 = time.perf_counter()
+    o.drawF(mv, pr)
+    t2 = time.perf_counter()
+    scale = (VIEW[0] * VIEW[1]) / float(sv[0] * sv[1])
+    t_frame = (t1 - t0) + (t2 - t1) * scale
+    return {"value": 1.0 / t_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/libtsdf_oracle.so, OpenMP {cores} threads: bricks+integrate full size {t1 - t0:.2f} s; "
+                      f"drawF on a {sv[0]}x{sv[1]} window {t2 - t1:.2f} s scaled x{scale:.0f} to {VIEW[0]}x{VIEW[1]}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timers", action="store_true", help="leave the per-kernel HIP event timers off")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch                      # first: the HIP runtime torch bundles is the one the library binds to
+    import torch.distributed as dist
+    import rgbd_recon_amd as rr
+    from importlib import import_module
+    mg = import_module("rgbd-recon_amd.multigpu")
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    cfg = CONFIGS[args.config]
+    limit = 0.01
+    scene = rr.scene.make_scene(n_streams=cfg["streams"], width=640, height=480, lut_res=LUT, inv_res=LUT)
+    ext = scene["bbox_max"] - scene["bbox_min"]
+    brick = [float(ext[a]) / cfg["res"][a] * 8 for a in range(3)]          # 8^3 voxels per brick
+    slab = mg.slab_range(cfg["res"][2], rank, world) if world > 1 else (0, 0)
+    hip = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, slab=slab)
+    hip.setUseBricks(cfg["use_bricks"]); hip.setSpaceSkip(cfg["skip_space"]); hip.setColorFilling(cfg["fill_holes"])
+    stream = torch.cuda.current_stream()
+    hip.set_stream(stream.cuda_stream)         # kernels, HIP event timers and the collectives share one stream
+    drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW)
+    mv, pr = rr.scene.default_view(*VIEW)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        drv.frame(mv, pr)
+    barrier()
+    hip.enable_timers(not args.no_timers)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.frame(mv, pr)
+    barrier()
+    dt = time.perf_counter() - t0
+    hip.enable_timers(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel device time from HIP events recorded on the launch stream during the timed region
+    stages = {}
+    if not args.no_timers:
+        for name in ("bricks", "2integrate", "brickdraw", "draw", "holefill", "3recon"):
+            n, ms = hip.timer_stats(name)
+            if n:
+                stages[name] = ms / n
+    ratio = hip.occupiedRatio()
+    ab = algorithmic_bytes(cfg, cfg["streams"], world)
+    out = {
+        "metric": "frames/sec (integrate+raymarch) at 512^3 x 4 streams" if args.config == "c2" else "frames/sec (integrate+raymarch) at 256^3 x 4 streams",
+        "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["name"], "config": args.config, "streams": cfg["streams"], "res": list(cfg["res"]),
+                   "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio,
+                   "parallelism": "single GPU" if world == 1 else f"{world} Z-slabs, RCCL halo all-gather + partial-image gather"},
+        "stage_ms": stages,
+    }
+    if "2integrate" in stages:
+        dom = max((k for k in ("2integrate", "draw") if k in stages), key=lambda k: stages[k])
+        key = "integrate" if dom == "2integrate" else "raymarch"
+        ach = ab[key] / (stages[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_integrate" if key == "integrate" else "k_raymarch",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes": ab[key], "avg_launch_ms": stages[dom]}
+        frame_bytes = ab["integrate"] + ab["raymarch"] + (ab["inpaint"] if cfg["fill_holes"] else 0)
+        out["frame_roofline"] = {"algorithmic_bytes": frame_bytes, "achieved": frame_bytes / (dt / args.steps) / 1e9,
+                                 "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene, cfg, limit, brick)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

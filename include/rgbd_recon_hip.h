@@ -140,6 +140,8 @@ int32_t tsdf_composite_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n);
  * "2integrate" brackets exactly the integrate kernel launch, "draw" exactly the raymarch kernel -------------------------------------------------------------- */
 int32_t tsdf_enable_timers(tsdf_ctx* ctx, int32_t active);
 int32_t tsdf_timer_ms(tsdf_ctx* ctx, const char* name, float* last_ms);   /* synchronises on that timer */
+/* every invocation since the previous call: count and summed device time; resets the timer */
+int32_t tsdf_timer_stats(tsdf_ctx* ctx, const char* name, uint32_t* count, float* total_ms);
 
 #ifdef __cplusplus
 }

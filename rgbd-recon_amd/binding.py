@@ -245,6 +245,11 @@ class ReconIntegrationHip:
         self._ck(self._L.tsdf_timer_ms(self._c, name.encode(), C.byref(ms)))
         return ms.value
 
+    def timer_stats(self, name):
+        n, ms = C.c_uint32(), C.c_float()
+        self._ck(self._L.tsdf_timer_stats(self._c, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def halo_info(self):
         layers, nbytes = C.c_uint32(), C.c_uint64()
         self._ck(self._L.tsdf_halo_info(self._c, C.byref(layers), C.byref(nbytes)))

@@ -18,7 +18,9 @@ using namespace rr;
 namespace {
 thread_local std::string g_create_error;
 
-struct Timer { hipEvent_t a = nullptr, b = nullptr; bool recorded = false; };
+// One named timer = a pool of event pairs, one pair per invocation since the last tsdf_timer_stats()
+struct Timer { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; bool open = false; };
+constexpr size_t kMaxTimerPairs = 8192;
 
 struct BrickRange { uint32_t lo[3], hi[3]; };
 }  // namespace
@@ -205,15 +207,21 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
 void timer_begin(tsdf_ctx* c, const char* name) {
   if (!c->timers_on) return;
   Timer& t = c->timers[name];
-  if (!t.a) { hipEventCreate(&t.a); hipEventCreate(&t.b); }
-  hipEventRecord(t.a, c->stream);
+  if (t.used == t.ev.size()) {
+    if (t.ev.size() >= kMaxTimerPairs) { t.used = t.ev.size() - 1; }      // saturate: overwrite the last pair
+    else { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); t.ev.emplace_back(a, b); }
+  }
+  hipEventRecord(t.ev[t.used].first, c->stream);
+  t.open = true;
 }
 void timer_end(tsdf_ctx* c, const char* name) {
   if (!c->timers_on) return;
-  Timer& t = c->timers[name];
-  if (!t.a) return;
-  hipEventRecord(t.b, c->stream);
-  t.recorded = true;
+  auto it = c->timers.find(name);
+  if (it == c->timers.end() || !it->second.open) return;
+  Timer& t = it->second;
+  hipEventRecord(t.ev[t.used].second, c->stream);
+  t.used++;
+  t.open = false;
 }
 
 // draw() matrix block, recon_integration.cpp:182-205 (+ vol_to_world :66-72)
@@ -358,7 +366,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
   for (void* p : c->lut_allocs) hipFree(p);
   if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
-  for (auto& kv : c->timers) { if (kv.second.a) hipEventDestroy(kv.second.a); if (kv.second.b) hipEventDestroy(kv.second.b); }
+  for (auto& kv : c->timers) for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
   return TSDF_OK;
@@ -716,9 +724,28 @@ int32_t tsdf_timer_ms(tsdf_ctx* c, const char* name, float* ms) {
   CHECK_CTX(c);
   if (!name || !ms) return TSDF_ERR_INVALID_ARGUMENT;
   auto it = c->timers.find(name);
-  if (it == c->timers.end() || !it->second.recorded) FAIL(c, TSDF_ERR_STATE, "timer '%s' has not run", name);
-  HIP_TRY(c, hipEventSynchronize(it->second.b));
-  HIP_TRY(c, hipEventElapsedTime(ms, it->second.a, it->second.b));
+  if (it == c->timers.end() || it->second.used == 0) FAIL(c, TSDF_ERR_STATE, "timer '%s' has not run", name);
+  auto& e = it->second.ev[it->second.used - 1];
+  HIP_TRY(c, hipEventSynchronize(e.second));
+  HIP_TRY(c, hipEventElapsedTime(ms, e.first, e.second));
+  return TSDF_OK;
+}
+int32_t tsdf_timer_stats(tsdf_ctx* c, const char* name, uint32_t* count, float* total_ms) {
+  CHECK_CTX(c);
+  if (!name || !count || !total_ms) return TSDF_ERR_INVALID_ARGUMENT;
+  *count = 0; *total_ms = 0.0f;
+  auto it = c->timers.find(name);
+  if (it == c->timers.end()) return TSDF_OK;
+  Timer& t = it->second;
+  double sum = 0.0;
+  for (size_t i = 0; i < t.used; ++i) {
+    float ms = 0.0f;
+    HIP_TRY(c, hipEventSynchronize(t.ev[i].second));
+    HIP_TRY(c, hipEventElapsedTime(&ms, t.ev[i].first, t.ev[i].second));
+    sum += ms;
+  }
+  *count = (uint32_t)t.used; *total_ms = (float)sum;
+  t.used = 0;
   return TSDF_OK;
 }
 
