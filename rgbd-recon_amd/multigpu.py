@@ -54,11 +54,11 @@ class SlabDriver:
 
     def _all_gather(self, out, inp):
         if self.stage_cpu:
-            o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
-            out.copy_(o)
+            o = torch.empty(out.numel(), dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.reshape(-1).cpu(), group=self.group)
+            out.view(-1).copy_(o)
         else:
-            dist.all_gather_into_tensor(out, inp, group=self.group)
+            dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
 
     def _gather0(self, out, inp):
         if self.stage_cpu:
@@ -94,3 +94,30 @@ class SlabDriver:
         if self.rank == 0:
             b.composite_dev(self.parts.data_ptr(), self.world)
             b.fillColors()
+
+
+def frame_slabs_on_one_device(backends, mv, proj, device):
+    """The same partition with ONE visible device (SURVEY.md §8e fallback): the slabs run one after another and the
+    "collectives" are device-to-device copies.  Used to check slab results against the unpartitioned volume on a 1-GPU box.
+    backends[k] owns slab k; the composite lands in backends[0]."""
+    world = len(backends)
+    layers, nbytes = backends[0].halo_info()
+    n = nbytes // 4
+    faces = torch.empty((world, 2, n), dtype=torch.float32, device=device)
+    npx = backends[0].view[0] * backends[0].view[1]
+    parts = torch.empty((world, npx * 6), dtype=torch.float32, device=device)
+    for k, b in enumerate(backends):
+        b.clearOccupiedBricks(); b.markBricks(); b.updateOccupiedBricks(False)
+        b.integrate()
+        b.halo_pack_dev(faces[k, 0].data_ptr(), faces[k, 1].data_ptr())
+        b.sync()
+    for k, b in enumerate(backends):
+        below = faces[k - 1, 1].data_ptr() if k > 0 else 0
+        above = faces[k + 1, 0].data_ptr() if k < world - 1 else 0
+        b.halo_unpack_dev(below, above)
+        b.draw(mv, proj)
+        b.export_partial_dev(parts[k].data_ptr())
+        b.sync()
+    backends[0].composite_dev(parts.data_ptr(), world)
+    backends[0].fillColors()
+    backends[0].sync()

@@ -1,0 +1,62 @@
+"""The C-ABI shared library loads and exports every symbol include/rgbd_recon_hip.h declares (no compute: CPU box)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(rr):
+    syms = rr.declared_symbols()
+    assert len(syms) >= 40 and "tsdf_integrate" in syms and "tsdf_raymarch" in syms and "tsdf_fill_colors" in syms
+    lib = rr.load_library()
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_config_struct_layout_matches_header(rr):
+    text = open(rr.HEADER_PATH).read()
+    body = re.search(r"typedef struct tsdf_config \{(.*?)\} tsdf_config;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(",")[0:]:
+            m = re.search(r"([a-z_0-9]+)\s*(\[\d+\])?\s*$", part.strip())
+            names.append(m.group(1))
+    assert names == [f[0] for f in rr.TsdfConfig._fields_]
+    assert ctypes.sizeof(rr.TsdfConfig) == 4 + 24 + 4 + 12 + 12 + 4 + 4 * 7 + 4 + 8
+
+
+def test_create_without_a_device_fails_loudly(rr):
+    """No CPU fallback: on a box without a GPU tsdf_create returns TSDF_ERR_NO_DEVICE, it does not compute."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is visible")
+    scene = rr.scene.make_scene(n_streams=1, width=16, height=12, lut_res=4, inv_res=4)
+    with pytest.raises(rr.TsdfError) as e:
+        rr.ReconIntegrationHip(scene, res=(8, 8, 8), brick_size=1.0, limit=0.01, view=(16, 16))
+    assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_bad_config_is_rejected_before_touching_the_gpu(rr):
+    lib = rr.load_library()
+    cfg = rr.TsdfConfig()
+    ctx = ctypes.c_void_p()
+    assert lib.tsdf_create(ctypes.byref(cfg), ctypes.byref(ctx)) == -1          # struct_size mismatch
+    assert b"struct_size" in lib.tsdf_last_error(None)
+    assert lib.tsdf_create(None, ctypes.byref(ctx)) == -1
+    assert lib.tsdf_integrate(None) == -1 and lib.tsdf_destroy(None) == -1
+
+
+def test_product_does_not_reference_the_oracle():
+    """oracle/ is test infrastructure: nothing under rgbd-recon_amd/ or include/ may import, include or link it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for base in ("rgbd-recon_amd", "include"):
+        for d, _, files in os.walk(os.path.join(root, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                    txt = open(os.path.join(d, f), errors="ignore").read()
+                    assert "tsdf_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(d, f)
