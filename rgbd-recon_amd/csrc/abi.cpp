@@ -326,6 +326,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   const bool whole = (V.own_tz0 == 0 && V.own_tz1 == ntz);
   V.tz0 = whole ? 0 : std::max(0, V.own_tz0 - c->halo_layers);
   V.tz1 = whole ? ntz : std::min(ntz, V.own_tz1 + c->halo_layers);
+  V.zlo = V.tz0 * 8; V.zhi = std::min(V.tz1 * 8, c->res[2]) - 1;
   if (!whole && V.own_tz1 - V.own_tz0 < c->halo_layers) { c->err = "slab thinner than its halo"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
   const size_t nvox = (size_t)(V.tz1 - V.tz0) * V.nty * V.ntx * TILE_VOX;
   int32_t rc;

@@ -95,7 +95,12 @@ __device__ __forceinline__ size_t vol_index(const Volume& V, int x, int y, int z
   return (tile << 9) + ((z & 7) << 6) + ((y & 7) << 3) + (x & 7);
 }
 __device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) {
-  const Axis X = axis_linear(u, V.res[0]), Y = axis_linear(v, V.res[1]), Z = axis_linear(w, V.res[2]);
+  const Axis X = axis_linear(u, V.res[0]), Y = axis_linear(v, V.res[1]);
+  Axis Z = axis_linear(w, V.res[2]);
+  // A slab context stores only planes [zlo, zhi].  Owned samples never leave them; a NaN position (NaN voxels exist,
+  // tsdf_integration.vs:52) would clamp to plane 0, so keep the taps inside the allocation (the result is NaN anyway).
+  Z.i0 = clampi(Z.i0, V.zlo, V.zhi);
+  Z.i1 = clampi(Z.i1, V.zlo, V.zhi);
   const float* __restrict__ t = V.data;
   const float c00 = lerpf(t[vol_index(V, X.i0, Y.i0, Z.i0)], t[vol_index(V, X.i1, Y.i0, Z.i0)], X.a);
   const float c10 = lerpf(t[vol_index(V, X.i0, Y.i1, Z.i0)], t[vol_index(V, X.i1, Y.i1, Z.i0)], X.a);

@@ -37,6 +37,7 @@ struct Volume {
   int ntx, nty;        // tiles per axis (x, y); z tiles stored: [tz0, tz1)
   int tz0, tz1;        // stored tile layers (owned slab + halo)
   int own_tz0, own_tz1;  // owned tile layers (integrated by this context)
+  int zlo, zhi;        // stored voxel planes [zlo, zhi]: every Z tap is clamped into them (slab contexts)
   float limit;
 };
 
