@@ -34,6 +34,7 @@ struct tsdf_ctx {
   int res[3]{};
   float vox[3]{};
   Volume vol{};
+  TileState tiles{};
   int halo_layers = 0;
   // bricks
   float brick_req[3]{};          // requested size (setBrickSize argument)
@@ -107,8 +108,8 @@ void release_view(tsdf_ctx* c) {
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
 void release_bricks(tsdf_ctx* c) {
-  hipFree(c->br.counters); hipFree(c->br.flags); hipFree(c->br.num_occupied);
-  c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr;
+  hipFree(c->br.counters); hipFree(c->br.flags); hipFree(c->br.num_occupied); hipFree(c->br.occupied);
+  c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr;
   for (int a = 0; a < 3; ++a) { hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); c->d_vox_first[a] = nullptr; c->d_vox_count[a] = nullptr; }
 }
 
@@ -195,9 +196,16 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
     B.vox_first[a] = c->d_vox_first[a];
     B.vox_count[a] = c->d_vox_count[a];
   }
+  // tiles == bricks structurally?  (every voxel in exactly one brick per axis, and a tile never straddles two)
+  bool uniform = true;
+  for (int a = 0; a < 3 && uniform; ++a)
+    for (int v = 0; v < c->res[a] && uniform; ++v)
+      uniform = count[a][v] == 1 && first[a][v] == first[a][v & ~7];
+  c->tiles.uniform = uniform ? 1 : 0;
   HIP_TRY(c, hipMalloc(&B.counters, (size_t)B.n * sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&B.flags, (size_t)B.n));
   HIP_TRY(c, hipMalloc(&B.num_occupied, sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc(&B.occupied, (size_t)B.n * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(B.counters, 0, (size_t)B.n * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(B.flags, 0, (size_t)B.n));
   HIP_TRY(c, hipMemset(B.num_occupied, 0, sizeof(uint32_t)));
@@ -337,6 +345,15 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   };
   if ((rc = tryhip(hipMalloc(&V.data, nvox * sizeof(float)), "hipMalloc(volume)"))) return fail(rc);
   launch_fill_u32(c->stream, (uint32_t*)V.data, 0u, nvox);
+  TileState& S = c->tiles;
+  S.n = (V.own_tz1 - V.own_tz0) * V.nty * V.ntx;
+  if ((rc = tryhip(hipMalloc(&S.active, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&S.dirty, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&S.list, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&S.count, sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
+  hipMemsetAsync(S.active, 0, (size_t)S.n, c->stream);
+  hipMemsetAsync(S.count, 0, sizeof(uint32_t), c->stream);
+  launch_mark_all_dirty(c->stream, S);          // the fresh allocation does not hold -limit yet
   if ((rc = tryhip(hipHostMalloc((void**)&c->h_num_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc"))) return fail(rc);
   *c->h_num_occupied = 0;
   if ((rc = setup_bricks(c, cfg->brick_size))) return fail(rc);
@@ -363,6 +380,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   release_view(c); release_bricks(c);
+  hipFree(c->tiles.active); hipFree(c->tiles.dirty); hipFree(c->tiles.list); hipFree(c->tiles.count);
   hipFree(c->vol.data); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
   hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
   for (void* p : c->lut_allocs) hipFree(p);
@@ -489,7 +507,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "2integrate");
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->use_bricks ? 1 : 0);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0);
   timer_end(c, "2integrate");
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -548,6 +566,7 @@ int32_t tsdf_set_tsdf_limit(tsdf_ctx* c, float limit) {
   const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
   if (!whole && (int)ceilf((limit * 0.5f * (float)c->res[2] + 2.0f) / 8.0f) > c->halo_layers) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit needs a wider slab halo than this context allocated");
   c->vol.limit = limit;
+  launch_mark_all_dirty(c->stream, c->tiles);    // the clear value changed
   return TSDF_OK;
 }
 int32_t tsdf_set_use_bricks(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->use_bricks = a != 0; return TSDF_OK; }
@@ -610,6 +629,7 @@ int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_linear, in, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float), hipMemcpyHostToDevice, c->stream));
   launch_volume_from_linear(c->stream, c->vol, c->d_linear);
+  launch_mark_all_dirty(c->stream, c->tiles);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSDF_OK;
 }
@@ -638,7 +658,10 @@ int32_t tsdf_download_image(tsdf_ctx* c, float* rgba, float* depth, float* ns, f
   if (rgba) HIP_TRY(c, hipMemcpy2D(rgba, w * 16, R.color, (size_t)R.stride * 16, w * 16, h, hipMemcpyDeviceToHost));
   if (depth) HIP_TRY(c, hipMemcpy2D(depth, w * 4, R.depth, (size_t)R.stride * 4, w * 4, h, hipMemcpyDeviceToHost));
   if (ns) HIP_TRY(c, hipMemcpy(ns, c->d_nsamples, w * h * 4, hipMemcpyDeviceToHost));
-  if (peels) HIP_TRY(c, hipMemcpy(peels, c->d_peels, w * h * 16, hipMemcpyDeviceToHost));
+  if (peels) {
+    HIP_TRY(c, hipMemcpy(peels, c->d_peels, w * h * 16, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < w * h; ++i) { peels[4 * i + 1] = -peels[4 * i + 1]; peels[4 * i + 3] = 0.0f; }   // device keeps max z; reference keeps min(-z)
+  }
   return TSDF_OK;
 }
 int32_t tsdf_upload_image(tsdf_ctx* c, const float* rgba, const float* depth) {

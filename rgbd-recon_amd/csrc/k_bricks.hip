@@ -74,13 +74,18 @@ void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages&
   hipLaunchKernelGGL(k_mark_bricks, grid, dim3(256), 0, st, T, F, B);
 }
 
-// flags[b] = counter[b] >= min_voxels; *num_occupied = popcount (one atomic per wave)
+// flags[b] = counter[b] >= min_voxels, the compacted occupied list and its length (one atomic per wave)
 __global__ __launch_bounds__(256) void k_update_occupied(Bricks B, uint32_t min_voxels) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const bool occ = (b < B.n) && (B.counters[b] >= min_voxels);
   if (b < B.n) B.flags[b] = occ ? 1 : 0;
   const unsigned long long m = __ballot(occ);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(B.num_occupied, (uint32_t)__popcll(m));
+  if (m == 0ull) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(B.num_occupied, (uint32_t)__popcll(m));
+  base = __shfl(base, 0);
+  if (occ) B.occupied[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
 }
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels) {
   hipMemsetAsync(B.num_occupied, 0, sizeof(uint32_t), st);

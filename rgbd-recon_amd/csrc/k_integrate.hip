@@ -1,10 +1,14 @@
 // K0 + K1: TSDF integration (tsdf_integration.vs:23-59 driven by ReconIntegration::integrate(),
-// recon_integration.cpp:242-269), fused with the volume clear.
+// recon_integration.cpp:242-269).
 //
-// Launch shape: one 256-thread workgroup per 8x8x8 storage tile (2 KiB of HBM, written as two fully
-// coalesced 1 KiB wave-stores per wave).  Voxels that no occupied brick lists keep the clear value
-// -limit (the reference clears the volume and then only draws the occupied bricks' voxel lists);
-// a wave whose ballot of "drawn" voxels is empty skips the stream loop entirely.
+// The reference clears the whole volume and then draws the voxel lists of the occupied bricks, one GL
+// draw per brick.  Here one frame is three launches over 8x8x8 storage tiles (2 KiB each, tile-major):
+//   k_classify_tiles   which tiles contain a voxel of an occupied brick's list -> compact "active" list
+//   k_clear_tiles      tiles that are inactive but still hold old surface data are reset to -limit
+//                      (tiles already clear are not touched: no dense 4*V store per frame)
+//   k_integrate_tiles  active tiles only (persistent workgroups pulling from the list); a tile is written
+//                      as two fully coalesced 1 KiB stores per wave
+// Without bricks (setUseBricks(false)) every tile is active and the dense kernel runs on a plain grid.
 #include "sampling.hpp"
 
 namespace rr {
@@ -50,32 +54,105 @@ __device__ __forceinline__ bool voxel_drawn(const Bricks& B, int x, int y, int z
   return any;
 }
 
-__global__ __launch_bounds__(256) void k_integrate(StreamTable T, FrameImages F, Volume V, Bricks B, int use_bricks, int n_tiles) {
-  // XCD-aware mapping: blocks b, b+8, b+16.. share an XCD (round-robin dispatch); give each XCD one
-  // contiguous run of tiles so neighbouring tiles (shared LUT texels / image pixels) hit the same L2.
-  int tile = blockIdx.x;
-  if ((n_tiles & 7) == 0) tile = (blockIdx.x & 7) * (n_tiles >> 3) + (blockIdx.x >> 3);
-  const int tx = tile % V.ntx, ty = (tile / V.ntx) % V.nty, tz = V.own_tz0 + tile / (V.ntx * V.nty);
-  float* __restrict__ out = V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9);
-  const float sx = 1.0f / (float)V.res[0], sy = 1.0f / (float)V.res[1], sz = 1.0f / (float)V.res[2];   // volume_sampler.cpp:36-38
-  const float limit = V.limit;
+__device__ __forceinline__ void tile_coords(const Volume& V, int tile, int& tx, int& ty, int& tz) {
+  tx = tile % V.ntx; ty = (tile / V.ntx) % V.nty; tz = V.own_tz0 + tile / (V.ntx * V.nty);
+}
+
+// One thread per owned tile: any occupied brick among those whose voxel lists can reach into the tile?
+__global__ __launch_bounds__(256) void k_classify_tiles(Volume V, Bricks B, TileState S) {
+  const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile >= S.n) return;
+  int t[3];
+  tile_coords(V, tile, t[0], t[1], t[2]);
+  int b0[3], b1[3];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int l = threadIdx.x + half * 256;
-    const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
-    bool drawn = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
-    if (drawn && use_bricks) drawn = voxel_drawn(B, x, y, z);
-    float v = -limit;                                                   // clearImage(-limit), :249-250
-    if (__ballot(drawn) != 0ull) {
-      if (drawn) v = integrate_voxel(T, F, limit, ((float)x + 0.5f) * sx, ((float)y + 0.5f) * sy, ((float)z + 0.5f) * sz);
+  for (int a = 0; a < 3; ++a) {           // the per-axis tables are monotone: scan the tile's 8 voxels for the brick span
+    const int v0 = t[a] * 8, v1 = min(t[a] * 8 + 7, V.res[a] - 1);
+    int lo = 0x7fffffff, hi = -1;
+    for (int v = v0; v <= v1; ++v) {
+      const int f = B.vox_first[a][v], n = B.vox_count[a][v];
+      if (n) { lo = min(lo, f); hi = max(hi, f + n - 1); }
     }
-    out[l] = v;
+    b0[a] = lo; b1[a] = hi;
+  }
+  bool active = false;
+  for (int k = b0[2]; k <= b1[2]; ++k)
+    for (int j = b0[1]; j <= b1[1]; ++j)
+      for (int i = b0[0]; i <= b1[0]; ++i)
+        active |= B.flags[((size_t)k * B.res[1] + j) * B.res[0] + i] != 0;
+  S.active[tile] = active ? 1 : 0;
+  if (active) S.list[atomicAdd(S.count, 1u)] = (uint32_t)tile;      // hipcc folds this into one add per wave
+}
+
+// Reset inactive tiles that still hold surface data.  Each wave looks at 64 tiles per step (one coalesced
+// 64-byte read of each flag array) and streams -limit over the dirty ones: 2 x 16 B per lane per tile.
+__global__ __launch_bounds__(256) void k_clear_tiles(Volume V, TileState S) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float4 cv = make_float4(-V.limit, -V.limit, -V.limit, -V.limit);
+  for (int base = wave * 64; base < S.n; base += nwaves * 64) {
+    const int tile = base + lane;
+    const bool need = tile < S.n && !S.active[tile] && S.dirty[tile];
+    unsigned long long m = __ballot(need);
+    if (need) S.dirty[tile] = 0;
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      int tx, ty, tz;
+      tile_coords(V, base + b, tx, ty, tz);
+      float4* __restrict__ out = (float4*)(V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9));
+      out[lane] = cv;
+      out[lane + 64] = cv;
+    }
   }
 }
 
-void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, int use_bricks) {
-  const int n_tiles = V.ntx * V.nty * (V.own_tz1 - V.own_tz0);
-  hipLaunchKernelGGL(k_integrate, dim3(n_tiles), dim3(256), 0, st, T, F, V, B, use_bricks, n_tiles);
+template <bool kList>
+__global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
+  const float sx = 1.0f / (float)V.res[0], sy = 1.0f / (float)V.res[1], sz = 1.0f / (float)V.res[2];   // volume_sampler.cpp:36-38
+  const float limit = V.limit;
+  const int n_work = kList ? (int)*S.count : S.n;
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    int tile;
+    if (kList) tile = (int)S.list[w];
+    else {
+      // XCD-aware mapping: blocks b, b+8, b+16.. share an XCD (round-robin dispatch); give each XCD one
+      // contiguous run of tiles so neighbouring tiles (shared LUT texels / image pixels) hit the same L2.
+      tile = ((S.n & 7) == 0) ? (w & 7) * (S.n >> 3) + (w >> 3) : w;
+    }
+    int tx, ty, tz;
+    tile_coords(V, tile, tx, ty, tz);
+    float* __restrict__ out = V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int l = threadIdx.x + half * 256;
+      const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
+      bool drawn = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      if (drawn && per_voxel_check) drawn = voxel_drawn(B, x, y, z);
+      float v = -limit;                                                 // clearImage(-limit), :249-250
+      if (drawn) v = integrate_voxel(T, F, limit, ((float)x + 0.5f) * sx, ((float)y + 0.5f) * sy, ((float)z + 0.5f) * sz);
+      out[l] = v;
+    }
+    if (threadIdx.x == 0) S.dirty[tile] = 1;
+  }
+}
+
+void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks) {
+  if (use_bricks) {
+    hipMemsetAsync(S.count, 0, sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_classify_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
+    hipLaunchKernelGGL(k_clear_tiles, dim3(1024), dim3(256), 0, st, V, S);
+    hipLaunchKernelGGL(k_integrate_tiles<true>, dim3(S.n < 2048 ? S.n : 2048), dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+  } else {
+    hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fill_u8(uint8_t* __restrict__ p, uint8_t v, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_mark_all_dirty(hipStream_t st, const TileState& S) {
+  hipLaunchKernelGGL(k_fill_u8, dim3((S.n + 255) / 256 > 1024 ? 1024 : (S.n + 255) / 256), dim3(256), 0, st, S.dirty, (uint8_t)1, S.n);
 }
 
 // ---- linear <-> tile-major conversion for the download/upload entry points

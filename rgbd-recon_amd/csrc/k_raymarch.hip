@@ -2,10 +2,11 @@
 // and the TSDF raymarch (tsdf_raymarch.fs:62-134 via draw(), :176-240).
 //
 // The reference rasterises every exposed face of every occupied brick with MIN blending to get, per
-// pixel, (min z, -max z, min back-face z).  Here each pixel walks the brick grid layer by layer along
-// the ray's dominant axis and applies the same per-face test to the occupied cells it touches: one
-// thread per pixel, no atomics, no overdraw.  The raymarch then runs one ray per pixel (the reference
-// shades the front and the back cube face with identical results).
+// pixel, (min z, -max z, min back-face z).  Here one wave per occupied brick scatters the same values
+// with integer atomics on the float bit patterns (order independent, hence deterministic); the work is
+// proportional to the occupied bricks' screen footprint, not to rays x grid cells.  The raymarch then runs
+// one ray per pixel (the reference shades the front and the back cube face with identical results,
+// SURVEY.md Appendix C.3).
 #include "sampling.hpp"
 
 namespace rr {
@@ -38,89 +39,89 @@ __device__ __forceinline__ bool neighbour_gt10(const Bricks& B, int ix, int iy, 
   return id < (uint32_t)B.n ? (B.counters[id] > 10u) : false;
 }
 
-__global__ __launch_bounds__(256) void k_depth_limits(ViewParams P, Bricks B, float4* __restrict__ peels) {
-  // 8x8 pixel tile per wave, 2x2 waves per workgroup
-  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-  const int px = blockIdx.x * 16 + (wv & 1) * 8 + (ln & 7);
-  const int py = blockIdx.y * 16 + (wv >> 1) * 8 + (ln >> 3);
-  if (px >= P.w || py >= P.h) return;
-  float r = 1.0f, g = 0.0f, b = 1.0f;                                   // clear colour, recon_integration.cpp:144
-  const float3 dw = pixel_dir_world(P, (float)px + 0.5f, (float)py + 0.5f);
+// Depth peels live as float bit patterns so that MIN/MAX blending becomes integer atomics (all values are in
+// [0,1], where uint order == float order): x = min z, y = MAX z (the reference keeps min(-z)), z = min back-face z.
+__global__ __launch_bounds__(256) void k_clear_peels(uint4* __restrict__ peels, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) peels[i] = make_uint4(__float_as_uint(1.0f), 0u, __float_as_uint(1.0f), 0u);   // clear (1,0,1,0), recon_integration.cpp:144
+}
+
+// One wave per occupied brick (persistent, pulling from the compacted list).  For each exposed face the wave
+// sweeps the pixel bounding box of the projected face and applies the reference's fragment rule to every pixel
+// centre whose ray crosses the face rectangle: z from the ray/plane intersection, near/far clip, MIN blend.
+__global__ __launch_bounds__(64) void k_depth_limits(ViewParams P, Bricks B, uint4* __restrict__ peels) {
+  const int lane = threadIdx.x;
+  const int n_occ = (int)*B.num_occupied;
   const float o[3] = {P.cam_world[0], P.cam_world[1], P.cam_world[2]};
-  const float d[3] = {dw.x, dw.y, dw.z};
-  // ray / grid-bounds interval (conservative: one brick of slack on either end)
-  float tn = 0.0f, tf = 3.0e38f;
-  bool miss = false;
+  for (int w = blockIdx.x; w < n_occ; w += gridDim.x) {
+    const uint32_t id = B.occupied[w];
+    int idx[3];
+    idx[2] = (int)(id / (uint32_t)(B.res[0] * B.res[1]));                // index_3d(), inc_bricks.glsl:30-38
+    const uint32_t rem = id % (uint32_t)(B.res[0] * B.res[1]);
+    idx[1] = (int)(rem / (uint32_t)B.res[0]);
+    idx[0] = (int)(rem % (uint32_t)B.res[0]);
+    float lo[3], hi[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float lo = B.bbox_min[a], hi = B.bbox_min[a] + (float)B.res[a] * B.size[a];
-    if (d[a] == 0.0f) { miss |= (o[a] < lo || o[a] > hi); continue; }
-    const float t0 = (lo - o[a]) / d[a], t1 = (hi - o[a]) / d[a];
-    tn = fmaxf(tn, fminf(t0, t1));
-    tf = fminf(tf, fmaxf(t0, t1));
-  }
-  miss |= !(tn <= tf);
-  if (!miss) {
-    // dominant axis in brick units
-    const float s0 = fabsf(d[0] / B.size[0]), s1 = fabsf(d[1] / B.size[1]), s2 = fabsf(d[2] / B.size[2]);
-    const int A = (s0 >= s1 && s0 >= s2) ? 0 : (s1 >= s2 ? 1 : 2);
-    const int A1 = (A + 1) % 3, A2 = (A + 2) % 3;
-    const float ka = (o[A] + tn * d[A] - B.bbox_min[A]) / B.size[A], kb = (o[A] + tf * d[A] - B.bbox_min[A]) / B.size[A];
-    const int k0 = clampi((int)floorf(fminf(ka, kb)) - 1, 0, B.res[A] - 1);
-    const int k1 = clampi((int)floorf(fmaxf(ka, kb)) + 1, 0, B.res[A] - 1);
-    for (int k = k0; k <= k1; ++k) {
-      const float pl0 = B.bbox_min[A] + (float)k * B.size[A], pl1 = pl0 + B.size[A];
-      float ta = (pl0 - o[A]) / d[A], tb = (pl1 - o[A]) / d[A];
-      if (ta > tb) { const float t = ta; ta = tb; tb = t; }
-      if (tb < 0.0f) continue;
-      ta = fmaxf(ta, 0.0f);
-      // cell ranges on the two other axes, with a quarter-brick safety margin
-      const float u0 = (o[A1] + ta * d[A1] - B.bbox_min[A1]) / B.size[A1], u1 = (o[A1] + tb * d[A1] - B.bbox_min[A1]) / B.size[A1];
-      const float v0 = (o[A2] + ta * d[A2] - B.bbox_min[A2]) / B.size[A2], v1 = (o[A2] + tb * d[A2] - B.bbox_min[A2]) / B.size[A2];
-      const int i0 = max((int)floorf(fminf(u0, u1) - 0.25f), 0), i1 = min((int)floorf(fmaxf(u0, u1) + 0.25f), B.res[A1] - 1);
-      const int j0 = max((int)floorf(fminf(v0, v1) - 0.25f), 0), j1 = min((int)floorf(fmaxf(v0, v1) + 0.25f), B.res[A2] - 1);
-      for (int j = j0; j <= j1; ++j)
-        for (int i = i0; i <= i1; ++i) {
-          int idx[3];
-          idx[A] = k; idx[A1] = i; idx[A2] = j;
-          const size_t id = ((size_t)idx[2] * B.res[1] + idx[1]) * B.res[0] + idx[0];
-          if (!B.flags[id]) continue;
-          float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {                                         // to_world(), inc_bricks.glsl:22-24
+      lo[a] = (float)idx[a] * B.size[a] + B.bbox_min[a] + 0.0f * B.size[a];
+      hi[a] = (float)idx[a] * B.size[a] + B.bbox_min[a] + 1.0f * B.size[a];
+    }
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {                                 // to_world(), inc_bricks.glsl:22-24
-            lo[a] = (float)idx[a] * B.size[a] + B.bbox_min[a] + 0.0f * B.size[a];
-            hi[a] = (float)idx[a] * B.size[a] + B.bbox_min[a] + 1.0f * B.size[a];
-          }
+    for (int a = 0; a < 3; ++a) {
+      const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+      for (int dir = -1; dir <= 1; dir += 2) {
+        if (neighbour_gt10(B, idx[0], idx[1], idx[2], a, dir)) continue;  // shared face culled in the GS, bricks.gs:26-43
+        const float coord = dir < 0 ? lo[a] : hi[a];
+        // pixel bounding box of the face (conservative: +-1 px; whole screen if a corner is behind the eye)
+        float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f;
+        bool behind = false;
 #pragma unroll
-            for (int dir = -1; dir <= 1; dir += 2) {
-              if (neighbour_gt10(B, idx[0], idx[1], idx[2], a, dir)) continue;   // shared face culled in the GS
-              const float coord = dir < 0 ? lo[a] : hi[a];
-              const float t = (coord - o[a]) / d[a];
-              if (!(t > 0.0f)) continue;
-              const float q1 = o[a1] + t * d[a1], q2 = o[a2] + t * d[a2];
-              if (q1 < lo[a1] || q1 > hi[a1] || q2 < lo[a2] || q2 > hi[a2]) continue;
-              float hp[3];
-              hp[a] = coord; hp[a1] = q1; hp[a2] = q2;
-              const float ez = P.mv.m[2] * hp[0] + P.mv.m[6] * hp[1] + P.mv.m[10] * hp[2] + P.mv.m[14] * 1.0f;
-              const float zw = (P.proj.m[10] * ez + P.proj.m[14]) / (-ez) * 0.5f + 0.5f;
-              if (!(zw >= 0.0f && zw <= 1.0f)) continue;                // near / far clip
-              const bool front = dir > 0 ? (o[a] > coord) : (o[a] < coord);
-              r = fminf(r, zw);
-              g = fminf(g, -zw);
-              b = fminf(b, front ? 1.0f : zw);                          // bricks.fs:6
-            }
-          }
+        for (int c = 0; c < 4; ++c) {
+          float hp[3];
+          hp[a] = coord; hp[a1] = (c & 1) ? hi[a1] : lo[a1]; hp[a2] = (c & 2) ? hi[a2] : lo[a2];
+          const float4 e = mat_mul(P.mv, hp[0], hp[1], hp[2], 1.0f);
+          const float4 cl = mat_mul(P.proj, e.x, e.y, e.z, e.w);
+          behind |= !(cl.w > 1.0e-6f);
+          const float wx = (cl.x / cl.w * 0.5f + 0.5f) * (float)P.w, wy = (cl.y / cl.w * 0.5f + 0.5f) * (float)P.h;
+          bx0 = fminf(bx0, wx); bx1 = fmaxf(bx1, wx); by0 = fminf(by0, wy); by1 = fmaxf(by1, wy);
         }
+        int x0 = 0, x1 = P.w - 1, y0 = 0, y1 = P.h - 1;
+        if (!behind) {
+          x0 = max((int)floorf(fmaxf(bx0, -1.0e6f)) - 1, 0); x1 = min((int)floorf(fminf(bx1, 1.0e6f)) + 1, P.w - 1);
+          y0 = max((int)floorf(fmaxf(by0, -1.0e6f)) - 1, 0); y1 = min((int)floorf(fminf(by1, 1.0e6f)) + 1, P.h - 1);
+        }
+        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+        if (bw <= 0 || bh <= 0) continue;
+        const bool front = dir > 0 ? (o[a] > coord) : (o[a] < coord);     // gl_FrontFacing of an outward-wound cube
+        for (int k = lane; k < bw * bh; k += 64) {
+          const int px = x0 + k % bw, py = y0 + k / bw;
+          const float3 dw = pixel_dir_world(P, (float)px + 0.5f, (float)py + 0.5f);
+          const float d[3] = {dw.x, dw.y, dw.z};
+          const float t = (coord - o[a]) / d[a];
+          if (!(t > 0.0f)) continue;
+          const float q1 = o[a1] + t * d[a1], q2 = o[a2] + t * d[a2];
+          if (q1 < lo[a1] || q1 > hi[a1] || q2 < lo[a2] || q2 > hi[a2]) continue;
+          float hp[3];
+          hp[a] = coord; hp[a1] = q1; hp[a2] = q2;
+          const float ez = P.mv.m[2] * hp[0] + P.mv.m[6] * hp[1] + P.mv.m[10] * hp[2] + P.mv.m[14] * 1.0f;
+          const float zw = (P.proj.m[10] * ez + P.proj.m[14]) / (-ez) * 0.5f + 0.5f;
+          if (!(zw >= 0.0f && zw <= 1.0f)) continue;                      // near / far clip
+          uint32_t* pp = (uint32_t*)&peels[(size_t)py * P.w + px];
+          const uint32_t zb = __float_as_uint(zw);
+          atomicMin(pp + 0, zb);                                          // bricks.fs:6 with GL_MIN blending
+          atomicMax(pp + 1, zb);
+          if (!front) atomicMin(pp + 2, zb);
+        }
+      }
     }
   }
-  peels[(size_t)py * P.w + px] = make_float4(r, g, b, 0.0f);
 }
 void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels) {
-  dim3 grid((P.w + 15) / 16, (P.h + 15) / 16);
-  hipLaunchKernelGGL(k_depth_limits, grid, dim3(256), 0, st, P, B, peels);
+  const int n = P.w * P.h;
+  hipLaunchKernelGGL(k_clear_peels, dim3((n + 255) / 256), dim3(256), 0, st, (uint4*)peels, n);
+  const int grid = B.n < 8192 ? B.n : 8192;
+  hipLaunchKernelGGL(k_depth_limits, dim3(grid), dim3(64), 0, st, P, B, (uint4*)peels);
 }
 
 // ------------------------------------------------------------------------------------------- K2
@@ -228,11 +229,12 @@ __global__ __launch_bounds__(256) void k_raymarch(ViewParams P, StreamTable T, F
   float3 pos = make_float3(0, 0, 0);
   bool covered = true;
   if (P.skip) {                                                         // getStartPos(), :384-393
-    const float4 dm = R.peels[(size_t)py * P.w + px];
-    float r = dm.x;
-    r = (r >= dm.z) ? 0.0f : r;
+    const uint4 dmb = ((const uint4*)R.peels)[(size_t)py * P.w + px];
+    const float dm_r = __uint_as_float(dmb.x), dm_g = -__uint_as_float(dmb.y), dm_b = __uint_as_float(dmb.z);   // g = min(-z) = -max z
+    float r = dm_r;
+    r = (r >= dm_b) ? 0.0f : r;
     const float3 pf = screen_to_vol(P, fx, fy, r);
-    float3 pb = screen_to_vol(P, fx, fy, -dm.y);
+    float3 pb = screen_to_vol(P, fx, fy, -dm_g);
     if (r >= 1.0f) pb = pf;
     pos = pf;
     const float3 dd = make_float3(pf.x - pb.x, pf.y - pb.y, pf.z - pb.z);

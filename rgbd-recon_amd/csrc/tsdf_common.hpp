@@ -41,6 +41,20 @@ struct Volume {
   float limit;
 };
 
+// Per-tile bookkeeping of the owned tiles (index = owned tile id, x fastest, own_tz0 first):
+//   active  this frame: some voxel of the tile is in the voxel list of an occupied brick
+//   dirty   the tile's 2 KiB in HBM differ from the clear value -limit
+// integrate() clears only dirty inactive tiles and computes only active ones, so a frame's volume traffic
+// follows the occupied bricks instead of the whole volume (the reference clears everything, :249-250).
+struct TileState {
+  uint8_t* active;
+  uint8_t* dirty;
+  uint32_t* list;      // compacted active tile ids (unordered)
+  uint32_t* count;     // device scalar
+  int n;               // owned tiles
+  int uniform;         // every tile lies inside exactly one brick's voxel list: tile active => all its voxels drawn
+};
+
 // Occupancy bricks (inc_bricks.glsl:10-20) plus the voxel -> brick tables that restate
 // VolumeSampler::containedVoxels (volume_sampler.cpp:50-62): along axis a voxel v lies in bricks
 // [first[a][v], first[a][v] + count[a][v]).
@@ -48,6 +62,7 @@ struct Bricks {
   uint32_t* counters;       // per brick
   uint8_t* flags;           // counter >= min_voxels (recon_integration.cpp:436)
   uint32_t* num_occupied;   // device scalar
+  uint32_t* occupied;       // compacted ids of the occupied bricks (Occupied SSBO, inc_bricks.glsl:18-20), unordered
   const uint16_t* vox_first[3];
   const uint8_t* vox_count[3];
   int res[3];               // brick grid
@@ -81,7 +96,8 @@ void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t 
 void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
 void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B);
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels);
-void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, int use_bricks);
+void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks);
+void launch_mark_all_dirty(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
 void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* linear);
 void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels);
