@@ -42,13 +42,18 @@ struct tsdf_ctx {
   std::vector<BrickRange> ranges;
   uint16_t* d_vox_first[3]{};
   uint8_t* d_vox_count[3]{};
+  uint16_t* d_tile_b0[3]{};
+  uint16_t* d_tile_b1[3]{};
+  bool occ_count_zeroed = false, tile_count_zeroed = false;   // the two device scalars were reset by tsdf_clear_bricks' memset
   uint32_t min_voxels = 10;      // recon_integration.cpp:59
   uint32_t* h_num_occupied = nullptr;   // pinned
   // calibration + frame
   StreamTable luts{};
   std::vector<void*> lut_allocs;
   bool have_calib[TSDF_MAX_STREAMS]{};
+  bool lds_ok[TSDF_MAX_STREAMS]{};   // the stream's per-tile LUT box fits the integrate kernel's LDS budget
   FrameImages frame{};
+  float* d_depth_plane = nullptr;
   float* d_stage_depth = nullptr; float* d_stage_q = nullptr; float* d_stage_s = nullptr; uint8_t* d_stage_col = nullptr;
   bool have_frame = false;
   // view
@@ -108,9 +113,12 @@ void release_view(tsdf_ctx* c) {
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
 void release_bricks(tsdf_ctx* c) {
-  hipFree(c->br.counters); hipFree(c->br.flags); hipFree(c->br.num_occupied); hipFree(c->br.occupied);
-  c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr;
-  for (int a = 0; a < 3; ++a) { hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); c->d_vox_first[a] = nullptr; c->d_vox_count[a] = nullptr; }
+  hipFree(c->br.counters); hipFree(c->br.flags); hipFree(c->br.occupied);   // num_occupied and tiles.count live behind the counters
+  c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr; c->tiles.count = nullptr;
+  for (int a = 0; a < 3; ++a) {
+    hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); hipFree(c->d_tile_b0[a]); hipFree(c->d_tile_b1[a]);
+    c->d_vox_first[a] = nullptr; c->d_vox_count[a] = nullptr; c->d_tile_b0[a] = nullptr; c->d_tile_b1[a] = nullptr;
+  }
 }
 
 // ViewLod::setResolution, view_lod.cpp:24-50; resize(), recon_integration.cpp:482-500
@@ -195,6 +203,20 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
     HIP_TRY(c, hipMemcpy(c->d_vox_count[a], count[a].data(), c->res[a] * sizeof(uint8_t), hipMemcpyHostToDevice));
     B.vox_first[a] = c->d_vox_first[a];
     B.vox_count[a] = c->d_vox_count[a];
+    const int nt = (c->res[a] + 7) / 8;
+    std::vector<uint16_t> t0(nt, 1), t1(nt, 0);
+    for (int t = 0; t < nt; ++t) {
+      int lo = 0x7fffffff, hi = -1;
+      for (int v = t * 8; v < std::min(t * 8 + 8, c->res[a]); ++v)
+        if (count[a][v]) { lo = std::min(lo, (int)first[a][v]); hi = std::max(hi, (int)first[a][v] + count[a][v] - 1); }
+      if (hi >= 0) { t0[t] = (uint16_t)lo; t1[t] = (uint16_t)hi; }
+    }
+    HIP_TRY(c, hipMalloc(&c->d_tile_b0[a], nt * sizeof(uint16_t)));
+    HIP_TRY(c, hipMalloc(&c->d_tile_b1[a], nt * sizeof(uint16_t)));
+    HIP_TRY(c, hipMemcpy(c->d_tile_b0[a], t0.data(), nt * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tile_b1[a], t1.data(), nt * sizeof(uint16_t), hipMemcpyHostToDevice));
+    B.tile_b0[a] = c->d_tile_b0[a];
+    B.tile_b1[a] = c->d_tile_b1[a];
   }
   // tiles == bricks structurally?  (every voxel in exactly one brick per axis, and a tile never straddles two)
   bool uniform = true;
@@ -202,13 +224,15 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
     for (int v = 0; v < c->res[a] && uniform; ++v)
       uniform = count[a][v] == 1 && first[a][v] == first[a][v & ~7];
   c->tiles.uniform = uniform ? 1 : 0;
-  HIP_TRY(c, hipMalloc(&B.counters, (size_t)B.n * sizeof(uint32_t)));
+  // [counters (n) | num_occupied | active tile count]: one memset per frame resets all three (tsdf_clear_bricks)
+  HIP_TRY(c, hipMalloc(&B.counters, ((size_t)B.n + 2) * sizeof(uint32_t)));
+  B.num_occupied = B.counters + B.n;
+  c->tiles.count = B.counters + B.n + 1;
   HIP_TRY(c, hipMalloc(&B.flags, (size_t)B.n));
-  HIP_TRY(c, hipMalloc(&B.num_occupied, sizeof(uint32_t)));
   HIP_TRY(c, hipMalloc(&B.occupied, (size_t)B.n * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemset(B.counters, 0, (size_t)B.n * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(B.counters, 0, ((size_t)B.n + 2) * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(B.flags, 0, (size_t)B.n));
-  HIP_TRY(c, hipMemset(B.num_occupied, 0, sizeof(uint32_t)));
+  c->occ_count_zeroed = c->tile_count_zeroed = false;
   return TSDF_OK;
 }
 
@@ -350,9 +374,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if ((rc = tryhip(hipMalloc(&S.active, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc(&S.dirty, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc(&S.list, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
-  if ((rc = tryhip(hipMalloc(&S.count, sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
   hipMemsetAsync(S.active, 0, (size_t)S.n, c->stream);
-  hipMemsetAsync(S.count, 0, sizeof(uint32_t), c->stream);
   launch_mark_all_dirty(c->stream, S);          // the fresh allocation does not hold -limit yet
   if ((rc = tryhip(hipHostMalloc((void**)&c->h_num_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc"))) return fail(rc);
   *c->h_num_occupied = 0;
@@ -363,6 +385,8 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   const size_t np = (size_t)cfg->num_streams * F.w * F.h, nc = (size_t)cfg->num_streams * F.cw * F.ch;
   if ((rc = tryhip(hipMalloc((void**)&F.dqs, np * sizeof(float4)), "hipMalloc(frame)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc((void**)&F.color, nc * sizeof(uchar4)), "hipMalloc(colour)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&c->d_depth_plane, np * sizeof(float)), "hipMalloc(depth)"))) return fail(rc);
+  F.depth = c->d_depth_plane;
   if ((rc = tryhip(hipMalloc(&c->d_stage_depth, np * 8), "hipMalloc(stage)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc(&c->d_stage_q, np * 4), "hipMalloc(stage)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc(&c->d_stage_s, np * 4), "hipMalloc(stage)"))) return fail(rc);
@@ -380,9 +404,9 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   release_view(c); release_bricks(c);
-  hipFree(c->tiles.active); hipFree(c->tiles.dirty); hipFree(c->tiles.list); hipFree(c->tiles.count);
+  hipFree(c->tiles.active); hipFree(c->tiles.dirty); hipFree(c->tiles.list);
   hipFree(c->vol.data); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
-  hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
+  hipFree(c->d_depth_plane); hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
   for (void* p : c->lut_allocs) hipFree(p);
   if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
   for (auto& kv : c->timers) for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -431,6 +455,18 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
     HIP_TRY(c, hipMemcpy(d, padded.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     L.xyz = d; for (int a = 0; a < 3; ++a) L.xyz_res[a] = (int)rx[a];
   }
+  // largest LUT texel box any 8^3 tile touches, with the kernel's own fp32 index arithmetic
+  int box = 1;
+  for (int a = 0; a < 3; ++a) {
+    const float step = 1.0f / (float)c->res[a];
+    const int n = (int)ri[a];
+    auto idx0 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k, 0), n - 1); };
+    auto idx1 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k + 1, 0), n - 1); };
+    int worst = 1;
+    for (int t = 0; t * 8 < c->res[a]; ++t) worst = std::max(worst, idx1(std::min(t * 8 + 7, c->res[a] - 1)) - idx0(t * 8) + 1);
+    box *= worst;
+  }
+  c->lds_ok[i] = box <= integrate_box_cap();
   c->have_calib[i] = true;
   return TSDF_OK;
 }
@@ -444,7 +480,7 @@ int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quali
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_depth, depth_rg, np * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_q, quality, np * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_s, silhouette, np * 4, hipMemcpyHostToDevice, c->stream));
-  launch_pack_frame(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, np);
+  launch_pack_frame(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, c->d_depth_plane, np);
   if (colour) {
     HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
     launch_pack_color(c->stream, c->d_stage_col, (uchar4*)F.color, nc);
@@ -468,7 +504,8 @@ int32_t tsdf_clear_bricks(tsdf_ctx* c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "bricks");
-  HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, (size_t)c->br.n * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, ((size_t)c->br.n + 2) * sizeof(uint32_t), c->stream));
+  c->occ_count_zeroed = c->tile_count_zeroed = true;
   return TSDF_OK;
 }
 int32_t tsdf_mark_bricks(tsdf_ctx* c) {
@@ -483,7 +520,8 @@ int32_t tsdf_mark_bricks(tsdf_ctx* c) {
 int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  launch_update_occupied(c->stream, c->br, c->min_voxels);
+  launch_update_occupied(c->stream, c->br, c->min_voxels, c->occ_count_zeroed ? 0 : 1);
+  c->occ_count_zeroed = false;
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(c->h_num_occupied, c->br.num_occupied, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   timer_end(c, "bricks");
@@ -507,7 +545,10 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "2integrate");
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0);
+  bool lds = true;
+  for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = lds && c->lds_ok[i];
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->tile_count_zeroed ? 0 : 1);
+  if (c->use_bricks) c->tile_count_zeroed = false;
   timer_end(c, "2integrate");
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -544,7 +585,7 @@ int32_t tsdf_fill_colors(tsdf_ctx* c) {
   if (!c->fill_holes) FAIL(c, TSDF_ERR_STATE, "colour filling is off: the raymarch did not render into the pyramid");
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "holefill");
-  for (int i = 1; i < c->atlas.num_lods; ++i) launch_inpaint_level(c->stream, c->atlas, i - 1);
+  launch_inpaint_pyramid(c->stream, c->atlas);
   launch_colorfill(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d);
   timer_end(c, "holefill");
   HIP_TRY(c, hipGetLastError());

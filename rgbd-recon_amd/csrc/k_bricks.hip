@@ -7,9 +7,12 @@
 namespace rr {
 
 __global__ __launch_bounds__(256) void k_pack_frame(const float2* __restrict__ depth_rg, const float* __restrict__ quality,
-                                                    const float* __restrict__ silhouette, float4* __restrict__ dqs, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    dqs[i] = make_float4(depth_rg[i].x, quality[i], silhouette[i], 0.0f);
+                                                    const float* __restrict__ silhouette, float4* __restrict__ dqs, float* __restrict__ depth, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = depth_rg[i].x;
+    dqs[i] = make_float4(d, quality[i], silhouette[i], 0.0f);
+    depth[i] = d;
+  }
 }
 __global__ __launch_bounds__(256) void k_pack_color(const uint8_t* __restrict__ rgb, uchar4* __restrict__ rgba, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -23,8 +26,8 @@ static inline int grid_for(size_t n, int block = 256, int cap = 2048) {
   size_t g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
 }
-void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, size_t n) {
-  hipLaunchKernelGGL(k_pack_frame, dim3(grid_for(n)), dim3(256), 0, st, (const float2*)depth_rg, quality, silhouette, dqs, n);
+void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, size_t n) {
+  hipLaunchKernelGGL(k_pack_frame, dim3(grid_for(n)), dim3(256), 0, st, (const float2*)depth_rg, quality, silhouette, dqs, depth, n);
 }
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n) {
   hipLaunchKernelGGL(k_pack_color, dim3(grid_for(n)), dim3(256), 0, st, rgb, rgba, n);
@@ -36,38 +39,58 @@ void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n) {
 // texture(sampler3D RGB32F (stored RGBA), p).xyz -- forward LUT cv_xyz
 __device__ __forceinline__ float sgnf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
 
-// One thread per depth pixel and stream.  Atomics go to the brick counters in L2; hipcc folds the
-// per-wave duplicates of a `+1` into one add per distinct address group where it can.
+// counters[id] += (number of lanes holding id), one atomic per distinct id in the wave.  Neighbouring pixels of a
+// row fall into the same few bricks, so a wave issues a handful of atomics instead of up to 64 contended ones.
+__device__ __forceinline__ void wave_count(uint32_t* __restrict__ counters, uint32_t id, bool valid) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t lid = __shfl(id, leader);
+    const unsigned long long same = __ballot(valid && id == lid) & todo;
+    if (lane == leader) atomicAdd(&counters[lid], (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
+}
+
+// One thread per depth pixel and stream (pre_normal.fs:22-33 runs per fragment of every layer).
 __global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages F, Bricks B) {
   const int px = blockIdx.x * 64 + (threadIdx.x & 63);
   const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int layer = blockIdx.z;
-  if (px >= F.w || py >= F.h) return;
-  const float u = ((float)px + 0.5f) / (float)F.w, v = ((float)py + 0.5f) / (float)F.h;
-  // NEAREST fetch at the pixel's own centre
-  const int nx = axis_nearest(u, F.w), ny = axis_nearest(v, F.h);
-  const float d = F.dqs[((size_t)layer * F.h + ny) * F.w + nx].x;
-  if (d <= 0.0f || d >= 1.0f) return;                                   // is_outside(), pre_normal.fs:22-24
-  const StreamLut& L = T.s[layer];
-  const float3 pos = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, d);         // world position, :32
-  // mark_brick(pos)
-  const float relx = pos.x - B.bbox_min[0], rely = pos.y - B.bbox_min[1], relz = pos.z - B.bbox_min[2];
-  const float fx = floorf(relx / B.size[0]), fy = floorf(rely / B.size[1]), fz = floorf(relz / B.size[2]);
-  if (!(fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)B.res[0] && fy < (float)B.res[1] && fz < (float)B.res[2])) return;
-  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-  const float cx = (float)ix * B.size[0] + B.bbox_min[0] + 0.5f * B.size[0];
-  const float cy = (float)iy * B.size[1] + B.bbox_min[1] + 0.5f * B.size[1];
-  const float cz = (float)iz * B.size[2] + B.bbox_min[2] + 0.5f * B.size[2];
-  const float dx = pos.x - cx, dy = pos.y - cy, dz = pos.z - cz;
-  const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
-  const float mv = fmaxf(ax, fmaxf(ay, az));
-  const int ox = (int)sgnf(dx * (ax < mv ? 0.0f : 1.0f));
-  const int oy = (int)sgnf(dy * (ay < mv ? 0.0f : 1.0f));
-  const int oz = (int)sgnf(dz * (az < mv ? 0.0f : 1.0f));
-  const int nbx = clampi(ix + ox, 0, B.res[0] - 1), nby = clampi(iy + oy, 0, B.res[1] - 1), nbz = clampi(iz + oz, 0, B.res[2] - 1);
-  if (ax > B.size[0] * 0.1f)                                            // adds 0 otherwise (inc_bricks.glsl:52)
-    atomicAdd(&B.counters[((size_t)nbz * B.res[1] + nby) * B.res[0] + nbx], 1u);
-  atomicAdd(&B.counters[((size_t)iz * B.res[1] + iy) * B.res[0] + ix], 1u);
+  bool own = false, nbr = false;
+  uint32_t id_own = 0, id_nbr = 0;
+  if (px < F.w && py < F.h) {
+    const float u = ((float)px + 0.5f) / (float)F.w, v = ((float)py + 0.5f) / (float)F.h;
+    const int nx = axis_nearest(u, F.w), ny = axis_nearest(v, F.h);     // NEAREST fetch at the pixel's own centre
+    const float d = F.depth[((size_t)layer * F.h + ny) * F.w + nx];
+    if (!(d <= 0.0f || d >= 1.0f)) {                                    // is_outside(), pre_normal.fs:22-24
+      const StreamLut& L = T.s[layer];
+      const float3 pos = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, d);     // world position, :32
+      // mark_brick(pos), inc_bricks.glsl:40-58
+      const float relx = pos.x - B.bbox_min[0], rely = pos.y - B.bbox_min[1], relz = pos.z - B.bbox_min[2];
+      const float fx = floorf(relx / B.size[0]), fy = floorf(rely / B.size[1]), fz = floorf(relz / B.size[2]);
+      if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)B.res[0] && fy < (float)B.res[1] && fz < (float)B.res[2]) {
+        const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        const float cx = (float)ix * B.size[0] + B.bbox_min[0] + 0.5f * B.size[0];
+        const float cy = (float)iy * B.size[1] + B.bbox_min[1] + 0.5f * B.size[1];
+        const float cz = (float)iz * B.size[2] + B.bbox_min[2] + 0.5f * B.size[2];
+        const float dx = pos.x - cx, dy = pos.y - cy, dz = pos.z - cz;
+        const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+        const float mv = fmaxf(ax, fmaxf(ay, az));
+        const int ox = (int)sgnf(dx * (ax < mv ? 0.0f : 1.0f));
+        const int oy = (int)sgnf(dy * (ay < mv ? 0.0f : 1.0f));
+        const int oz = (int)sgnf(dz * (az < mv ? 0.0f : 1.0f));
+        const int nbx = clampi(ix + ox, 0, B.res[0] - 1), nby = clampi(iy + oy, 0, B.res[1] - 1), nbz = clampi(iz + oz, 0, B.res[2] - 1);
+        nbr = ax > B.size[0] * 0.1f;                                    // the neighbour add is 0 otherwise (:52)
+        id_nbr = (uint32_t)(((size_t)nbz * B.res[1] + nby) * B.res[0] + nbx);
+        own = true;
+        id_own = (uint32_t)(((size_t)iz * B.res[1] + iy) * B.res[0] + ix);
+      }
+    }
+  }
+  wave_count(B.counters, id_nbr, nbr);
+  wave_count(B.counters, id_own, own);
 }
 void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B) {
   dim3 grid((F.w + 63) / 64, (F.h + 3) / 4, T.n);
@@ -87,8 +110,8 @@ __global__ __launch_bounds__(256) void k_update_occupied(Bricks B, uint32_t min_
   base = __shfl(base, 0);
   if (occ) B.occupied[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
 }
-void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels) {
-  hipMemsetAsync(B.num_occupied, 0, sizeof(uint32_t), st);
+void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, int zero_count) {
+  if (zero_count) hipMemsetAsync(B.num_occupied, 0, sizeof(uint32_t), st);
   hipLaunchKernelGGL(k_update_occupied, dim3((B.n + 255) / 256), dim3(256), 0, st, B, min_voxels);
 }
 

@@ -30,11 +30,9 @@ __device__ __forceinline__ Texel fetch_squeezed(const Atlas& A, int w, int lod, 
   return t;
 }
 
-// tsdf_inpaint.fs:34-89 -- one thread per pixel of level lod + 1
-__global__ __launch_bounds__(256) void k_inpaint_level(Atlas A, int w, int lod) {
+// tsdf_inpaint.fs:34-89 for pixel (lx0, ly0) of level lod + 1
+__device__ __forceinline__ void inpaint_pixel(const Atlas& A, int w, int lod, int lx0, int ly0) {
   const int rx = A.res[lod + 1][0], ry = A.res[lod + 1][1], ox = A.off[lod + 1][0], oy = A.off[lod + 1][1];
-  const int lx0 = blockIdx.x * 16 + (threadIdx.x & 15), ly0 = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (lx0 >= rx || ly0 >= ry) return;
   const int fx = ox + lx0, fy = oy + ly0;                 // gl_FragCoord (pixel_center_integer)
   const float tcx = ((float)fx - (float)ox) / (float)rx, tcy = ((float)fy - (float)oy) / (float)ry;   // :37
   const int lx = (int)((float)A.off[lod][0] + (float)A.res[lod][0] * tcx);                           // to_lod_pos, :30-32
@@ -69,10 +67,35 @@ __global__ __launch_bounds__(256) void k_inpaint_level(Atlas A, int w, int lod) 
   A.color[o] = make_float4(tr / tw, tg / tw, tb / tw, 1.0f);
   A.depth[o] = td / tw;
 }
+
+// one thread per pixel of level lod + 1 (the large levels)
+__global__ __launch_bounds__(256) void k_inpaint_level(Atlas A, int w, int lod) {
+  const int lx0 = blockIdx.x * 16 + (threadIdx.x & 15), ly0 = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (lx0 >= A.res[lod + 1][0] || ly0 >= A.res[lod + 1][1]) return;
+  inpaint_pixel(A, w, lod, lx0, ly0);
+}
+// The small tail of the pyramid (levels first_lod + 1 .. num_lods - 1, a few thousand pixels in all) in ONE
+// workgroup: each level is a loop over its pixels, a workgroup barrier orders a level's global stores before
+// the next level's loads (same CU, workgroup-scope fence), and the launch boundaries between them disappear.
+__global__ __launch_bounds__(1024) void k_inpaint_tail(Atlas A, int w, int first_lod) {
+  for (int lod = first_lod; lod + 1 < A.num_lods; ++lod) {
+    const int rx = A.res[lod + 1][0], n = rx * A.res[lod + 1][1];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) inpaint_pixel(A, w, lod, i % rx, i / rx);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+constexpr int kTailPixels = 1024;   // levels with at most this many pixels go to the fused tail (one pass of 1024 threads each)
 void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod) {
   const int w = A.res[0][0];
   dim3 grid((A.res[lod + 1][0] + 15) / 16, (A.res[lod + 1][1] + 15) / 16);
   hipLaunchKernelGGL(k_inpaint_level, grid, dim3(256), 0, st, A, w, lod);
+}
+void launch_inpaint_pyramid(hipStream_t st, const Atlas& A) {
+  const int w = A.res[0][0];
+  int lod = 0;
+  for (; lod + 1 < A.num_lods && A.res[lod + 1][0] * A.res[lod + 1][1] > kTailPixels; ++lod) launch_inpaint_level(st, A, lod);
+  if (lod + 1 < A.num_lods) hipLaunchKernelGGL(k_inpaint_tail, dim3(1), dim3(1024), 0, st, A, w, lod);
 }
 
 __device__ __forceinline__ int mirror_idx(int i, int n) {   // GL_MIRRORED_REPEAT, view_lod.cpp:52-53
@@ -103,6 +126,15 @@ __global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4
   const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (px >= w || py >= h) return;
   const float tcx = (float)px / (float)A.res[0][0], tcy = (float)py / (float)A.res[0][1];             // :32
+  const size_t o = (size_t)py * w + px;
+  // depth comes from level 0 alone (:54) and the fragment only lands if it beats the cleared depth (GL_LESS, :313):
+  // background pixels need none of the colour work
+  const float d0 = fetch_atlas(A, (int)((float)A.off[0][0] + (float)A.res[0][0] * tcx), (int)((float)A.off[0][1] + (float)A.res[0][1] * tcy)).d;
+  if (!(d0 < 1.0f)) {
+    fb_c[o] = make_float4(0, 0, 0, 0);
+    fb_d[o] = 1.0f;
+    return;
+  }
   float4 out = make_float4(0, 0, 0, 0);
   int level = 0;
   for (; level < A.num_lods; ++level) {                                                               // :36-40
@@ -130,11 +162,8 @@ __global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4
     out = make_float4((c1.x * w1 + c2.x * w2) / (w1 + w2), (c1.y * w1 + c2.y * w2) / (w1 + w2),
                       (c1.z * w1 + c2.z * w2) / (w1 + w2), (c1.w * w1 + c2.w * w2) / (w1 + w2));
   }
-  const float d0 = fetch_atlas(A, (int)((float)A.off[0][0] + (float)A.res[0][0] * tcx), (int)((float)A.off[0][1] + (float)A.res[0][1] * tcy)).d;   // :54
-  const size_t o = (size_t)py * w + px;
-  const bool pass = d0 < 1.0f;                                                                        // GL_LESS vs cleared depth
-  fb_c[o] = pass ? out : make_float4(0, 0, 0, 0);
-  fb_d[o] = pass ? d0 : 1.0f;
+  fb_c[o] = out;
+  fb_d[o] = d0;
 }
 void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth) {
   dim3 grid((w + 15) / 16, (h + 15) / 16);

@@ -6,8 +6,8 @@
 //   k_classify_tiles   which tiles contain a voxel of an occupied brick's list -> compact "active" list
 //   k_clear_tiles      tiles that are inactive but still hold old surface data are reset to -limit
 //                      (tiles already clear are not touched: no dense 4*V store per frame)
-//   k_integrate_tiles  active tiles only (persistent workgroups pulling from the list); a tile is written
-//                      as two fully coalesced 1 KiB stores per wave
+//   k_integrate_tiles* active tiles only (persistent workgroups pulling from the list); a tile is written
+//                      as two fully coalesced 1 KiB stores per wave; the _lds variant stages the LUT box in LDS
 // Without bricks (setUseBricks(false)) every tile is active and the dense kernel runs on a plain grid.
 #include "sampling.hpp"
 
@@ -66,15 +66,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(Volume V, Bricks B, Tile
   tile_coords(V, tile, t[0], t[1], t[2]);
   int b0[3], b1[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {           // the per-axis tables are monotone: scan the tile's 8 voxels for the brick span
-    const int v0 = t[a] * 8, v1 = min(t[a] * 8 + 7, V.res[a] - 1);
-    int lo = 0x7fffffff, hi = -1;
-    for (int v = v0; v <= v1; ++v) {
-      const int f = B.vox_first[a][v], n = B.vox_count[a][v];
-      if (n) { lo = min(lo, f); hi = max(hi, f + n - 1); }
-    }
-    b0[a] = lo; b1[a] = hi;
-  }
+  for (int a = 0; a < 3; ++a) { b0[a] = B.tile_b0[a][t[a]]; b1[a] = B.tile_b1[a][t[a]]; }   // host-built brick span per tile index
   bool active = false;
   for (int k = b0[2]; k <= b1[2]; ++k)
     for (int j = b0[1]; j <= b1[1]; ++j)
@@ -107,19 +99,24 @@ __global__ __launch_bounds__(256) void k_clear_tiles(Volume V, TileState S) {
   }
 }
 
+// Shared tile loop: which tile does work item w map to
+template <bool kList>
+__device__ __forceinline__ int work_tile(const TileState& S, int w) {
+  if (kList) return (int)S.list[w];
+  // XCD-aware mapping: blocks b, b+8, b+16.. share an XCD (round-robin dispatch); give each XCD one
+  // contiguous run of tiles so neighbouring tiles (shared LUT texels / image pixels) hit the same L2.
+  return ((S.n & 7) == 0) ? (w & 7) * (S.n >> 3) + (w >> 3) : w;
+}
+
+// Generic path: every tap straight from global memory.  Used when a tile's LUT neighbourhood does not fit
+// the LDS budget (inverse LUT much finer than the TSDF).
 template <bool kList>
 __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
   const float sx = 1.0f / (float)V.res[0], sy = 1.0f / (float)V.res[1], sz = 1.0f / (float)V.res[2];   // volume_sampler.cpp:36-38
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
-    int tile;
-    if (kList) tile = (int)S.list[w];
-    else {
-      // XCD-aware mapping: blocks b, b+8, b+16.. share an XCD (round-robin dispatch); give each XCD one
-      // contiguous run of tiles so neighbouring tiles (shared LUT texels / image pixels) hit the same L2.
-      tile = ((S.n & 7) == 0) ? (w & 7) * (S.n >> 3) + (w >> 3) : w;
-    }
+    const int tile = work_tile<kList>(S, w);
     int tx, ty, tz;
     tile_coords(V, tile, tx, ty, tz);
     float* __restrict__ out = V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9);
@@ -137,16 +134,137 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
   }
 }
 
-void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks) {
-  if (use_bricks) {
-    hipMemsetAsync(S.count, 0, sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_classify_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
-    hipLaunchKernelGGL(k_clear_tiles, dim3(1024), dim3(256), 0, st, V, S);
-    hipLaunchKernelGGL(k_integrate_tiles<true>, dim3(S.n < 2048 ? S.n : 2048), dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
-  } else {
-    hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+// LDS path.  The voxel grid is axis aligned with the inverse LUT, so the 512 voxels of a tile only ever touch a
+// small box of LUT texels per stream (4^3 at 512^3 over a 128^3 LUT).  Per tile and chunk of up to 4 streams:
+//   A  24 lanes per stream evaluate the per-axis GL filter set-up (i0, i1, weight) of the tile's 8 voxel coordinates
+//   B  the workgroup copies each stream's texel box HBM/L2 -> LDS with one batch of independent 16-B loads
+//   C  every voxel interpolates x -> y -> z out of LDS (the same fp32 operations as tex3d_rgba_xyz), issues the image
+//      gathers of ALL streams of the chunk together, and only then runs the order-dependent fusion rule on registers
+// so a voxel pays two dependent memory round trips per chunk instead of two per stream.
+constexpr int kBoxCap = 512;      // LUT texels per stream held in LDS (8 KiB); the host checks the bound per calibration
+constexpr int kChunk = 2;
+
+template <bool kList>
+__global__ __launch_bounds__(256, 4) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
+  __shared__ float4 s_box[kChunk][kBoxCap];
+  __shared__ int s_i0[kChunk][3][8], s_i1[kChunk][3][8];
+  __shared__ float s_w[kChunk][3][8];
+  const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
+  const float limit = V.limit;
+  const int n_work = kList ? (int)*S.count : S.n;
+  const int tid = threadIdx.x;
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int tile = work_tile<kList>(S, w);
+    int t3[3];
+    tile_coords(V, tile, t3[0], t3[1], t3[2]);
+    float* __restrict__ out = V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
+    // both voxels of this thread: l and l + 256 share x and y, z differs by 4
+    const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
+    const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
+    bool drawn[2];
+    float tsd[2], wsum[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int z = t3[2] * 8 + lz + 4 * h;
+      drawn[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      if (drawn[h] && per_voxel_check) drawn[h] = voxel_drawn(B, x, y, z);
+      tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
+      wsum[h] = 0.0f;
+    }
+    for (int cb = 0; cb < T.n; cb += kChunk) {
+      const int nc = min(kChunk, T.n - cb);
+      __syncthreads();                                                  // previous readers of s_* are done
+      if (tid < nc * 24) {                                              // phase A
+        const int c = tid / 24, a = (tid % 24) >> 3, k = tid & 7;
+        const int coord = min(t3[a] * 8 + k, V.res[a] - 1);             // padding voxels reuse the last real coordinate
+        const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], T.s[cb + c].inv_res[a]);
+        s_i0[c][a][k] = ax.i0; s_i1[c][a][k] = ax.i1; s_w[c][a][k] = ax.a;
+      }
+      __syncthreads();
+      for (int c = 0; c < nc; ++c) {                                    // phase B
+        const StreamLut& L = T.s[cb + c];
+        const int mx = s_i0[c][0][0], my = s_i0[c][1][0], mz = s_i0[c][2][0];
+        const int dx = s_i1[c][0][7] - mx + 1, dy = s_i1[c][1][7] - my + 1, dz = s_i1[c][2][7] - mz + 1;
+        const int n = min(dx * dy * dz, kBoxCap);
+        for (int e = tid; e < n; e += 256) {
+          const int bx = e % dx, by = (e / dx) % dy, bz = e / (dx * dy);
+          s_box[c][e] = L.inv[((size_t)(mz + bz) * L.inv_res[1] + (my + by)) * L.inv_res[0] + (mx + bx)];
+        }
+      }
+      __syncthreads();
+      if (__ballot(drawn[0] | drawn[1]) != 0ull) {                      // phase C
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {                                   // one voxel at a time: half the live registers
+          const int kz = lz + 4 * h;
+          float3 pc[kChunk];
+          Dqs q[kChunk];
+#pragma unroll
+          for (int c = 0; c < kChunk; ++c) {
+            if (c < nc) {
+              const int mx = s_i0[c][0][0], my = s_i0[c][1][0], mz = s_i0[c][2][0];
+              const int dx = s_i1[c][0][7] - mx + 1, dy = s_i1[c][1][7] - my + 1;
+              const int x0 = s_i0[c][0][lx] - mx, x1 = s_i1[c][0][lx] - mx;
+              const int y0 = (s_i0[c][1][ly] - my) * dx, y1 = (s_i1[c][1][ly] - my) * dx;
+              const int z0 = (s_i0[c][2][kz] - mz) * dx * dy, z1 = (s_i1[c][2][kz] - mz) * dx * dy;
+              const float ax = s_w[c][0][lx], ay = s_w[c][1][ly], az = s_w[c][2][kz];
+              const float4* bx = s_box[c];
+              const float3 c00 = lerp3(bx[z0 + y0 + x0], bx[z0 + y0 + x1], ax);
+              const float3 c10 = lerp3(bx[z0 + y1 + x0], bx[z0 + y1 + x1], ax);
+              const float3 c01 = lerp3(bx[z1 + y0 + x0], bx[z1 + y0 + x1], ax);
+              const float3 c11 = lerp3(bx[z1 + y1 + x0], bx[z1 + y1 + x1], ax);
+              pc[c] = lerp3(lerp3(c00, c10, ay), lerp3(c01, c11, ay), az);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < kChunk; ++c)
+            if (c < nc && drawn[h]) q[c] = dqs_fetch(F, cb + c, pc[c].x, pc[c].y);
+          if (drawn[h]) {
+            float weighted_tsd = tsd[h], total_weight = wsum[h];
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c) {                          // tsdf_integration.vs:30-55, in stream order
+              if (c < nc) {
+                bool skip = false;
+                if (dqs_silhouette(q[c]) < 1.0f) {
+                  if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
+                }
+                if (!skip) {
+                  const float sdist = pc[c].z - dqs_depth(q[c]);
+                  if (sdist <= -limit) {
+                    weighted_tsd = -limit;
+                  } else if (sdist >= limit) {
+                  } else {
+                    const float weight = dqs_quality(q[c]);
+                    weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
+                    total_weight += weight;
+                  }
+                }
+              }
+            }
+            tsd[h] = weighted_tsd; wsum[h] = total_weight;
+          }
+        }
+      }
+    }
+    out[tid] = drawn[0] ? tsd[0] : -limit;                              // clearImage(-limit), :249-250
+    out[tid + 256] = drawn[1] ? tsd[1] : -limit;
+    if (tid == 0) S.dirty[tile] = 1;
   }
 }
+
+void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count) {
+  if (use_bricks) {
+    if (zero_count) hipMemsetAsync(S.count, 0, sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_classify_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
+    hipLaunchKernelGGL(k_clear_tiles, dim3(1024), dim3(256), 0, st, V, S);
+    const dim3 grid(S.n < 4096 ? S.n : 4096);
+    if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+  } else {
+    if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+    else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+  }
+}
+int integrate_box_cap() { return kBoxCap; }
 
 __global__ __launch_bounds__(256) void k_fill_u8(uint8_t* __restrict__ p, uint8_t v, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;

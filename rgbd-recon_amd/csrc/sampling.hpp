@@ -63,7 +63,7 @@ __device__ __forceinline__ float2 tex3d_rg(const float2* __restrict__ t, const i
 }
 
 // The 2x2 footprint of the packed {depth, quality, silhouette} image at (u, v) of layer i.
-struct Dqs { float4 t00, t10, t01, t11; float ax, ay; int nx, ny, x0, x1, y0, y1; };
+struct Dqs { float4 t00, t10, t01, t11; float ax, ay; };
 __device__ __forceinline__ Dqs dqs_fetch(const FrameImages& F, int layer, float u, float v) {
   const Axis X = axis_linear(u, F.w), Y = axis_linear(v, F.h);
   const float4* __restrict__ b = F.dqs + (size_t)layer * F.w * F.h;
@@ -71,8 +71,6 @@ __device__ __forceinline__ Dqs dqs_fetch(const FrameImages& F, int layer, float 
   r.t00 = b[(size_t)Y.i0 * F.w + X.i0]; r.t10 = b[(size_t)Y.i0 * F.w + X.i1];
   r.t01 = b[(size_t)Y.i1 * F.w + X.i0]; r.t11 = b[(size_t)Y.i1 * F.w + X.i1];
   r.ax = X.a; r.ay = Y.a;
-  r.x0 = X.i0; r.x1 = X.i1; r.y0 = Y.i0; r.y1 = Y.i1;
-  r.nx = axis_nearest(u, F.w); r.ny = axis_nearest(v, F.h);
   return r;
 }
 __device__ __forceinline__ float dqs_silhouette(const Dqs& d) {   // LINEAR R32F
@@ -81,10 +79,11 @@ __device__ __forceinline__ float dqs_silhouette(const Dqs& d) {   // LINEAR R32F
 __device__ __forceinline__ float dqs_quality(const Dqs& d) {      // LINEAR R32F
   return lerpf(lerpf(d.t00.y, d.t10.y, d.ax), lerpf(d.t01.y, d.t11.y, d.ax), d.ay);
 }
-// NEAREST RG32F .r: the nearest texel floor(u*n) is always one of the bilinear pair {i0, i1}
-// (i0 = floor(u*n - .5)), also after clamping, so it is picked from the footprint already in registers.
+// NEAREST RG32F .r out of the bilinear footprint.  With p = u*n the nearest texel is floor(p) and the bilinear
+// pair is {floor(p - .5), +1}; f = p - .5 and its fraction a = f - floor(f) are exact in fp32 for p >= .25, so
+// floor(p) = floor(f) + (a >= .5).  For p < .25 both pair members clamp to texel 0 and so does floor(p).
 __device__ __forceinline__ float dqs_depth(const Dqs& d) {
-  const bool xr = (d.nx != d.x0), yr = (d.ny != d.y0);
+  const bool xr = d.ax >= 0.5f, yr = d.ay >= 0.5f;
   const float lo = xr ? d.t10.x : d.t00.x, hi = xr ? d.t11.x : d.t01.x;
   return yr ? hi : lo;
 }

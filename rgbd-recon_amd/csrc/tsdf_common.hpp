@@ -26,6 +26,7 @@ struct StreamTable {
 // (the three arrays are always fetched at the same coordinate, tsdf_integration.vs:32-50) and RGBA8 colour.
 struct FrameImages {
   const float4* dqs;      // [N][H][W]
+  const float* depth;     // [N][H][W] depth.r alone (brick marking reads nothing else)
   const uchar4* color;    // [N][Hc][Wc]
   int w, h, cw, ch;
 };
@@ -65,6 +66,8 @@ struct Bricks {
   uint32_t* occupied;       // compacted ids of the occupied bricks (Occupied SSBO, inc_bricks.glsl:18-20), unordered
   const uint16_t* vox_first[3];
   const uint8_t* vox_count[3];
+  const uint16_t* tile_b0[3];   // per storage tile index along an axis: first / last brick whose voxel list reaches into it
+  const uint16_t* tile_b1[3];   // (b0 > b1: none)
   int res[3];               // brick grid
   int n;
   float size[3];            // world brick size
@@ -91,12 +94,13 @@ struct Atlas {
 };
 
 // launchers (one per kernel family, defined in the .hip files)
-void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, size_t n);
+void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, size_t n);
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);
 void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
 void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B);
-void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels);
-void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks);
+void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, int zero_count);
+void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count);
+int integrate_box_cap();
 void launch_mark_all_dirty(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
 void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* linear);
@@ -104,6 +108,7 @@ void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, f
 struct RayTarget { float4* color; float* depth; int stride; float* nsamples; const float4* peels; float clear[4]; };
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial);
 void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod);
+void launch_inpaint_pyramid(hipStream_t st, const Atlas& A);
 void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth);
 void launch_clear_image(hipStream_t st, float4* color, float* depth, size_t n, float4 c, float d);
 void launch_export_partial(hipStream_t st, const RayTarget& R, int w, int h, void* dst);
