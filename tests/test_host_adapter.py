@@ -1,0 +1,52 @@
+"""The C++ adapter (rgbd-recon_amd/host/recon_integration_hip.hpp) exposes the reference operator's method names and
+the headless harness built on it compiles, links against the C ABI and runs one frame in the reference's call order."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "rgbd-recon_amd", "host")
+
+# public methods of kinect::ReconIntegration + kinect::Reconstruction
+# (framework/reconstruction/recon_integration.hpp:40-64, reconstruction.hpp:16-23)
+REFERENCE_SURFACE = ["draw", "drawF", "integrate", "setColorFilling", "setUseBricks", "setSpaceSkip", "setDrawBricks",
+                     "setVoxelSize", "setTsdfLimit", "setBrickSize", "numBricks", "occupiedRatio", "getBrickSize",
+                     "clearOccupiedBricks", "updateOccupiedBricks", "setMinVoxelsPerBrick", "resize", "drawOccupiedBricks",
+                     "setViewportOffset", "reload", "setColorMaskMode"]
+
+
+def build_harness():
+    exe = os.path.join(HOST, "frame_harness")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", os.path.join(HOST, "frame_harness.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "rgbd-recon_amd"), "-lrgbd_recon_hip", "-Wl,-rpath," + os.path.join(ROOT, "rgbd-recon_amd")])
+    return exe
+
+
+def test_adapter_has_the_reference_method_names():
+    text = open(os.path.join(HOST, "recon_integration_hip.hpp")).read()
+    for name in REFERENCE_SURFACE:
+        assert re.search(r"\b%s\s*\(" % name, text), name
+
+
+def test_python_mirror_has_the_reference_method_names(rr):
+    for name in ["draw", "drawF", "integrate", "setColorFilling", "setUseBricks", "setSpaceSkip", "setTsdfLimit", "setBrickSize",
+                 "numBricks", "occupiedRatio", "getBrickSize", "clearOccupiedBricks", "updateOccupiedBricks", "setMinVoxelsPerBrick", "resize"]:
+        assert callable(getattr(rr.ReconIntegrationHip, name)), name
+
+
+def test_harness_builds_and_fails_loudly_without_a_device():
+    import torch
+    exe = build_harness()
+    if torch.cuda.is_available():
+        pytest.skip("a device is visible; see the gpu variant")
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 3 and "no HIP device" in p.stderr
+
+
+@pytest.mark.gpu
+def test_harness_runs_a_frame_on_the_gpu():
+    p = subprocess.run([build_harness()], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "of 4096 voxels at sdist 0.02" in p.stdout
