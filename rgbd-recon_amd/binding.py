@@ -16,7 +16,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "librgbd_recon_hip.so")
+LIB_PATH = os.environ.get("RGBDR_LIB", os.path.join(_PKG, "librgbd_recon_hip.so"))   # override: A/B builds of the kernels
 HEADER_PATH = os.path.join(_ROOT, "include", "rgbd_recon_hip.h")
 
 TSDF_MAX_STREAMS = 16

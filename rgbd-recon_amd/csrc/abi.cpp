@@ -35,6 +35,8 @@ struct tsdf_ctx {
   float vox[3]{};
   Volume vol{};
   TileState tiles{};
+  uint8_t* d_cls_all = nullptr;      // tile class of every stored tile (owned + halo)
+  uint32_t* d_pyr = nullptr;
   int halo_layers = 0;
   // bricks
   float brick_req[3]{};          // requested size (setBrickSize argument)
@@ -60,6 +62,7 @@ struct tsdf_ctx {
   int vw = 0, vh = 0;
   Atlas atlas{};
   float4* d_peels = nullptr; float* d_nsamples = nullptr;
+  void* d_hits = nullptr; uint32_t* d_hit_counters = nullptr; int hit_parity = 0;   // raymarch hit list (k_march -> k_shade)
   float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
   float* d_linear = nullptr;     // scratch for volume up/download
   // flags (recon_integration.cpp:54-57)
@@ -110,6 +113,7 @@ Mat4 to_mat4(const double* d) { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (f
 
 void release_view(tsdf_ctx* c) {
   hipFree(c->atlas.color); hipFree(c->atlas.depth); hipFree(c->d_peels); hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
+  hipFree(c->d_hits); hipFree(c->d_hit_counters); c->d_hits = nullptr; c->d_hit_counters = nullptr;
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
 void release_bricks(tsdf_ctx* c) {
@@ -145,6 +149,10 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   HIP_TRY(c, hipMalloc(&c->d_nsamples, nv * sizeof(float)));
   HIP_TRY(c, hipMalloc(&c->d_fb_c, nv * sizeof(float4)));
   HIP_TRY(c, hipMalloc(&c->d_fb_d, nv * sizeof(float)));
+  HIP_TRY(c, hipMalloc(&c->d_hits, nv * 16));
+  HIP_TRY(c, hipMalloc(&c->d_hit_counters, 2 * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemsetAsync(c->d_hit_counters, 0, 2 * sizeof(uint32_t), c->stream));
+  c->hit_parity = 0;
   // the atlas starts as ViewLod::enable() leaves it (colour (0,1,0,0), depth 1); regions no kernel writes keep that
   launch_clear_image(c->stream, A.color, A.depth, na, make_float4(0.0f, 1.0f, 0.0f, 0.0f), 1.0f);
   launch_clear_image(c->stream, c->d_fb_c, c->d_fb_d, nv, make_float4(0, 0, 0, 0), 1.0f);
@@ -372,10 +380,26 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   TileState& S = c->tiles;
   S.n = (V.own_tz1 - V.own_tz0) * V.nty * V.ntx;
   if ((rc = tryhip(hipMalloc(&S.active, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
-  if ((rc = tryhip(hipMalloc(&S.dirty, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
+  V.n_stored_tiles = (V.tz1 - V.tz0) * V.nty * V.ntx;
+  if ((rc = tryhip(hipMalloc(&c->d_cls_all, (size_t)V.n_stored_tiles), "hipMalloc(tiles)"))) return fail(rc);
+  hipMemsetAsync(c->d_cls_all, kTileMixed, (size_t)V.n_stored_tiles, c->stream);   // halo layers keep this value for good
+  V.cls = c->d_cls_all;
+  {                                               // empty-space pyramid: levels 1..4 = cells of 2, 4, 8, 16 tiles
+    int words = 0;
+    for (int l = 1; l <= 4; ++l) {
+      V.pyr_off[l] = words;
+      int cells = 1;
+      for (int a = 0; a < 3; ++a) { V.pyr_n[l][a] = (((c->res[a] + 7) / 8) + (1 << l) - 1) >> l; cells *= V.pyr_n[l][a]; }
+      words += (cells + 31) / 32;
+    }
+    V.pyr_off[0] = words;
+    if (words * 4 > 60 * 1024) { c->err = "volume too large for the raymarch's LDS empty-space pyramid"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+    if ((rc = tryhip(hipMalloc(&c->d_pyr, (size_t)words * sizeof(uint32_t)), "hipMalloc(pyramid)"))) return fail(rc);
+    V.pyr = c->d_pyr;
+  }
+  S.cls = c->d_cls_all + (size_t)(V.own_tz0 - V.tz0) * V.nty * V.ntx;
   if ((rc = tryhip(hipMalloc(&S.list, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
   hipMemsetAsync(S.active, 0, (size_t)S.n, c->stream);
-  launch_mark_all_dirty(c->stream, S);          // the fresh allocation does not hold -limit yet
   if ((rc = tryhip(hipHostMalloc((void**)&c->h_num_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc"))) return fail(rc);
   *c->h_num_occupied = 0;
   if ((rc = setup_bricks(c, cfg->brick_size))) return fail(rc);
@@ -404,7 +428,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   release_view(c); release_bricks(c);
-  hipFree(c->tiles.active); hipFree(c->tiles.dirty); hipFree(c->tiles.list);
+  hipFree(c->tiles.active); hipFree(c->d_cls_all); hipFree(c->d_pyr); hipFree(c->tiles.list);
   hipFree(c->vol.data); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
   hipFree(c->d_depth_plane); hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
   for (void* p : c->lut_allocs) hipFree(p);
@@ -569,7 +593,8 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   }
   const bool partial = !(c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
   timer_begin(c, "draw");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, ray_target(c), partial ? 1 : 0);
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, ray_target(c), partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity);
+  c->hit_parity ^= 1;
   timer_end(c, "draw");
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -607,7 +632,7 @@ int32_t tsdf_set_tsdf_limit(tsdf_ctx* c, float limit) {
   const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
   if (!whole && (int)ceilf((limit * 0.5f * (float)c->res[2] + 2.0f) / 8.0f) > c->halo_layers) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit needs a wider slab halo than this context allocated");
   c->vol.limit = limit;
-  launch_mark_all_dirty(c->stream, c->tiles);    // the clear value changed
+  launch_mark_all_mixed(c->stream, c->tiles);    // the clear value changed: no tile is known to hold it
   return TSDF_OK;
 }
 int32_t tsdf_set_use_bricks(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->use_bricks = a != 0; return TSDF_OK; }
@@ -670,7 +695,7 @@ int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_linear, in, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float), hipMemcpyHostToDevice, c->stream));
   launch_volume_from_linear(c->stream, c->vol, c->d_linear);
-  launch_mark_all_dirty(c->stream, c->tiles);
+  launch_mark_all_mixed(c->stream, c->tiles);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSDF_OK;
 }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(Volume V, Bricks B, Tile
   if (active) S.list[atomicAdd(S.count, 1u)] = (uint32_t)tile;      // hipcc folds this into one add per wave
 }
 
-// Reset inactive tiles that still hold surface data.  Each wave looks at 64 tiles per step (one coalesced
+// Reset inactive tiles that hold anything but the clear value.  Each wave looks at 64 tiles per step (one coalesced
 // 64-byte read of each flag array) and streams -limit over the dirty ones: 2 x 16 B per lane per tile.
 __global__ __launch_bounds__(256) void k_clear_tiles(Volume V, TileState S) {
   const int lane = threadIdx.x & 63;
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256) void k_clear_tiles(Volume V, TileState S) {
   const float4 cv = make_float4(-V.limit, -V.limit, -V.limit, -V.limit);
   for (int base = wave * 64; base < S.n; base += nwaves * 64) {
     const int tile = base + lane;
-    const bool need = tile < S.n && !S.active[tile] && S.dirty[tile];
+    const bool need = tile < S.n && !S.active[tile] && S.cls[tile] != kTileMinus;
     unsigned long long m = __ballot(need);
-    if (need) S.dirty[tile] = 0;
+    if (need) S.cls[tile] = kTileMinus;
     while (m) {
       const int b = __ffsll((long long)m) - 1;
       m &= m - 1;
@@ -108,6 +108,17 @@ __device__ __forceinline__ int work_tile(const TileState& S, int w) {
   return ((S.n & 7) == 0) ? (w & 7) * (S.n >> 3) + (w >> 3) : w;
 }
 
+// Class of the tile a workgroup has just produced: thread-local "all my real voxels are -limit / +limit" bits are
+// AND-ed per wave and across the four waves through one LDS word (padding voxels past the volume never get sampled
+// and do not count).  Call with s_flag preset to 3 and a barrier between the preset and the first call.
+__device__ __forceinline__ void tile_class_vote(int* s_flag, bool in0, float v0, bool in1, float v1, float limit) {
+  const bool neg = (!in0 || v0 == -limit) && (!in1 || v1 == -limit);
+  const bool pos = (!in0 || v0 == limit) && (!in1 || v1 == limit);
+  const int m = (__all(neg) ? 1 : 0) | (__all(pos) ? 2 : 0);
+  if ((threadIdx.x & 63) == 0) atomicAnd(s_flag, m);
+}
+__device__ __forceinline__ uint8_t tile_class_from(int f) { return (f & 1) ? kTileMinus : ((f & 2) ? kTilePlus : kTileMixed); }
+
 // Generic path: every tap straight from global memory.  Used when a tile's LUT neighbourhood does not fit
 // the LDS budget (inverse LUT much finer than the TSDF).
 template <bool kList>
@@ -115,22 +126,35 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
   const float sx = 1.0f / (float)V.res[0], sy = 1.0f / (float)V.res[1], sz = 1.0f / (float)V.res[2];   // volume_sampler.cpp:36-38
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
+  __shared__ int s_flag;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int tile = work_tile<kList>(S, w);
     int tx, ty, tz;
     tile_coords(V, tile, tx, ty, tz);
     float* __restrict__ out = V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9);
+    __syncthreads();
+    if (threadIdx.x == 0) s_flag = 3;
+    __syncthreads();
+    float v[2];
+    bool in[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int l = threadIdx.x + half * 256;
       const int x = tx * 8 + (l & 7), y = ty * 8 + ((l >> 3) & 7), z = tz * 8 + (l >> 6);
-      bool drawn = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      in[half] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      bool drawn = in[half];
       if (drawn && per_voxel_check) drawn = voxel_drawn(B, x, y, z);
-      float v = -limit;                                                 // clearImage(-limit), :249-250
-      if (drawn) v = integrate_voxel(T, F, limit, ((float)x + 0.5f) * sx, ((float)y + 0.5f) * sy, ((float)z + 0.5f) * sz);
-      out[l] = v;
+      v[half] = -limit;                                                 // clearImage(-limit), :249-250
+      if (drawn) v[half] = integrate_voxel(T, F, limit, ((float)x + 0.5f) * sx, ((float)y + 0.5f) * sy, ((float)z + 0.5f) * sz);
+      out[l] = v[half];
     }
-    if (threadIdx.x == 0) S.dirty[tile] = 1;
+    if (kUseSkip) {
+      tile_class_vote(&s_flag, in[0], v[0], in[1], v[1], limit);
+      __syncthreads();
+      if (threadIdx.x == 0) S.cls[tile] = tile_class_from(s_flag);
+    } else if (threadIdx.x == 0) {
+      S.cls[tile] = kTileMixed;
+    }
   }
 }
 
@@ -149,6 +173,7 @@ __global__ __launch_bounds__(256, 4) void k_integrate_tiles_lds(StreamTable T, F
   __shared__ float4 s_box[kChunk][kBoxCap];
   __shared__ int s_i0[kChunk][3][8], s_i1[kChunk][3][8];
   __shared__ float s_w[kChunk][3][8];
+  __shared__ int s_flag;
   const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
@@ -161,12 +186,13 @@ __global__ __launch_bounds__(256, 4) void k_integrate_tiles_lds(StreamTable T, F
     // both voxels of this thread: l and l + 256 share x and y, z differs by 4
     const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
-    bool drawn[2];
+    bool drawn[2], inres[2];
     float tsd[2], wsum[2];
+    if (tid == 0) s_flag = 3;                                           // ordered before the vote by the chunk barriers
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int z = t3[2] * 8 + lz + 4 * h;
-      drawn[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      drawn[h] = inres[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
       if (drawn[h] && per_voxel_check) drawn[h] = voxel_drawn(B, x, y, z);
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
       wsum[h] = 0.0f;
@@ -245,9 +271,16 @@ __global__ __launch_bounds__(256, 4) void k_integrate_tiles_lds(StreamTable T, F
         }
       }
     }
-    out[tid] = drawn[0] ? tsd[0] : -limit;                              // clearImage(-limit), :249-250
-    out[tid + 256] = drawn[1] ? tsd[1] : -limit;
-    if (tid == 0) S.dirty[tile] = 1;
+    const float v0 = drawn[0] ? tsd[0] : -limit, v1 = drawn[1] ? tsd[1] : -limit;   // clearImage(-limit), :249-250
+    out[tid] = v0;
+    out[tid + 256] = v1;
+    if (kUseSkip) {
+      tile_class_vote(&s_flag, inres[0], v0, inres[1], v1, limit);
+      __syncthreads();
+      if (tid == 0) S.cls[tile] = tile_class_from(s_flag);
+    } else if (tid == 0) {
+      S.cls[tile] = kTileMixed;
+    }
   }
 }
 
@@ -269,8 +302,8 @@ int integrate_box_cap() { return kBoxCap; }
 __global__ __launch_bounds__(256) void k_fill_u8(uint8_t* __restrict__ p, uint8_t v, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
-void launch_mark_all_dirty(hipStream_t st, const TileState& S) {
-  hipLaunchKernelGGL(k_fill_u8, dim3((S.n + 255) / 256 > 1024 ? 1024 : (S.n + 255) / 256), dim3(256), 0, st, S.dirty, (uint8_t)1, S.n);
+void launch_mark_all_mixed(hipStream_t st, const TileState& S) {
+  hipLaunchKernelGGL(k_fill_u8, dim3((S.n + 255) / 256 > 1024 ? 1024 : (S.n + 255) / 256), dim3(256), 0, st, S.cls, kTileMixed, S.n);
 }
 
 // ---- linear <-> tile-major conversion for the download/upload entry points

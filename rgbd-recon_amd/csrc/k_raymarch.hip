@@ -142,24 +142,37 @@ __device__ __forceinline__ float3 color_bilinear(const FrameImages& F, int layer
   return o;
 }
 
-// blendColors(), tsdf_raymarch.fs:295-330
+// blendColors(), tsdf_raymarch.fs:295-330.  Streams are taken four at a time: the inverse-LUT taps of the whole chunk are
+// issued together, then the colour-LUT taps, then the image footprints; the accumulation itself stays in stream order.
 __device__ float4 blend_colors(const StreamTable& T, const FrameImages& F, float limit, float3 sp) {
   float3 tc = make_float3(0, 0, 0), tc2 = make_float3(0, 0, 0);
   float tw = 0.0f, tw2 = 0.0f;
-  for (int i = 0; i < T.n; ++i) {
-    const StreamLut& L = T.s[i];
-    const float3 pc = tex3d_rgba_xyz(L.inv, L.inv_res, sp.x, sp.y, sp.z);
-    const float2 pcol = tex3d_rg(L.uv, L.uv_res, pc.x, pc.y, pc.z);
-    const float3 col = color_bilinear(F, i, pcol.x, pcol.y);
-    const Dqs q = dqs_fetch(F, i, pc.x, pc.y);
-    const float dist = fabsf(dqs_depth(q) - pc.z);
-    float quality = 0.0f;
-    if (dist < limit) quality = dqs_quality(q);
-    const float de = dist + 0.01f;
-    tc.x = tc.x + col.x * quality / de; tc.y = tc.y + col.y * quality / de; tc.z = tc.z + col.z * quality / de;
-    tw += quality / de;
-    tc2.x = tc2.x + col.x / dist; tc2.y = tc2.y + col.y / dist; tc2.z = tc2.z + col.z / dist;
-    tw2 += 1.0f / dist;
+  for (int cb = 0; cb < T.n; cb += 4) {
+    const int nc = min(4, T.n - cb);
+    float3 pc[4], col[4];
+    float2 pcol[4];
+    Dqs q[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < nc) pc[c] = tex3d_rgba_xyz(T.s[cb + c].inv, T.s[cb + c].inv_res, sp.x, sp.y, sp.z);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < nc) pcol[c] = tex3d_rg(T.s[cb + c].uv, T.s[cb + c].uv_res, pc[c].x, pc[c].y, pc[c].z);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < nc) { col[c] = color_bilinear(F, cb + c, pcol[c].x, pcol[c].y); q[c] = dqs_fetch(F, cb + c, pc[c].x, pc[c].y); }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < nc) {
+        const float dist = fabsf(dqs_depth(q[c]) - pc[c].z);
+        float quality = 0.0f;
+        if (dist < limit) quality = dqs_quality(q[c]);
+        const float de = dist + 0.01f;
+        tc.x = tc.x + col[c].x * quality / de; tc.y = tc.y + col[c].y * quality / de; tc.z = tc.z + col[c].z * quality / de;
+        tw += quality / de;
+        tc2.x = tc2.x + col[c].x / dist; tc2.y = tc2.y + col[c].y / dist; tc2.z = tc2.z + col[c].z / dist;
+        tw2 += 1.0f / dist;
+      }
   }
   if (tw > 0.0f) return make_float4(tc.x / tw, tc.y / tw, tc.z / tw, 1.0f);
   return make_float4(tc2.x / tw2, tc2.y / tw2, tc2.z / tw2, -1.0f);
@@ -216,73 +229,257 @@ __device__ __forceinline__ bool sample_owned(const Volume& V, float pz) {
   return tz >= V.own_tz0 && tz < V.own_tz1;
 }
 
-__global__ __launch_bounds__(256) void k_raymarch(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, int partial) {
+// K2 runs as two launches.  k_march (one thread per pixel, 8x8 pixel tile per wave) finds the first zero crossing and
+// appends it to a compact hit list; k_shade (one thread per hit, dense waves) does submitFragment().  Rays that hit
+// nothing cost no shading registers or divergence, and the hit list length never goes through the host.
+struct Hit { float x, y, z; uint32_t pix; };   // refined sample position (volume space) + pixel index
+
+// Empty-space pyramid.  One workgroup per level-4 cell (16^3 tiles = 128^3 voxels) reduces the tile classes of its cell
+// to the bits of levels 1..4.  A tile past the volume counts as empty (nothing samples it), a tile this slab context does
+// not store counts as occupied.
+__global__ __launch_bounds__(256) void k_build_pyramid(Volume V) {
+  __shared__ uint8_t s1[512], s2[64], s3[8];
+  const int c4[3] = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  const int ntz = (V.res[2] + 7) >> 3;
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) {                  // level-1 cells of this level-4 cell: 8^3
+    const int l1[3] = {c4[0] * 8 + (i & 7), c4[1] * 8 + ((i >> 3) & 7), c4[2] * 8 + (i >> 6)};
+    bool empty = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int tx = l1[0] * 2 + (k & 1), ty = l1[1] * 2 + ((k >> 1) & 1), tz = l1[2] * 2 + (k >> 2);
+      if (tx >= V.ntx || ty >= V.nty || tz >= ntz) continue;
+      if (tz < V.tz0 || tz >= V.tz1) { empty = false; continue; }
+      empty = empty && V.cls[((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx] == kTileMinus;
+    }
+    s1[i] = empty ? 1 : 0;
+    if (l1[0] < V.pyr_n[1][0] && l1[1] < V.pyr_n[1][1] && l1[2] < V.pyr_n[1][2]) {
+      const int bit = (l1[2] * V.pyr_n[1][1] + l1[1]) * V.pyr_n[1][0] + l1[0];
+      if (empty) atomicOr(&V.pyr[V.pyr_off[1] + (bit >> 5)], 1u << (bit & 31));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                                               // level 2: 4^3 per level-4 cell
+    const int i = threadIdx.x, x = i & 3, y = (i >> 2) & 3, z = i >> 4;
+    bool e = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e = e && s1[((z * 2 + (k >> 2)) * 8 + (y * 2 + ((k >> 1) & 1))) * 8 + (x * 2 + (k & 1))];
+    s2[i] = e ? 1 : 0;
+    const int l2[3] = {c4[0] * 4 + x, c4[1] * 4 + y, c4[2] * 4 + z};
+    if (e && l2[0] < V.pyr_n[2][0] && l2[1] < V.pyr_n[2][1] && l2[2] < V.pyr_n[2][2]) {
+      const int bit = (l2[2] * V.pyr_n[2][1] + l2[1]) * V.pyr_n[2][0] + l2[0];
+      atomicOr(&V.pyr[V.pyr_off[2] + (bit >> 5)], 1u << (bit & 31));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {                                                // level 3: 2^3
+    const int i = threadIdx.x, x = i & 1, y = (i >> 1) & 1, z = i >> 2;
+    bool e = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e = e && s2[((z * 2 + (k >> 2)) * 4 + (y * 2 + ((k >> 1) & 1))) * 4 + (x * 2 + (k & 1))];
+    s3[i] = e ? 1 : 0;
+    const int l3[3] = {c4[0] * 2 + x, c4[1] * 2 + y, c4[2] * 2 + z};
+    if (e && l3[0] < V.pyr_n[3][0] && l3[1] < V.pyr_n[3][1] && l3[2] < V.pyr_n[3][2]) {
+      const int bit = (l3[2] * V.pyr_n[3][1] + l3[1]) * V.pyr_n[3][0] + l3[0];
+      atomicOr(&V.pyr[V.pyr_off[3] + (bit >> 5)], 1u << (bit & 31));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                                               // level 4
+    bool e = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e = e && s3[k];
+    if (e) {
+      const int bit = (c4[2] * V.pyr_n[4][1] + c4[1]) * V.pyr_n[4][0] + c4[0];
+      atomicOr(&V.pyr[V.pyr_off[4] + (bit >> 5)], 1u << (bit & 31));
+    }
+  }
+}
+
+// If the footprint of the sample at `pos` (q = pos * res - 0.5 in voxel units, taps floor(q) and floor(q) + 1) lies inside an
+// all-(-limit) cell of the pyramid, returns how many further steps keep it inside that cell (distance to the cell wall
+// along the ray, less a two-step safety margin); 0 otherwise.  The coarsest level that applies wins.
+__device__ __forceinline__ uint32_t empty_run(const Volume& V, const uint32_t* pyr, float3 pos, const float* dq) {
+  const float q[3] = {pos.x * (float)V.res[0] - 0.5f, pos.y * (float)V.res[1] - 0.5f, pos.z * (float)V.res[2] - 0.5f};
+  int iq[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) iq[a] = (int)fminf(fmaxf(floorf(q[a]), 0.0f), (float)(V.res[a] - 1));
+  for (int l = 4; l >= 1; --l) {
+    const int sh = 3 + l;
+    const int cx = iq[0] >> sh, cy = iq[1] >> sh, cz = iq[2] >> sh;
+    const int bit = (cz * V.pyr_n[l][1] + cy) * V.pyr_n[l][0] + cx;
+    if (!((pyr[V.pyr_off[l] + (bit >> 5)] >> (bit & 31)) & 1u)) continue;
+    const int cc[3] = {cx, cy, cz};
+    float m = 3.0e38f;
+    bool in_cell = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      // the footprint stays in the cell while lo <= q < hi; the outermost cells extend to infinity because out-of-range
+      // taps clamp onto their border voxels
+      const float lo = cc[a] == 0 ? -3.0e38f : (float)(cc[a] << sh);
+      const float hi = cc[a] == V.pyr_n[l][a] - 1 ? 3.0e38f : (float)(((cc[a] + 1) << sh) - 1);
+      in_cell = in_cell && (q[a] >= lo) && (q[a] < hi);
+      if (dq[a] > 0.0f) m = fminf(m, (hi - q[a]) / dq[a]);
+      else if (dq[a] < 0.0f) m = fminf(m, (lo - q[a]) / dq[a]);
+    }
+    if (!in_cell) continue;
+    const float mf = floorf(fminf(m, 1.0e6f)) - 2.0f;
+    return mf >= 1.0f ? (uint32_t)mf : 0u;
+  }
+  return 0u;
+}
+
+template <bool kPartial>
+__global__ __launch_bounds__(256) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
+  constexpr bool partial = kPartial;
+  extern __shared__ uint32_t s_pyr[];
+  if (kUseSkip) {
+    for (int i = threadIdx.x; i < V.pyr_off[0]; i += blockDim.x) s_pyr[i] = V.pyr[i];
+    __syncthreads();
+  }
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const float limit = V.limit, sd = limit * 0.5f;                       // sampleDistance, :34
   const int px = blockIdx.x * 16 + (wv & 1) * 8 + (ln & 7);
   const int py = blockIdx.y * 16 + (wv >> 1) * 8 + (ln >> 3);
-  if (px >= P.w || py >= P.h) return;
+  const bool inside = px < P.w && py < P.h;
   const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-  const float limit = V.limit, sd = limit * 0.5f;                       // sampleDistance, :34
   const float3 dn = normalize3(pixel_dir_vol(P, fx, fy));
   const float3 step = make_float3(dn.x * sd, dn.y * sd, dn.z * sd);     // :64
   uint32_t max_n = 0;
   float3 pos = make_float3(0, 0, 0);
-  bool covered = true;
-  if (P.skip) {                                                         // getStartPos(), :384-393
-    const uint4 dmb = ((const uint4*)R.peels)[(size_t)py * P.w + px];
-    const float dm_r = __uint_as_float(dmb.x), dm_g = -__uint_as_float(dmb.y), dm_b = __uint_as_float(dmb.z);   // g = min(-z) = -max z
-    float r = dm_r;
-    r = (r >= dm_b) ? 0.0f : r;
-    const float3 pf = screen_to_vol(P, fx, fy, r);
-    float3 pb = screen_to_vol(P, fx, fy, -dm_g);
-    if (r >= 1.0f) pb = pf;
-    pos = pf;
-    const float3 dd = make_float3(pf.x - pb.x, pf.y - pb.y, pf.z - pb.z);
-    max_n = (uint32_t)ceilf(sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z) / sd);   // :73
-  } else {                                                              // intersectBox(), :363-374
-    const float3 o = make_float3(P.cam_vol[0], P.cam_vol[1], P.cam_vol[2]);
-    const float3 inv = make_float3(1.0f / step.x, 1.0f / step.y, 1.0f / step.z);
-    const float3 tbot = make_float3(inv.x * (0.0f - o.x), inv.y * (0.0f - o.y), inv.z * (0.0f - o.z));
-    const float3 ttop = make_float3(inv.x * (1.0f - o.x), inv.y * (1.0f - o.y), inv.z * (1.0f - o.z));
-    const float3 tmn = make_float3(fminf(ttop.x, tbot.x), fminf(ttop.y, tbot.y), fminf(ttop.z, tbot.z));
-    const float3 tmx = make_float3(fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z));
-    const float t0 = fmaxf(fmaxf(tmn.x, tmn.y), fmaxf(tmn.x, tmn.z));
-    const float t1 = fminf(fminf(tmx.x, tmx.y), fminf(tmx.x, tmx.z));
-    if (!(t0 <= t1) || t1 < 0.0f) covered = false;                      // no fragment: pixel not under the cube
-    else {
-      const float t_near = t0 < 0.0f ? 0.0f : t0;
-      pos = make_float3(o.x + step.x * t_near, o.y + step.y * t_near, o.z + step.z * t_near);
-      max_n = (uint32_t)ceilf(fabsf(t1 - t_near));
+  bool covered = inside;
+  if (inside) {
+    if (P.skip) {                                                       // getStartPos(), :384-393
+      const uint4 dmb = ((const uint4*)R.peels)[(size_t)py * P.w + px];
+      const float dm_r = __uint_as_float(dmb.x), dm_g = -__uint_as_float(dmb.y), dm_b = __uint_as_float(dmb.z);   // g = min(-z) = -max z
+      float r = dm_r;
+      r = (r >= dm_b) ? 0.0f : r;
+      const float3 pf = screen_to_vol(P, fx, fy, r);
+      float3 pb = screen_to_vol(P, fx, fy, -dm_g);
+      if (r >= 1.0f) pb = pf;
+      pos = pf;
+      const float3 dd = make_float3(pf.x - pb.x, pf.y - pb.y, pf.z - pb.z);
+      max_n = (uint32_t)ceilf(sqrtf(dd.x * dd.x + dd.y * dd.y + dd.z * dd.z) / sd);   // :73
+    } else {                                                            // intersectBox(), :363-374
+      const float3 o = make_float3(P.cam_vol[0], P.cam_vol[1], P.cam_vol[2]);
+      const float3 inv = make_float3(1.0f / step.x, 1.0f / step.y, 1.0f / step.z);
+      const float3 tbot = make_float3(inv.x * (0.0f - o.x), inv.y * (0.0f - o.y), inv.z * (0.0f - o.z));
+      const float3 ttop = make_float3(inv.x * (1.0f - o.x), inv.y * (1.0f - o.y), inv.z * (1.0f - o.z));
+      const float3 tmn = make_float3(fminf(ttop.x, tbot.x), fminf(ttop.y, tbot.y), fminf(ttop.z, tbot.z));
+      const float3 tmx = make_float3(fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z));
+      const float t0 = fmaxf(fmaxf(tmn.x, tmn.y), fmaxf(tmn.x, tmn.z));
+      const float t1 = fminf(fminf(tmx.x, tmx.y), fminf(tmx.x, tmx.z));
+      if (!(t0 <= t1) || t1 < 0.0f) covered = false;                    // no fragment: pixel not under the cube
+      else {
+        const float t_near = t0 < 0.0f ? 0.0f : t0;
+        pos = make_float3(o.x + step.x * t_near, o.y + step.y * t_near, o.z + step.z * t_near);
+        max_n = (uint32_t)ceilf(fabsf(t1 - t_near));
+      }
     }
   }
-  float prev = -limit;                                                  // :89
+  // The march, :89-110.  Sample positions never depend on the densities, so (a) while the ray is in space known to hold
+  // nothing but -limit, whole runs of samples are accounted for by just performing the reference's `pos += step`
+  // additions, and (b) elsewhere four consecutive samples are fetched together and then examined in order.  Positions,
+  // densities and counts are those of the one-at-a-time loop.
+  const float dq[3] = {step.x * (float)V.res[0], step.y * (float)V.res[1], step.z * (float)V.res[2]};   // voxels per step
+  float prev = -limit;
   bool prev_valid = true;
+  bool try_skip = kUseSkip;                                             // the last samples seen were all exactly -limit
   float3 pos_prev = pos;
   uint32_t n = 0;
   bool hit = false;
-  while (n < max_n) {                                                   // :92-110
-    n += 1;
-    if (!partial || sample_owned(V, pos.z)) {
-      const float density = tex3d_tsdf(V, pos.x, pos.y, pos.z);
-      if (density > 0.0f) {
-        if (!prev_valid) prev = tex3d_tsdf(V, pos_prev.x, pos_prev.y, pos_prev.z);   // sample n-1 lies in the halo
-        const float k = prev / (density - prev);
-        pos = make_float3((pos.x - step.x) - step.x * k, (pos.y - step.y) - step.y * k, (pos.z - step.z) - step.z * k);
-        hit = true;
-        break;
+  float3 hit_pos = pos;
+  float hit_d = 0.0f;
+  while (n < max_n && !hit) {
+    if (try_skip) {
+      uint32_t cnt = empty_run(V, s_pyr, pos, dq);
+      if (cnt >= 3u) {
+        cnt += 1u;                                                      // the sample at pos itself
+        if (cnt > max_n - n) cnt = max_n - n;
+        for (uint32_t j = 0; j < cnt; ++j) {
+          pos_prev = pos;
+          pos = make_float3(pos.x + step.x, pos.y + step.y, pos.z + step.z);
+        }
+        n += cnt;
+        prev = -limit;
+        prev_valid = !partial;            // slab mode: the last sample may belong to a neighbour; a hit re-reads it
+        continue;
       }
-      prev = density;
-      prev_valid = true;
-    } else {
-      prev_valid = false;
     }
-    pos_prev = pos;
-    pos = make_float3(pos.x + step.x, pos.y + step.y, pos.z + step.z);
+    float3 p[4];
+    float d[4];
+    bool own[4];
+    p[0] = pos;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) p[k] = make_float3(p[k - 1].x + step.x, p[k - 1].y + step.y, p[k - 1].z + step.z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      own[k] = (n + k < max_n) && (!partial || sample_owned(V, p[k].z));
+      d[k] = own[k] ? tex3d_tsdf(V, p[k].x, p[k].y, p[k].z) : 0.0f;
+    }
+    bool all_minus = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!hit && n < max_n) {
+        n += 1;
+        if (own[k]) {
+          all_minus = all_minus && (d[k] == -limit);
+          if (d[k] > 0.0f) {
+            hit = true;
+            hit_pos = p[k];
+            hit_d = d[k];
+          } else {
+            prev = d[k];
+            prev_valid = true;
+            pos_prev = p[k];
+          }
+        } else {
+          prev_valid = false;
+          pos_prev = p[k];
+        }
+      }
+    }
+    try_skip = kUseSkip && all_minus;
+    if (!hit) pos = make_float3(p[3].x + step.x, p[3].y + step.y, p[3].z + step.z);
   }
-  const size_t oi = (size_t)py * R.stride + px;
-  float4 out = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
-  float out_d = 1.0f;
-  if (hit) {                                                            // submitFragment(), :116-134
+  if (hit) {                                                            // approximate ray-cell intersection, :99-101
+    if (partial && !prev_valid) prev = tex3d_tsdf(V, pos_prev.x, pos_prev.y, pos_prev.z);   // sample n-1 is a neighbour's: read it from the halo
+    const float kk = prev / (hit_d - prev);
+    pos = make_float3((hit_pos.x - step.x) - step.x * kk, (hit_pos.y - step.y) - step.y * kk, (hit_pos.z - step.z) - step.z * kk);
+  }
+  // compact the hits of this wave into the list (one atomic per wave)
+  const unsigned long long hm = __ballot(hit);
+  if (hm) {
+    const int leader = __ffsll((long long)hm) - 1;
+    uint32_t base = 0;
+    if (ln == leader) base = atomicAdd(hit_count, (uint32_t)__popcll(hm));
+    base = __shfl(base, leader);
+    if (hit) {
+      Hit h;
+      h.x = pos.x; h.y = pos.y; h.z = pos.z; h.pix = (uint32_t)(py * P.w + px);
+      hits[base + (uint32_t)__popcll(hm & ((1ull << ln) - 1ull))] = h;
+    }
+  }
+  if (inside) {
+    if (!hit) {                                                         // discard: the target keeps its clear value
+      const size_t oi = (size_t)py * R.stride + px;
+      R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
+      R.depth[oi] = 1.0f;
+    }
+    const float ns = (float)n * 0.0027f;                                // writeNumSamples(), :395-398
+    R.nsamples[(size_t)py * P.w + px] = covered ? ((partial && !hit) ? -ns : ns) : 0.0f;
+  }
+}
+
+// submitFragment(), :116-134, one thread per hit.  Thread 0 also re-arms the OTHER hit counter for the next frame.
+__global__ __launch_bounds__(256) void k_shade(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
+                                               const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0u;
+  const uint32_t n_hits = *hit_count;
+  const float limit = V.limit, sd = limit * 0.5f;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += gridDim.x * blockDim.x) {
+    const Hit h = hits[i];
+    const float3 pos = make_float3(h.x, h.y, h.z);
+    const int px = (int)(h.pix % (uint32_t)P.w), py = (int)(h.pix / (uint32_t)P.w);
     const float gx = tex3d_tsdf(V, pos.x + sd, pos.y, pos.z) - tex3d_tsdf(V, pos.x - sd, pos.y, pos.z);
     const float gy = tex3d_tsdf(V, pos.x, pos.y + sd, pos.z) - tex3d_tsdf(V, pos.x, pos.y - sd, pos.z);
     const float gz = tex3d_tsdf(V, pos.x, pos.y, pos.z + sd) - tex3d_tsdf(V, pos.x, pos.y, pos.z - sd);
@@ -302,16 +499,23 @@ __global__ __launch_bounds__(256) void k_raymarch(ViewParams P, StreamTable T, F
     }
     float fd = (P.proj.m[10] * vp.z + P.proj.m[14]) / -vp.z * 0.5f + 0.5f;   // gl_FragDepth, :133
     fd = fminf(fmaxf(fd, 0.0f), 1.0f);
-    if (fd < 1.0f) { out = col; out_d = fd; }                           // GL_LESS against the cleared 1.0
+    const size_t oi = (size_t)py * R.stride + px;
+    const bool pass = fd < 1.0f;                                        // GL_LESS against the cleared 1.0
+    R.color[oi] = pass ? col : make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
+    R.depth[oi] = pass ? fd : 1.0f;
   }
-  R.color[oi] = out;
-  R.depth[oi] = out_d;
-  const float ns = (float)n * 0.0027f;                                  // writeNumSamples(), :395-398
-  R.nsamples[(size_t)py * P.w + px] = covered ? ((partial && !hit) ? -ns : ns) : 0.0f;
 }
-void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial) {
+void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
+                     void* hit_list, uint32_t* hit_counters, int parity) {
+  if (kUseSkip) {
+    hipMemsetAsync(V.pyr, 0, (size_t)V.pyr_off[0] * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_build_pyramid, dim3(V.pyr_n[4][0], V.pyr_n[4][1], V.pyr_n[4][2]), dim3(256), 0, st, V);
+  }
   dim3 grid((P.w + 15) / 16, (P.h + 15) / 16);
-  hipLaunchKernelGGL(k_raymarch, grid, dim3(256), 0, st, P, T, F, V, R, partial);
+  const size_t lds = kUseSkip ? (size_t)V.pyr_off[0] * sizeof(uint32_t) : 0;
+  if (partial) hipLaunchKernelGGL(k_march<true>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+  else hipLaunchKernelGGL(k_march<false>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+  hipLaunchKernelGGL(k_shade, dim3(1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1));
 }
 
 // ------------------------------------------------------------------------------------------- multi-GPU image exchange

@@ -37,8 +37,10 @@ __device__ __forceinline__ float3 lerp3(float3 a, float3 b, float t) {
 // texture(sampler3D RGBA32F, p).xyz
 __device__ __forceinline__ float3 tex3d_rgba_xyz(const float4* __restrict__ t, const int* res, float u, float v, float w) {
   const Axis X = axis_linear(u, res[0]), Y = axis_linear(v, res[1]), Z = axis_linear(w, res[2]);
-  const size_t r00 = ((size_t)Z.i0 * res[1] + Y.i0) * res[0], r10 = ((size_t)Z.i0 * res[1] + Y.i1) * res[0];
-  const size_t r01 = ((size_t)Z.i1 * res[1] + Y.i0) * res[0], r11 = ((size_t)Z.i1 * res[1] + Y.i1) * res[0];
+  // 32-bit texel indices (a LUT has < 2^31 texels, checked at upload)
+  const uint32_t zr0 = (uint32_t)Z.i0 * (uint32_t)res[1], zr1 = (uint32_t)Z.i1 * (uint32_t)res[1];
+  const uint32_t r00 = (zr0 + Y.i0) * (uint32_t)res[0], r10 = (zr0 + Y.i1) * (uint32_t)res[0];
+  const uint32_t r01 = (zr1 + Y.i0) * (uint32_t)res[0], r11 = (zr1 + Y.i1) * (uint32_t)res[0];
   const float3 c00 = lerp3(t[r00 + X.i0], t[r00 + X.i1], X.a);
   const float3 c10 = lerp3(t[r10 + X.i0], t[r10 + X.i1], X.a);
   const float3 c01 = lerp3(t[r01 + X.i0], t[r01 + X.i1], X.a);
@@ -48,8 +50,9 @@ __device__ __forceinline__ float3 tex3d_rgba_xyz(const float4* __restrict__ t, c
 // texture(sampler3D RG32F, p).xy
 __device__ __forceinline__ float2 tex3d_rg(const float2* __restrict__ t, const int* res, float u, float v, float w) {
   const Axis X = axis_linear(u, res[0]), Y = axis_linear(v, res[1]), Z = axis_linear(w, res[2]);
-  const size_t r00 = ((size_t)Z.i0 * res[1] + Y.i0) * res[0], r10 = ((size_t)Z.i0 * res[1] + Y.i1) * res[0];
-  const size_t r01 = ((size_t)Z.i1 * res[1] + Y.i0) * res[0], r11 = ((size_t)Z.i1 * res[1] + Y.i1) * res[0];
+  const uint32_t zr0 = (uint32_t)Z.i0 * (uint32_t)res[1], zr1 = (uint32_t)Z.i1 * (uint32_t)res[1];
+  const uint32_t r00 = (zr0 + Y.i0) * (uint32_t)res[0], r10 = (zr0 + Y.i1) * (uint32_t)res[0];
+  const uint32_t r01 = (zr1 + Y.i0) * (uint32_t)res[0], r11 = (zr1 + Y.i1) * (uint32_t)res[0];
   float2 a = t[r00 + X.i0], b = t[r00 + X.i1];
   const float2 c00 = make_float2(lerpf(a.x, b.x, X.a), lerpf(a.y, b.y, X.a));
   a = t[r10 + X.i0]; b = t[r10 + X.i1];
@@ -66,10 +69,11 @@ __device__ __forceinline__ float2 tex3d_rg(const float2* __restrict__ t, const i
 struct Dqs { float4 t00, t10, t01, t11; float ax, ay; };
 __device__ __forceinline__ Dqs dqs_fetch(const FrameImages& F, int layer, float u, float v) {
   const Axis X = axis_linear(u, F.w), Y = axis_linear(v, F.h);
-  const float4* __restrict__ b = F.dqs + (size_t)layer * F.w * F.h;
+  const float4* __restrict__ b = F.dqs;
+  const uint32_t base = (uint32_t)layer * (uint32_t)(F.w * F.h), r0 = base + (uint32_t)Y.i0 * (uint32_t)F.w, r1 = base + (uint32_t)Y.i1 * (uint32_t)F.w;
   Dqs r;
-  r.t00 = b[(size_t)Y.i0 * F.w + X.i0]; r.t10 = b[(size_t)Y.i0 * F.w + X.i1];
-  r.t01 = b[(size_t)Y.i1 * F.w + X.i0]; r.t11 = b[(size_t)Y.i1 * F.w + X.i1];
+  r.t00 = b[r0 + X.i0]; r.t10 = b[r0 + X.i1];
+  r.t01 = b[r1 + X.i0]; r.t11 = b[r1 + X.i1];
   r.ax = X.a; r.ay = Y.a;
   return r;
 }
@@ -88,25 +92,37 @@ __device__ __forceinline__ float dqs_depth(const Dqs& d) {
   return yr ? hi : lo;
 }
 
-// TSDF R32F, LINEAR + CLAMP_TO_EDGE, tile-major storage
-__device__ __forceinline__ size_t vol_index(const Volume& V, int x, int y, int z) {
-  const size_t tile = ((size_t)((z >> 3) - V.tz0) * V.nty + (y >> 3)) * V.ntx + (x >> 3);
-  return (tile << 9) + ((z & 7) << 6) + ((y & 7) << 3) + (x & 7);
-}
-__device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) {
-  const Axis X = axis_linear(u, V.res[0]), Y = axis_linear(v, V.res[1]);
-  Axis Z = axis_linear(w, V.res[2]);
+// TSDF R32F, LINEAR + CLAMP_TO_EDGE, tile-major storage.  All offsets are 32-bit element indices (a context stores
+// < 2^32 voxels); the address of tap (x,y,z) is the sum of three per-axis partial offsets, so the eight taps of a
+// footprint cost six partials and eight adds instead of eight full index computations.
+__device__ __forceinline__ uint32_t vol_off_x(int x) { return ((uint32_t)(x >> 3) << 9) + (uint32_t)(x & 7); }
+__device__ __forceinline__ uint32_t vol_off_y(const Volume& V, int y) { return (((uint32_t)(y >> 3) * (uint32_t)V.ntx) << 9) + ((uint32_t)(y & 7) << 3); }
+__device__ __forceinline__ uint32_t vol_off_z(const Volume& V, int z) { return (((uint32_t)((z >> 3) - V.tz0) * (uint32_t)(V.nty * V.ntx)) << 9) + ((uint32_t)(z & 7) << 6); }
+__device__ __forceinline__ size_t vol_index(const Volume& V, int x, int y, int z) { return (size_t)(vol_off_x(x) + vol_off_y(V, y) + vol_off_z(V, z)); }
+
+struct TsdfTaps { Axis X, Y, Z; };
+__device__ __forceinline__ TsdfTaps tsdf_taps(const Volume& V, float u, float v, float w) {
+  TsdfTaps t;
+  t.X = axis_linear(u, V.res[0]); t.Y = axis_linear(v, V.res[1]); t.Z = axis_linear(w, V.res[2]);
   // A slab context stores only planes [zlo, zhi].  Owned samples never leave them; a NaN position (NaN voxels exist,
   // tsdf_integration.vs:52) would clamp to plane 0, so keep the taps inside the allocation (the result is NaN anyway).
-  Z.i0 = clampi(Z.i0, V.zlo, V.zhi);
-  Z.i1 = clampi(Z.i1, V.zlo, V.zhi);
-  const float* __restrict__ t = V.data;
-  const float c00 = lerpf(t[vol_index(V, X.i0, Y.i0, Z.i0)], t[vol_index(V, X.i1, Y.i0, Z.i0)], X.a);
-  const float c10 = lerpf(t[vol_index(V, X.i0, Y.i1, Z.i0)], t[vol_index(V, X.i1, Y.i1, Z.i0)], X.a);
-  const float c01 = lerpf(t[vol_index(V, X.i0, Y.i0, Z.i1)], t[vol_index(V, X.i1, Y.i0, Z.i1)], X.a);
-  const float c11 = lerpf(t[vol_index(V, X.i0, Y.i1, Z.i1)], t[vol_index(V, X.i1, Y.i1, Z.i1)], X.a);
-  return lerpf(lerpf(c00, c10, Y.a), lerpf(c01, c11, Y.a), Z.a);
+  t.Z.i0 = clampi(t.Z.i0, V.zlo, V.zhi);
+  t.Z.i1 = clampi(t.Z.i1, V.zlo, V.zhi);
+  return t;
 }
+__device__ __forceinline__ float tsdf_fetch(const Volume& V, const TsdfTaps& t) {
+  const float* __restrict__ d = V.data;
+  const uint32_t x0 = vol_off_x(t.X.i0), x1 = vol_off_x(t.X.i1);
+  const uint32_t y0 = vol_off_y(V, t.Y.i0), y1 = vol_off_y(V, t.Y.i1);
+  const uint32_t z0 = vol_off_z(V, t.Z.i0), z1 = vol_off_z(V, t.Z.i1);
+  const uint32_t b00 = z0 + y0, b10 = z0 + y1, b01 = z1 + y0, b11 = z1 + y1;
+  const float c00 = lerpf(d[b00 + x0], d[b00 + x1], t.X.a);
+  const float c10 = lerpf(d[b10 + x0], d[b10 + x1], t.X.a);
+  const float c01 = lerpf(d[b01 + x0], d[b01 + x1], t.X.a);
+  const float c11 = lerpf(d[b11 + x0], d[b11 + x1], t.X.a);
+  return lerpf(lerpf(c00, c10, t.Y.a), lerpf(c01, c11, t.Y.a), t.Z.a);
+}
+__device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) { return tsdf_fetch(V, tsdf_taps(V, u, v, w)); }
 
 __device__ __forceinline__ float4 mat_mul(const Mat4& a, float x, float y, float z, float w) {
   return make_float4(a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w,

@@ -39,17 +39,35 @@ struct Volume {
   int tz0, tz1;        // stored tile layers (owned slab + halo)
   int own_tz0, own_tz1;  // owned tile layers (integrated by this context)
   int zlo, zhi;        // stored voxel planes [zlo, zhi]: every Z tap is clamped into them (slab contexts)
+  const uint8_t* cls;  // tile class of every STORED tile, index ((tz - tz0) * nty + ty) * ntx + tx; halo layers stay kTileMixed
+  int n_stored_tiles;
+  // Empty-space pyramid over the WHOLE volume, rebuilt before every raymarch: level l (1..4) has one bit per cell of
+  // 2^l tiles (16, 32, 64, 128 voxels) = 1 iff every tile of the cell is stored by this context and is kTileMinus.
+  uint32_t* pyr;       // bit arrays of the four levels, back to back
+  int pyr_off[5];      // word offset of level l (index 1..4); pyr_off[0] = total words
+  int pyr_n[5][3];     // cells per axis of level l
   float limit;
 };
 
 // Per-tile bookkeeping of the owned tiles (index = owned tile id, x fastest, own_tz0 first):
 //   active  this frame: some voxel of the tile is in the voxel list of an occupied brick
-//   dirty   the tile's 2 KiB in HBM differ from the clear value -limit
-// integrate() clears only dirty inactive tiles and computes only active ones, so a frame's volume traffic
-// follows the occupied bricks instead of the whole volume (the reference clears everything, :249-250).
+//   cls     what the tile's 2 KiB in HBM hold: 0 = every voxel is -limit (the clear value), 1 = every voxel is +limit,
+//           2 = anything else / unknown
+// integrate() clears only inactive tiles with cls != 0 and computes only active ones, so a frame's volume traffic
+// follows the occupied bricks instead of the whole volume (the reference clears everything, :249-250).  The raymarch
+// uses cls to skip the fetch of samples whose whole footprint lies in uniform tiles (the value is known exactly).
+constexpr uint8_t kTileMinus = 0, kTilePlus = 1, kTileMixed = 2;
+// Empty-space run skipping in the raymarch (bit pyramid of all-(-limit) cells, k_raymarch.hip) and the per-tile class
+// vote in integrate that feeds it.  Measured on MI355X it LOSES (c2 march 68 -> 98 us, c1 280 -> 340 us, plus a 17 us
+// pyramid build): a skip decision costs about as many VALU instructions as the few samples it saves at 2.56 voxels per
+// step.  Kept behind this switch, off, with the measurement in DESIGN.md.
+#ifndef RR_USE_SKIP
+#define RR_USE_SKIP 0
+#endif
+constexpr bool kUseSkip = RR_USE_SKIP != 0;
 struct TileState {
   uint8_t* active;
-  uint8_t* dirty;
+  uint8_t* cls;        // owned tiles only (points into Volume::cls at the first owned layer)
   uint32_t* list;      // compacted active tile ids (unordered)
   uint32_t* count;     // device scalar
   int n;               // owned tiles
@@ -101,12 +119,13 @@ void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages&
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, int zero_count);
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count);
 int integrate_box_cap();
-void launch_mark_all_dirty(hipStream_t st, const TileState& S);
+void launch_mark_all_mixed(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
 void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* linear);
 void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels);
 struct RayTarget { float4* color; float* depth; int stride; float* nsamples; const float4* peels; float clear[4]; };
-void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial);
+void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
+                     void* hit_list, uint32_t* hit_counters, int parity);   // hit_list: 16 B per view pixel; two counters used alternately
 void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod);
 void launch_inpaint_pyramid(hipStream_t st, const Atlas& A);
 void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth);
