@@ -159,18 +159,39 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 }
 
 // LDS path.  The voxel grid is axis aligned with the inverse LUT, so the 512 voxels of a tile only ever touch a
-// small box of LUT texels per stream (4^3 at 512^3 over a 128^3 LUT).  Per tile and chunk of up to 4 streams:
+// small box of LUT texels per stream (4^3 at 512^3 over a 128^3 LUT) and the trilinear filter is separable over the
+// tile.  Per tile and chunk of kChunk streams:
 //   A  24 lanes per stream evaluate the per-axis GL filter set-up (i0, i1, weight) of the tile's 8 voxel coordinates
 //   B  the workgroup copies each stream's texel box HBM/L2 -> LDS with one batch of independent 16-B loads
-//   C  every voxel interpolates x -> y -> z out of LDS (the same fp32 operations as tex3d_rgba_xyz), issues the image
-//      gathers of ALL streams of the chunk together, and only then runs the order-dependent fusion rule on registers
-// so a voxel pays two dependent memory round trips per chunk instead of two per stream.
-constexpr int kBoxCap = 512;      // LUT texels per stream held in LDS (8 KiB); the host checks the bound per calibration
-constexpr int kChunk = 2;
+//   X  lerp along x for every (row of the box, voxel x)            dz*dy*8 lerps  (128)
+//   Y  lerp along y for every (box z-plane, voxel y, voxel x)      dz*8*8  lerps  (256)
+//   Z  each voxel lerps its two z-planes (512), issues the image gathers of ALL streams of the chunk together, and
+//      only then runs the order-dependent fusion rule on registers
+// The x -> y -> z order and every operand are those of tex3d_rgba_xyz, so the result is bit-identical, at 1.75 instead
+// of 7 three-component lerps per voxel and stream, and a voxel pays two dependent memory round trips per chunk.
+// Tuning knobs, values from A/B runs on MI355X (c2 / c1 integrate, ms): chunk 2, 4 waves/SIMD, 512-texel cap 0.139 / 0.509;
+// + both voxels of a thread in flight 0.108 / 0.463; + 384-texel cap, 5 waves 0.096 / 0.384; chunk 1, 6 waves/SIMD
+// 0.085 / 0.347 (chosen).  The kernel is bound by dependent-load latency per workgroup, so occupancy wins.
+#ifndef RR_K1_BOXCAP
+#define RR_K1_BOXCAP 384
+#endif
+#ifndef RR_K1_BOUNDS
+#define RR_K1_BOUNDS 6
+#endif
+#ifndef RR_K1_UNROLL_H
+#define RR_K1_UNROLL_H 2
+#endif
+constexpr int kBoxCap = RR_K1_BOXCAP;   // LUT texels per stream held in LDS; also caps the y-pass planes (dz * 64)
+constexpr int kRowCap = RR_K1_BOXCAP;   // x-pass results: dz*dy rows of 8
+#ifndef RR_K1_CHUNK
+#define RR_K1_CHUNK 1
+#endif
+constexpr int kChunk = RR_K1_CHUNK;
 
 template <bool kList>
-__global__ __launch_bounds__(256, 4) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
-  __shared__ float4 s_box[kChunk][kBoxCap];
+__global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
+  __shared__ float4 s_box[kChunk][kBoxCap];     // the texel box; after the x-pass it is reused for the y-pass results
+  __shared__ float4 s_row[kChunk][kRowCap];     // x-pass results
   __shared__ int s_i0[kChunk][3][8], s_i1[kChunk][3][8];
   __shared__ float s_w[kChunk][3][8];
   __shared__ int s_flag;
@@ -218,27 +239,42 @@ __global__ __launch_bounds__(256, 4) void k_integrate_tiles_lds(StreamTable T, F
         }
       }
       __syncthreads();
-      if (__ballot(drawn[0] | drawn[1]) != 0ull) {                      // phase C
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {                                   // one voxel at a time: half the live registers
+      for (int c = 0; c < nc; ++c) {                                    // pass X
+        const int mx = s_i0[c][0][0];
+        const int dx = s_i1[c][0][7] - mx + 1, dy = s_i1[c][1][7] - s_i0[c][1][0] + 1, dz = s_i1[c][2][7] - s_i0[c][2][0] + 1;
+        const int n1 = min(dy * dz * 8, kRowCap);
+        for (int e = tid; e < n1; e += 256) {
+          const int k = e & 7, row = e >> 3;
+          const float4 a = s_box[c][row * dx + (s_i0[c][0][k] - mx)], b = s_box[c][row * dx + (s_i1[c][0][k] - mx)];
+          const float3 r = lerp3(a, b, s_w[c][0][k]);
+          s_row[c][e] = make_float4(r.x, r.y, r.z, 0.0f);
+        }
+      }
+      __syncthreads();
+      for (int c = 0; c < nc; ++c) {                                    // pass Y (overwrites the box)
+        const int my = s_i0[c][1][0];
+        const int dy = s_i1[c][1][7] - my + 1, dz = s_i1[c][2][7] - s_i0[c][2][0] + 1;
+        const int n2 = min(dz * 64, kBoxCap);
+        for (int e = tid; e < n2; e += 256) {
+          const int k = e & 7, j = (e >> 3) & 7, bz = e >> 6;
+          const float4 a = s_row[c][((bz * dy + (s_i0[c][1][j] - my)) << 3) + k], b = s_row[c][((bz * dy + (s_i1[c][1][j] - my)) << 3) + k];
+          const float3 r = lerp3(a, b, s_w[c][1][j]);
+          s_box[c][e] = make_float4(r.x, r.y, r.z, 0.0f);
+        }
+      }
+      __syncthreads();
+      if (__ballot(drawn[0] | drawn[1]) != 0ull) {                      // pass Z + fusion
+#pragma unroll RR_K1_UNROLL_H
+        for (int h = 0; h < 2; ++h) {
           const int kz = lz + 4 * h;
           float3 pc[kChunk];
           Dqs q[kChunk];
 #pragma unroll
           for (int c = 0; c < kChunk; ++c) {
             if (c < nc) {
-              const int mx = s_i0[c][0][0], my = s_i0[c][1][0], mz = s_i0[c][2][0];
-              const int dx = s_i1[c][0][7] - mx + 1, dy = s_i1[c][1][7] - my + 1;
-              const int x0 = s_i0[c][0][lx] - mx, x1 = s_i1[c][0][lx] - mx;
-              const int y0 = (s_i0[c][1][ly] - my) * dx, y1 = (s_i1[c][1][ly] - my) * dx;
-              const int z0 = (s_i0[c][2][kz] - mz) * dx * dy, z1 = (s_i1[c][2][kz] - mz) * dx * dy;
-              const float ax = s_w[c][0][lx], ay = s_w[c][1][ly], az = s_w[c][2][kz];
-              const float4* bx = s_box[c];
-              const float3 c00 = lerp3(bx[z0 + y0 + x0], bx[z0 + y0 + x1], ax);
-              const float3 c10 = lerp3(bx[z0 + y1 + x0], bx[z0 + y1 + x1], ax);
-              const float3 c01 = lerp3(bx[z1 + y0 + x0], bx[z1 + y0 + x1], ax);
-              const float3 c11 = lerp3(bx[z1 + y1 + x0], bx[z1 + y1 + x1], ax);
-              pc[c] = lerp3(lerp3(c00, c10, ay), lerp3(c01, c11, ay), az);
+              const int mz = s_i0[c][2][0];
+              const float4 a = s_box[c][(((s_i0[c][2][kz] - mz) << 3) + ly) * 8 + lx], b = s_box[c][(((s_i1[c][2][kz] - mz) << 3) + ly) * 8 + lx];
+              pc[c] = lerp3(a, b, s_w[c][2][kz]);
             }
           }
 #pragma unroll
