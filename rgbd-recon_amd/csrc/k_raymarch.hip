@@ -328,8 +328,16 @@ __device__ __forceinline__ uint32_t empty_run(const Volume& V, const uint32_t* p
   return 0u;
 }
 
+#ifndef RR_MARCH_BATCH
+#define RR_MARCH_BATCH 8
+#endif
+#ifndef RR_MARCH_BOUNDS
+#define RR_MARCH_BOUNDS 1
+#endif
+constexpr int kBatch = RR_MARCH_BATCH;   // samples in flight per ray
+
 template <bool kPartial>
-__global__ __launch_bounds__(256) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
+__global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
   constexpr bool partial = kPartial;
   extern __shared__ uint32_t s_pyr[];
   if (kUseSkip) {
@@ -405,20 +413,21 @@ __global__ __launch_bounds__(256) void k_march(ViewParams P, Volume V, RayTarget
         continue;
       }
     }
-    float3 p[4];
-    float d[4];
-    bool own[4];
+    float3 p[kBatch];
+    float d[kBatch];
+    bool own[kBatch];
     p[0] = pos;
 #pragma unroll
-    for (int k = 1; k < 4; ++k) p[k] = make_float3(p[k - 1].x + step.x, p[k - 1].y + step.y, p[k - 1].z + step.z);
+    for (int k = 1; k < kBatch; ++k) p[k] = make_float3(p[k - 1].x + step.x, p[k - 1].y + step.y, p[k - 1].z + step.z);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kBatch; ++k) {
       own[k] = (n + k < max_n) && (!partial || sample_owned(V, p[k].z));
-      d[k] = own[k] ? tex3d_tsdf(V, p[k].x, p[k].y, p[k].z) : 0.0f;
+      d[k] = tex3d_tsdf(V, p[k].x, p[k].y, p[k].z);   // unconditional: taps are clamped into the allocation, and a predicated
+                                                      // fetch would make the compiler wait for each sample's loads separately
     }
     bool all_minus = true;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kBatch; ++k) {
       if (!hit && n < max_n) {
         n += 1;
         if (own[k]) {
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(256) void k_march(ViewParams P, Volume V, RayTarget
       }
     }
     try_skip = kUseSkip && all_minus;
-    if (!hit) pos = make_float3(p[3].x + step.x, p[3].y + step.y, p[3].z + step.z);
+    if (!hit) pos = make_float3(p[kBatch - 1].x + step.x, p[kBatch - 1].y + step.y, p[kBatch - 1].z + step.z);
   }
   if (hit) {                                                            // approximate ray-cell intersection, :99-101
     if (partial && !prev_valid) prev = tex3d_tsdf(V, pos_prev.x, pos_prev.y, pos_prev.z);   // sample n-1 is a neighbour's: read it from the halo
