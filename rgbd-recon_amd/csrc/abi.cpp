@@ -48,6 +48,7 @@ struct tsdf_ctx {
   uint16_t* d_tile_b1[3]{};
   bool occ_count_zeroed = false, tile_count_zeroed = false;   // the two device scalars were reset by tsdf_clear_bricks' memset
   uint32_t min_voxels = 10;      // recon_integration.cpp:59
+  size_t counter_words = 0;
   uint32_t* h_num_occupied = nullptr;   // pinned
   // calibration + frame
   StreamTable luts{};
@@ -233,12 +234,13 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
       uniform = count[a][v] == 1 && first[a][v] == first[a][v & ~7];
   c->tiles.uniform = uniform ? 1 : 0;
   // [counters (n) | num_occupied | active tile count]: one memset per frame resets all three (tsdf_clear_bricks)
-  HIP_TRY(c, hipMalloc(&B.counters, ((size_t)B.n + 2) * sizeof(uint32_t)));
+  c->counter_words = (((size_t)B.n + 2 + 63) / 64) * 64;      // one aligned fill kernel instead of body + tail
+  HIP_TRY(c, hipMalloc(&B.counters, c->counter_words * sizeof(uint32_t)));
   B.num_occupied = B.counters + B.n;
   c->tiles.count = B.counters + B.n + 1;
   HIP_TRY(c, hipMalloc(&B.flags, (size_t)B.n));
   HIP_TRY(c, hipMalloc(&B.occupied, (size_t)B.n * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemset(B.counters, 0, ((size_t)B.n + 2) * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(B.counters, 0, c->counter_words * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(B.flags, 0, (size_t)B.n));
   c->occ_count_zeroed = c->tile_count_zeroed = false;
   return TSDF_OK;
@@ -527,7 +529,7 @@ int32_t tsdf_clear_bricks(tsdf_ctx* c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "bricks");
-  HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, ((size_t)c->br.n + 2) * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), c->stream));
   c->occ_count_zeroed = c->tile_count_zeroed = true;
   return TSDF_OK;
 }
@@ -546,19 +548,17 @@ int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
   launch_update_occupied(c->stream, c->br, c->min_voxels, c->occ_count_zeroed ? 0 : 1);
   c->occ_count_zeroed = false;
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(c->h_num_occupied, c->br.num_occupied, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   timer_end(c, "bricks");
-  if (ratio) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *ratio = (float)*c->h_num_occupied / (float)c->br.n;               // :440
-  }
+  if (ratio) return tsdf_occupied_ratio(c, ratio);                     // the reference reads the count back every frame (:432-440); here only on request
   return TSDF_OK;
 }
 int32_t tsdf_occupied_ratio(tsdf_ctx* c, float* ratio) {
   CHECK_CTX(c);
   if (!ratio) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(c->h_num_occupied, c->br.num_occupied, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  *ratio = (float)*c->h_num_occupied / (float)c->br.n;
+  *ratio = (float)*c->h_num_occupied / (float)c->br.n;                 // :440
   return TSDF_OK;
 }
 

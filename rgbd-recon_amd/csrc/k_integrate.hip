@@ -2,9 +2,9 @@
 // recon_integration.cpp:242-269).
 //
 // The reference clears the whole volume and then draws the voxel lists of the occupied bricks, one GL
-// draw per brick.  Here one frame is three launches over 8x8x8 storage tiles (2 KiB each, tile-major):
-//   k_classify_tiles   which tiles contain a voxel of an occupied brick's list -> compact "active" list
-//   k_clear_tiles      tiles that are inactive but still hold old surface data are reset to -limit
+// draw per brick.  Here one frame is two launches over 8x8x8 storage tiles (2 KiB each, tile-major):
+//   k_classify_clear_tiles  which tiles contain a voxel of an occupied brick's list -> compact "active" list; tiles that
+//                      are inactive but still hold old surface data are reset to -limit in the same pass
 //                      (tiles already clear are not touched: no dense 4*V store per frame)
 //   k_integrate_tiles* active tiles only (persistent workgroups pulling from the list); a tile is written
 //                      as two fully coalesced 1 KiB stores per wave; the _lds variant stages the LUT box in LDS
@@ -58,44 +58,46 @@ __device__ __forceinline__ void tile_coords(const Volume& V, int tile, int& tx, 
   tx = tile % V.ntx; ty = (tile / V.ntx) % V.nty; tz = V.own_tz0 + tile / (V.ntx * V.nty);
 }
 
-// One thread per owned tile: any occupied brick among those whose voxel lists can reach into the tile?
-__global__ __launch_bounds__(256) void k_classify_tiles(Volume V, Bricks B, TileState S) {
-  const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tile >= S.n) return;
-  int t[3];
-  tile_coords(V, tile, t[0], t[1], t[2]);
-  int b0[3], b1[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { b0[a] = B.tile_b0[a][t[a]]; b1[a] = B.tile_b1[a][t[a]]; }   // host-built brick span per tile index
-  bool active = false;
-  for (int k = b0[2]; k <= b1[2]; ++k)
-    for (int j = b0[1]; j <= b1[1]; ++j)
-      for (int i = b0[0]; i <= b1[0]; ++i)
-        active |= B.flags[((size_t)k * B.res[1] + j) * B.res[0] + i] != 0;
-  S.active[tile] = active ? 1 : 0;
-  if (active) S.list[atomicAdd(S.count, 1u)] = (uint32_t)tile;      // hipcc folds this into one add per wave
-}
-
-// Reset inactive tiles that hold anything but the clear value.  Each wave looks at 64 tiles per step (one coalesced
-// 64-byte read of each flag array) and streams -limit over the dirty ones: 2 x 16 B per lane per tile.
-__global__ __launch_bounds__(256) void k_clear_tiles(Volume V, TileState S) {
+// One lane per owned tile: is any occupied brick among those whose voxel lists can reach into the tile?  Active tiles go
+// to the compacted work list (one atomic per wave); inactive tiles that hold anything but the clear value are reset on
+// the spot by the whole wave (2 x 16 B per lane per tile).  Tiles already clear are not touched.
+__global__ __launch_bounds__(256) void k_classify_clear_tiles(Volume V, Bricks B, TileState S) {
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+  bool active = false, need_clear = false;
+  if (tile < S.n) {
+    int t[3];
+    tile_coords(V, tile, t[0], t[1], t[2]);
+    int b0[3], b1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { b0[a] = B.tile_b0[a][t[a]]; b1[a] = B.tile_b1[a][t[a]]; }   // host-built brick span per tile index
+    for (int k = b0[2]; k <= b1[2]; ++k)
+      for (int j = b0[1]; j <= b1[1]; ++j)
+        for (int i = b0[0]; i <= b1[0]; ++i)
+          active |= B.flags[((size_t)k * B.res[1] + j) * B.res[0] + i] != 0;
+    S.active[tile] = active ? 1 : 0;
+    need_clear = !active && S.cls[tile] != kTileMinus;
+    if (need_clear) S.cls[tile] = kTileMinus;
+  }
+  const unsigned long long am = __ballot(active);
+  if (am) {
+    const int leader = __ffsll((long long)am) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(S.count, (uint32_t)__popcll(am));
+    base = __shfl(base, leader);
+    if (active) S.list[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)tile;
+  }
+  unsigned long long m = __ballot(need_clear);
   const float4 cv = make_float4(-V.limit, -V.limit, -V.limit, -V.limit);
-  for (int base = wave * 64; base < S.n; base += nwaves * 64) {
-    const int tile = base + lane;
-    const bool need = tile < S.n && !S.active[tile] && S.cls[tile] != kTileMinus;
-    unsigned long long m = __ballot(need);
-    if (need) S.cls[tile] = kTileMinus;
-    while (m) {
-      const int b = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      int tx, ty, tz;
-      tile_coords(V, base + b, tx, ty, tz);
-      float4* __restrict__ out = (float4*)(V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9));
-      out[lane] = cv;
-      out[lane + 64] = cv;
-    }
+  const int wave_base = tile - lane;
+  while (m) {
+    const int bpos = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    int tx, ty, tz;
+    tile_coords(V, wave_base + bpos, tx, ty, tz);
+    float4* __restrict__ out = (float4*)(V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9));
+    out[lane] = cv;
+    out[lane + 64] = cv;
   }
 }
 
@@ -323,8 +325,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count) {
   if (use_bricks) {
     if (zero_count) hipMemsetAsync(S.count, 0, sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_classify_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
-    hipLaunchKernelGGL(k_clear_tiles, dim3(1024), dim3(256), 0, st, V, S);
+    hipLaunchKernelGGL(k_classify_clear_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
     const dim3 grid(S.n < 4096 ? S.n : 4096);
     if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);

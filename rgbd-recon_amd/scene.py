@@ -96,8 +96,8 @@ class Camera:
         return (self.cx + self.f * a) / self.w, (self.cy + self.f * b) / self.h, d
 
 
-def _ray_sphere(o, d):
-    oc = o - SPHERE_C
+def _ray_sphere(o, d, centre):
+    oc = o - centre
     b = np.einsum("...k,...k->...", oc, d)
     c = np.einsum("...k,...k->...", oc, oc) - SPHERE_R ** 2
     a = np.einsum("...k,...k->...", d, d)
@@ -106,8 +106,8 @@ def _ray_sphere(o, d):
     return np.where(t > 0, t, np.inf)
 
 
-def _ray_box(o, d):
-    lo, hi = BOX_C - BOX_H, BOX_C + BOX_H
+def _ray_box(o, d, centre):
+    lo, hi = centre - BOX_H, centre + BOX_H
     with np.errstate(divide="ignore", invalid="ignore"):
         inv = 1.0 / d
         t0 = (lo - o) * inv
@@ -122,8 +122,11 @@ def _ray_box(o, d):
 
 
 def make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128, seed=1234,
-               color_width=None, color_height=None):
-    """Returns a dict of contiguous numpy arrays (see module docstring for formats)."""
+               color_width=None, color_height=None, sphere_c=None, box_c=None):
+    """Returns a dict of contiguous numpy arrays (see module docstring for formats).  sphere_c / box_c move the two
+    objects (a second, different frame for the same calibration)."""
+    sphere_c = SPHERE_C if sphere_c is None else np.asarray(sphere_c, np.float64)
+    box_c = BOX_C if box_c is None else np.asarray(box_c, np.float64)
     rng = np.random.default_rng(seed)
     focal = 570.0 * width / 640.0
     cw = color_width or width
@@ -167,13 +170,13 @@ def make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128, see
         b = (py - cam.cy) / cam.f
         dirs = cam.fwd + a[..., None] * cam.right + b[..., None] * cam.up      # z-depth parametrised
         o = np.broadcast_to(cam.pos, dirs.shape)
-        ts = _ray_sphere(o, dirs)
-        tb, axis = _ray_box(o, dirs)
+        ts = _ray_sphere(o, dirs, sphere_c)
+        tb, axis = _ray_box(o, dirs, box_c)
         t = np.minimum(ts, tb)
         hit = np.isfinite(t)
         tt = np.where(hit, t, 0.0)
         p = o + tt[..., None] * dirs
-        nrm_s = (p - SPHERE_C) / SPHERE_R
+        nrm_s = (p - sphere_c) / SPHERE_R
         nrm_b = np.zeros_like(p)
         sgn = -np.sign(np.take_along_axis(dirs, axis[..., None], -1))[..., 0]
         np.put_along_axis(nrm_b, axis[..., None], sgn[..., None], -1)

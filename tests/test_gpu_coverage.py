@@ -1,0 +1,110 @@
+"""-m gpu: configurations and state changes around the hot path, each against the oracle on identical inputs:
+stream counts 1 and 8 (the reference hard-codes 5), unequal LUT / colour resolutions, every setter the operator has,
+and a sequence of different frames (the tile bookkeeping must reset tiles that stop being occupied)."""
+import numpy as np
+import pytest
+
+from helpers import tsdf_close
+from oracle.oracle import OracleRecon
+
+pytestmark = pytest.mark.gpu
+
+LIMIT = 0.04
+KW = dict(res=(64, 64, 64), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=LIMIT, view=(160, 90))
+
+
+def frame(o, mv, pr):
+    o.clearOccupiedBricks(); o.markBricks(); r = o.updateOccupiedBricks()
+    o.integrate()
+    o.drawF(mv, pr)
+    return r
+
+
+def compare(hip, orc, limit=LIMIT):
+    a, b = hip.tsdf(), orc.tsdf()
+    assert tsdf_close(a, b, limit).all()
+    (fc, fd), (gc, gd) = hip.framebuffer(), orc.framebuffer()
+    assert ((fd < 1) != (gd < 1)).mean() <= 2e-3
+    both = (fd < 1) & (gd < 1)
+    assert (np.abs(fd[both] - gd[both]) > 1e-4).mean() <= 2e-3
+    with np.errstate(invalid="ignore"):
+        assert (np.abs(fc[both] - gc[both]) > 2e-3).mean() <= 1e-2
+    return both.sum()
+
+
+@pytest.mark.parametrize("n_streams", [1, 8])
+def test_stream_counts(rr, n_streams):
+    sc = rr.scene.make_scene(n_streams=n_streams, width=96, height=72, lut_res=16, inv_res=24, color_width=64, color_height=40)
+    hip, orc = rr.ReconIntegrationHip(sc, **KW), OracleRecon(sc, **KW)
+    mv, pr = rr.scene.default_view(*KW["view"])
+    assert frame(hip, mv, pr) == frame(orc, mv, pr)
+    assert compare(hip, orc) > 200
+
+
+def test_lut_finer_than_volume_takes_the_global_path(rr):
+    """inverse LUT 64^3 over a 32^3 TSDF: a tile's texel box (18^3) exceeds the LDS budget -> generic kernel, same answer."""
+    sc = rr.scene.make_scene(n_streams=2, width=96, height=72, lut_res=16, inv_res=64)
+    kw = dict(KW, res=(32, 32, 32), limit=0.08)
+    hip, orc = rr.ReconIntegrationHip(sc, **kw), OracleRecon(sc, **kw)
+    for o in (hip, orc):
+        o.setUseBricks(False)
+        o.integrate()
+    assert tsdf_close(hip.tsdf(), orc.tsdf(), 0.08).all()
+
+
+def test_setters_between_frames(rr, small_scene):
+    hip, orc = rr.ReconIntegrationHip(small_scene, **KW), OracleRecon(small_scene, **KW)
+    mv, pr = rr.scene.default_view(*KW["view"])
+    frame(hip, mv, pr); frame(orc, mv, pr)
+    compare(hip, orc)
+    # setTsdfLimit: the clear value and the raymarch step change (recon_integration.cpp:456-460)
+    for o in (hip, orc):
+        o.setTsdfLimit(0.06)
+    frame(hip, mv, pr); frame(orc, mv, pr)
+    compare(hip, orc, 0.06)
+    # setMinVoxelsPerBrick + setUseBricks / setSpaceSkip / setColorFilling toggles
+    for o in (hip, orc):
+        o.setMinVoxelsPerBrick(40)
+    assert frame(hip, mv, pr) == frame(orc, mv, pr)
+    compare(hip, orc, 0.06)
+    for o in (hip, orc):
+        o.setSpaceSkip(False); o.setColorFilling(False)
+    frame(hip, mv, pr); frame(orc, mv, pr)
+    compare(hip, orc, 0.06)
+    for o in (hip, orc):
+        o.setUseBricks(False); o.setColorFilling(True)
+    frame(hip, mv, pr); frame(orc, mv, pr)
+    compare(hip, orc, 0.06)
+
+
+def test_set_brick_size_and_resize(rr, small_scene):
+    hip = rr.ReconIntegrationHip(small_scene, **KW)
+    mv, pr = rr.scene.default_view(*KW["view"])
+    frame(hip, mv, pr)
+    hip.setBrickSize([2.0 / 16, 2.2 / 16, 2.0 / 16])                    # setBrickSize -> divideBox (:462-472)
+    hip.resize(96, 64)                                                  # resize (:482-500)
+    kw = dict(KW, brick_size=[2.0 / 16, 2.2 / 16, 2.0 / 16], view=(96, 64))
+    orc = OracleRecon(small_scene, **kw)
+    assert hip.res_bricks == orc.res_bricks == (16, 16, 16) and hip.num_lods == orc.num_lods
+    mv, pr = rr.scene.default_view(96, 64)
+    assert frame(hip, mv, pr) == frame(orc, mv, pr)
+    assert compare(hip, orc) > 100
+
+
+def test_frame_sequence_resets_tiles_that_empty_out(rr):
+    """Three different frames through ONE context vs a fresh oracle per frame: tiles occupied in frame k but not in k+1
+    must read -limit again (the reference clears the whole volume every frame, recon_integration.cpp:249-250)."""
+    kw = dict(n_streams=3, width=128, height=96, lut_res=24, inv_res=32)
+    frames = [rr.scene.make_scene(**kw), rr.scene.make_scene(sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2), **kw),
+              rr.scene.make_scene(sphere_c=(-0.45, 1.5, 0.4), box_c=(0.2, 0.3, -0.6), **kw)]
+    hip = rr.ReconIntegrationHip(frames[0], **KW)
+    mv, pr = rr.scene.default_view(*KW["view"])
+    occupied = []
+    for sc in frames + [frames[0]]:
+        hip.upload_frame(sc)
+        orc = OracleRecon(sc, **KW)
+        assert frame(hip, mv, pr) == frame(orc, mv, pr)
+        compare(hip, orc)
+        occupied.append(set(np.flatnonzero(hip.bricks()[1])))
+    assert occupied[0] - occupied[1] and occupied[1] - occupied[2]      # bricks really do empty out between the frames
+    assert occupied[0] == occupied[3]
