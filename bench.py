@@ -32,6 +32,17 @@ CONFIGS = {
 VIEW = (1280, 720)
 LUT = 128
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")   # per-kernel HBM bytes from separate rocprofv3 --pmc passes
+
+
+def measured_traffic(config, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json, made by
+    profiles/summarize_pmc.py from FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections); None if absent."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            return json.load(f).get(config, {}).get(kernel, {}).get("hbm_bytes")
+    except (OSError, ValueError):
+        return None
 
 
 def algorithmic_bytes(cfg, n_streams, world):
@@ -116,6 +127,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # host -> device frame upload, outside the timed region (value = HBM-resident rate); reported for the PCIe-inclusive figure
+    hip.sync()
+    tu0 = time.perf_counter()
+    for _ in range(5):
+        hip.upload_frame(scene)
+    hip.sync()
+    upload_ms = (time.perf_counter() - tu0) / 5 * 1e3
     for _ in range(args.warmup):
         drv.frame(mv, pr)
     barrier()
@@ -149,14 +167,19 @@ def main():
                    "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio,
                    "parallelism": "single GPU" if world == 1 else f"{world} Z-slabs, RCCL halo all-gather + partial-image gather"},
         "stage_ms": stages,
+        "upload_ms_per_frame": upload_ms,
+        "pcie_inclusive_frames_per_s": 1e3 / (upload_ms + dt / args.steps * 1e3),
     }
     if "2integrate" in stages:
         dom = max((k for k in ("2integrate", "draw") if k in stages), key=lambda k: stages[k])
         key = "integrate" if dom == "2integrate" else "raymarch"
         ach = ab[key] / (stages[dom] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_integrate" if key == "integrate" else "k_raymarch",
+        kname = "k_integrate_tiles_lds" if key == "integrate" else "k_march+k_shade"
+        out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "algorithmic_bytes": ab[key], "avg_launch_ms": stages[dom]}
+                           "traffic": measured_traffic(args.config, kname), "algorithmic_bytes": ab[key], "avg_launch_ms": stages[dom],
+                           "note": "algorithmic bytes are the DENSE figures of BASELINE.md section 3; with brick culling the launch touches "
+                                   "only occupied tiles (occupied_brick_ratio), so achieved may exceed what HBM really moved (traffic)"}
         frame_bytes = ab["integrate"] + ab["raymarch"] + (ab["inpaint"] if cfg["fill_holes"] else 0)
         out["frame_roofline"] = {"algorithmic_bytes": frame_bytes, "achieved": frame_bytes / (dt / args.steps) / 1e9,
                                  "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}

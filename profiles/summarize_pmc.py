@@ -1,0 +1,41 @@
+"""profiles/traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (run on the GPU box, separate passes as
+MI355X_MICROARCH.md prescribes; both counters are in KiB).
+
+    python profiles/summarize_pmc.py <config> <fetch_counter_collection.csv> <write_counter_collection.csv>
+
+Corrections: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950 -> x2 (an upper bound for gathers);
+WRITE_SIZE is taken as is (calibration on this path: the dense c1 integrate writes 256^3 x 4 B = 67.1 MB and the counter
+reads 67.1 MB; a 512 MiB fill reads 524288 KiB)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+GROUPS = {"k_integrate_tiles_lds": ("k_integrate_tiles_lds",), "k_march+k_shade": ("k_march", "k_shade")}
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in agg.items()}     # steady-state launches
+
+
+def main():
+    cfg, fetch, write = sys.argv[1:4]
+    f, w = per_kernel(fetch), per_kernel(write)
+    out = {}
+    for name, parts in GROUPS.items():
+        fb = sum(v for k, v in f.items() if any(p in k for p in parts)) * 1024 * 2
+        wb = sum(v for k, v in w.items() if any(p in k for p in parts)) * 1024
+        out[name] = {"fetch_bytes_corrected": fb, "write_bytes_corrected": wb, "hbm_bytes": fb + wb}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[cfg] = out
+    json.dump(data, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
