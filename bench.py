@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"], help="N > 1: integrate the halo layers locally, or RCCL all-gather them")
+    ap.add_argument("--composite", default="compact", choices=["compact", "dense"], help="N > 1: gather hit records, or whole partial images")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true", help="leave the per-kernel HIP event timers off")
     args = ap.parse_args()
@@ -115,11 +117,12 @@ def main():
     ext = scene["bbox_max"] - scene["bbox_min"]
     brick = [float(ext[a]) / cfg["res"][a] * 8 for a in range(3)]          # 8^3 voxels per brick
     slab = mg.slab_range(cfg["res"][2], rank, world) if world > 1 else (0, 0)
-    hip = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, slab=slab)
+    hip = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, slab=slab,
+                                 recompute_halo=(args.halo == "recompute"))
     hip.setUseBricks(cfg["use_bricks"]); hip.setSpaceSkip(cfg["skip_space"]); hip.setColorFilling(cfg["fill_holes"])
     stream = torch.cuda.current_stream()
     hip.set_stream(stream.cuda_stream)         # kernels, HIP event timers and the collectives share one stream
-    drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW)
+    drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite)
     mv, pr = rr.scene.default_view(*VIEW)
 
     def barrier():
@@ -165,7 +168,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "config": args.config, "streams": cfg["streams"], "res": list(cfg["res"]),
                    "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio,
-                   "parallelism": "single GPU" if world == 1 else f"{world} Z-slabs, RCCL halo all-gather + partial-image gather"},
+                   "parallelism": "single GPU" if world == 1 else f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0"},
         "stage_ms": stages,
         "upload_ms_per_frame": upload_ms,
         "pcie_inclusive_frames_per_s": 1e3 / (upload_ms + dt / args.steps * 1e3),

@@ -57,6 +57,9 @@ typedef struct tsdf_config {
   /* multi-GPU Z-slab partition: this context owns voxel planes [slab_z0, slab_z1);
    * 0,0 = the whole volume.  Both must be multiples of 8 (storage tile) unless 0 / res_z. */
   uint32_t slab_z0, slab_z1;
+  /* 1: this context also integrates the halo tile layers next to its slab itself (voxels are independent in K1), so no
+   * halo exchange is needed before the raymarch; 0: the halo is filled by tsdf_halo_unpack_dev from the neighbours. */
+  uint32_t slab_recompute_halo;
 } tsdf_config;
 
 /* ---- lifetime / errors ------------------------------------------------------------------------- */
@@ -134,6 +137,11 @@ int32_t tsdf_halo_unpack_dev(tsdf_ctx* ctx, const void* below_dev, const void* a
 int32_t tsdf_export_partial_dev(tsdf_ctx* ctx, void* dst_dev);
 /* nearest-hit select over n gathered partial images into this context's raymarch target */
 int32_t tsdf_composite_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n);
+/* The same exchange in compact form: one 32-byte record {pixel, nsamples, depth, pad, rgba} per ray that hit inside this
+ * slab, behind a 32-byte header {count, overflow, ...}.  dst must hold 32 + 32 * capacity bytes. */
+int32_t tsdf_export_hits_dev(tsdf_ctx* ctx, void* dst_dev, uint32_t capacity);
+/* n record buffers, stride_bytes apart, composited into this context's raymarch target (rank 0) */
+int32_t tsdf_composite_hits_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n, uint64_t stride_bytes);
 
 /* ---- timers: the reference's TimerDatabase names: "2integrate", "3recon", "draw",
  * "holefill", "brickdraw", plus "bricks" (clear + mark + update).

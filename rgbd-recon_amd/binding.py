@@ -33,7 +33,7 @@ class TsdfConfig(C.Structure):
                 ("voxel_size", C.c_float), ("res", C.c_uint32 * 3), ("brick_size", C.c_float * 3),
                 ("limit", C.c_float), ("num_streams", C.c_uint32), ("depth_w", C.c_uint32), ("depth_h", C.c_uint32),
                 ("color_w", C.c_uint32), ("color_h", C.c_uint32), ("view_w", C.c_uint32), ("view_h", C.c_uint32),
-                ("device", C.c_int32), ("slab_z0", C.c_uint32), ("slab_z1", C.c_uint32)]
+                ("device", C.c_int32), ("slab_z0", C.c_uint32), ("slab_z1", C.c_uint32), ("slab_recompute_halo", C.c_uint32)]
 
 
 def build_library():
@@ -76,7 +76,7 @@ class ReconIntegrationHip:
     NetKinectArray hold in the reference (rgbd-recon_amd/scene.py layout)."""
 
     def __init__(self, scene, res=None, voxel_size=0.01, brick_size=0.1, limit=0.01, view=(1280, 720),
-                 device=0, slab=(0, 0), upload=True):
+                 device=0, slab=(0, 0), upload=True, recompute_halo=False):
         self._L = load_library()
         self._c = None
         cfg = TsdfConfig()
@@ -93,6 +93,7 @@ class ReconIntegrationHip:
         cfg.view_w, cfg.view_h = view
         cfg.device = device
         cfg.slab_z0, cfg.slab_z1 = slab
+        cfg.slab_recompute_halo = int(bool(recompute_halo))
         ctx = C.c_void_p()
         rc = self._L.tsdf_create(C.byref(cfg), C.byref(ctx))
         if rc != 0:
@@ -263,6 +264,12 @@ class ReconIntegrationHip:
 
     def export_partial_dev(self, dst_ptr):
         self._ck(self._L.tsdf_export_partial_dev(self._c, C.c_void_p(dst_ptr)))
+
+    def export_hits_dev(self, dst_ptr, capacity):
+        self._ck(self._L.tsdf_export_hits_dev(self._c, C.c_void_p(dst_ptr), C.c_uint32(capacity)))
+
+    def composite_hits_dev(self, gathered_ptr, n, stride_bytes):
+        self._ck(self._L.tsdf_composite_hits_dev(self._c, C.c_void_p(gathered_ptr), C.c_uint32(n), C.c_uint64(stride_bytes)))
 
     def composite_dev(self, gathered_ptr, n):
         self._ck(self._L.tsdf_composite_dev(self._c, C.c_void_p(gathered_ptr), int(n)))

@@ -63,7 +63,8 @@ struct tsdf_ctx {
   int vw = 0, vh = 0;
   Atlas atlas{};
   float4* d_peels = nullptr; float* d_nsamples = nullptr;
-  void* d_hits = nullptr; uint32_t* d_hit_counters = nullptr; int hit_parity = 0;   // raymarch hit list (k_march -> k_shade)
+  void* d_hits = nullptr; uint32_t* d_hit_counters = nullptr; int hit_parity = 0;
+  unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
   float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
   float* d_linear = nullptr;     // scratch for volume up/download
   // flags (recon_integration.cpp:54-57)
@@ -114,7 +115,7 @@ Mat4 to_mat4(const double* d) { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (f
 
 void release_view(tsdf_ctx* c) {
   hipFree(c->atlas.color); hipFree(c->atlas.depth); hipFree(c->d_peels); hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
-  hipFree(c->d_hits); hipFree(c->d_hit_counters); c->d_hits = nullptr; c->d_hit_counters = nullptr;
+  hipFree(c->d_hits); hipFree(c->d_hit_counters); hipFree(c->d_comp_key); c->d_hits = nullptr; c->d_hit_counters = nullptr; c->d_comp_key = nullptr;
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
 void release_bricks(tsdf_ctx* c) {
@@ -369,6 +370,9 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   V.tz0 = whole ? 0 : std::max(0, V.own_tz0 - c->halo_layers);
   V.tz1 = whole ? ntz : std::min(ntz, V.own_tz1 + c->halo_layers);
   V.zlo = V.tz0 * 8; V.zhi = std::min(V.tz1 * 8, c->res[2]) - 1;
+  const bool recompute = !whole && cfg->slab_recompute_halo != 0;
+  V.int_tz0 = recompute ? V.tz0 : V.own_tz0;
+  V.int_tz1 = recompute ? V.tz1 : V.own_tz1;
   if (!whole && V.own_tz1 - V.own_tz0 < c->halo_layers) { c->err = "slab thinner than its halo"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
   const size_t nvox = (size_t)(V.tz1 - V.tz0) * V.nty * V.ntx * TILE_VOX;
   int32_t rc;
@@ -380,7 +384,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if ((rc = tryhip(hipMalloc(&V.data, nvox * sizeof(float)), "hipMalloc(volume)"))) return fail(rc);
   launch_fill_u32(c->stream, (uint32_t*)V.data, 0u, nvox);
   TileState& S = c->tiles;
-  S.n = (V.own_tz1 - V.own_tz0) * V.nty * V.ntx;
+  S.n = (V.int_tz1 - V.int_tz0) * V.nty * V.ntx;
   if ((rc = tryhip(hipMalloc(&S.active, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
   V.n_stored_tiles = (V.tz1 - V.tz0) * V.nty * V.ntx;
   if ((rc = tryhip(hipMalloc(&c->d_cls_all, (size_t)V.n_stored_tiles), "hipMalloc(tiles)"))) return fail(rc);
@@ -399,7 +403,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
     if ((rc = tryhip(hipMalloc(&c->d_pyr, (size_t)words * sizeof(uint32_t)), "hipMalloc(pyramid)"))) return fail(rc);
     V.pyr = c->d_pyr;
   }
-  S.cls = c->d_cls_all + (size_t)(V.own_tz0 - V.tz0) * V.nty * V.ntx;
+  S.cls = c->d_cls_all + (size_t)(V.int_tz0 - V.tz0) * V.nty * V.ntx;
   if ((rc = tryhip(hipMalloc(&S.list, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
   hipMemsetAsync(S.active, 0, (size_t)S.n, c->stream);
   if ((rc = tryhip(hipHostMalloc((void**)&c->h_num_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc"))) return fail(rc);
@@ -803,6 +807,25 @@ int32_t tsdf_composite_dev(tsdf_ctx* c, const void* gathered, uint32_t n) {
   if (!gathered || n < 1) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
   launch_composite(c->stream, gathered, (int)n, ray_target(c), c->vw, c->vh);
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+
+int32_t tsdf_export_hits_dev(tsdf_ctx* c, void* dst, uint32_t capacity) {
+  CHECK_CTX(c);
+  if (!dst || capacity < 1) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  // the raymarch that just ran used counter (hit_parity ^ 1): raymarch_impl flips the parity after its launch
+  launch_export_hits(c->stream, ray_target(c), c->vw, c->d_hits, c->d_hit_counters + (c->hit_parity ^ 1), dst, capacity);
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+int32_t tsdf_composite_hits_dev(tsdf_ctx* c, const void* gathered, uint32_t n, uint64_t stride_bytes) {
+  CHECK_CTX(c);
+  if (!gathered || n < 1 || n > 32 || stride_bytes < 32) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->d_comp_key) HIP_TRY(c, hipMalloc(&c->d_comp_key, (size_t)c->vw * c->vh * sizeof(unsigned long long)));
+  launch_composite_hits(c->stream, gathered, (size_t)stride_bytes, (int)n, ray_target(c), c->vw, c->vh, c->d_comp_key);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
 }

@@ -55,7 +55,7 @@ __device__ __forceinline__ bool voxel_drawn(const Bricks& B, int x, int y, int z
 }
 
 __device__ __forceinline__ void tile_coords(const Volume& V, int tile, int& tx, int& ty, int& tz) {
-  tx = tile % V.ntx; ty = (tile / V.ntx) % V.nty; tz = V.own_tz0 + tile / (V.ntx * V.nty);
+  tx = tile % V.ntx; ty = (tile / V.ntx) % V.nty; tz = V.int_tz0 + tile / (V.ntx * V.nty);
 }
 
 // One lane per owned tile: is any occupied brick among those whose voxel lists can reach into the tile?  Active tiles go

@@ -397,6 +397,17 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   bool hit = false;
   float3 hit_pos = pos;
   float hit_d = 0.0f;
+  if (partial) {
+    // Slab mode: ownership is by voxel plane and z is monotonic along the ray, so this rank's samples form ONE contiguous
+    // run.  Samples before it cost only the reference's `pos += step`; the run ends the march (a miss reports max_n, which
+    // every rank computes identically).
+    while (n < max_n && !sample_owned(V, pos.z)) {
+      pos_prev = pos;
+      pos = make_float3(pos.x + step.x, pos.y + step.y, pos.z + step.z);
+      n += 1;
+      prev_valid = false;
+    }
+  }
   while (n < max_n && !hit) {
     if (try_skip) {
       uint32_t cnt = empty_run(V, s_pyr, pos, dq);
@@ -449,6 +460,7 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
     }
     try_skip = kUseSkip && all_minus;
     if (!hit) pos = make_float3(p[kBatch - 1].x + step.x, p[kBatch - 1].y + step.y, p[kBatch - 1].z + step.z);
+    if (partial && !hit && !prev_valid) { n = max_n; break; }          // the batch ended outside the slab: nothing further is ours
   }
   if (hit) {                                                            // approximate ray-cell intersection, :99-101
     if (partial && !prev_valid) prev = tex3d_tsdf(V, pos_prev.x, pos_prev.y, pos_prev.z);   // sample n-1 is a neighbour's: read it from the halo
@@ -573,6 +585,78 @@ __global__ __launch_bounds__(256) void k_composite(const char* __restrict__ g, i
 void launch_composite(hipStream_t st, const void* gathered, int n, const RayTarget& R, int w, int h) {
   const size_t np = (size_t)w * h;
   hipLaunchKernelGGL(k_composite, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, (const char*)gathered, n, R, w, h);
+}
+
+}  // namespace rr
+
+namespace rr {
+
+// ---- compact exchange: instead of 24 B for every view pixel, a slab ships one 32-byte record per ray that hit in it
+struct HitRecord { uint32_t pix; float ns; float depth; uint32_t pad; float4 color; };
+static_assert(sizeof(HitRecord) == 32, "HitRecord is 32 bytes");
+// buffer = [count, overflow, 6 pad words][records...]
+__global__ __launch_bounds__(256) void k_export_hits(RayTarget R, int w, const Hit* __restrict__ hits, const uint32_t* __restrict__ hit_count,
+                                                     uint32_t* __restrict__ header, HitRecord* __restrict__ rec, uint32_t capacity) {
+  const uint32_t n_hits = *hit_count, n = n_hits < capacity ? n_hits : capacity;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { header[0] = n; header[1] = n_hits > capacity ? 1u : 0u; }
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t pix = hits[i].pix;
+    const int px = (int)(pix % (uint32_t)w), py = (int)(pix / (uint32_t)w);
+    HitRecord r;
+    r.pix = pix; r.ns = R.nsamples[pix]; r.depth = R.depth[(size_t)py * R.stride + px]; r.pad = 0u;
+    r.color = R.color[(size_t)py * R.stride + px];
+    rec[i] = r;
+  }
+}
+void launch_export_hits(hipStream_t st, const RayTarget& R, int w, const void* hit_list, const uint32_t* hit_count, void* dst, uint32_t capacity) {
+  hipLaunchKernelGGL(k_export_hits, dim3(512), dim3(256), 0, st, R, w, (const Hit*)hit_list, hit_count, (uint32_t*)dst, (HitRecord*)((char*)dst + 32), capacity);
+}
+
+// composite on the gathering rank: (1) every pixel starts as "no rank hit" (clear colour, depth 1, the common miss count),
+// (2) every record bids for its pixel with the key (sample count, rank, index) -- the smallest sample count is the first zero
+// crossing along the ray --, (3) the winning record writes the pixel.
+__global__ __launch_bounds__(256) void k_comp_init(RayTarget R, int w, int h, unsigned long long* __restrict__ key) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const int x = i % w, y = i / w;
+  R.color[(size_t)y * R.stride + x] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
+  R.depth[(size_t)y * R.stride + x] = 1.0f;
+  R.nsamples[i] = fabsf(R.nsamples[i]);             // misses carry -count in slab mode; a hit pixel is overwritten in (3)
+  key[i] = ~0ull;
+}
+__device__ __forceinline__ unsigned long long hit_key(float ns, uint32_t rank, uint32_t idx) {
+  return ((unsigned long long)__float_as_uint(ns) << 32) | ((unsigned long long)rank << 27) | idx;
+}
+__global__ __launch_bounds__(256) void k_comp_bid(const char* __restrict__ g, size_t stride_bytes, int n_ranks, unsigned long long* __restrict__ key) {
+  const int r = blockIdx.y;
+  if (r >= n_ranks) return;
+  const uint32_t* header = (const uint32_t*)(g + (size_t)r * stride_bytes);
+  const HitRecord* rec = (const HitRecord*)(g + (size_t)r * stride_bytes + 32);
+  const uint32_t n = header[0];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (rec[i].ns > 0.0f) atomicMin(&key[rec[i].pix], hit_key(rec[i].ns, (uint32_t)r, i));
+}
+__global__ __launch_bounds__(256) void k_comp_write(const char* __restrict__ g, size_t stride_bytes, int n_ranks, const unsigned long long* __restrict__ key,
+                                                    RayTarget R, int w) {
+  const int r = blockIdx.y;
+  if (r >= n_ranks) return;
+  const uint32_t* header = (const uint32_t*)(g + (size_t)r * stride_bytes);
+  const HitRecord* rec = (const HitRecord*)(g + (size_t)r * stride_bytes + 32);
+  const uint32_t n = header[0];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const HitRecord h = rec[i];
+    if (!(h.ns > 0.0f) || key[h.pix] != hit_key(h.ns, (uint32_t)r, i)) continue;
+    const int x = (int)(h.pix % (uint32_t)w), y = (int)(h.pix / (uint32_t)w);
+    R.color[(size_t)y * R.stride + x] = h.color;
+    R.depth[(size_t)y * R.stride + x] = h.depth;
+    R.nsamples[h.pix] = h.ns;
+  }
+}
+void launch_composite_hits(hipStream_t st, const void* gathered, size_t stride_bytes, int n, const RayTarget& R, int w, int h, unsigned long long* key) {
+  const int np = w * h;
+  hipLaunchKernelGGL(k_comp_init, dim3((np + 255) / 256), dim3(256), 0, st, R, w, h, key);
+  hipLaunchKernelGGL(k_comp_bid, dim3(128, n), dim3(256), 0, st, (const char*)gathered, stride_bytes, n, key);
+  hipLaunchKernelGGL(k_comp_write, dim3(128, n), dim3(256), 0, st, (const char*)gathered, stride_bytes, n, key, R, w);
 }
 
 }  // namespace rr

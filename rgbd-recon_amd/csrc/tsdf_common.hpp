@@ -37,7 +37,8 @@ struct Volume {
   int res[3];          // logical resolution
   int ntx, nty;        // tiles per axis (x, y); z tiles stored: [tz0, tz1)
   int tz0, tz1;        // stored tile layers (owned slab + halo)
-  int own_tz0, own_tz1;  // owned tile layers (integrated by this context)
+  int own_tz0, own_tz1;  // owned tile layers: the samples of the raymarch this context is responsible for
+  int int_tz0, int_tz1;  // tile layers integrate() computes: the owned ones, plus the halo when it is recomputed locally
   int zlo, zhi;        // stored voxel planes [zlo, zhi]: every Z tap is clamped into them (slab contexts)
   const uint8_t* cls;  // tile class of every STORED tile, index ((tz - tz0) * nty + ty) * ntx + tx; halo layers stay kTileMixed
   int n_stored_tiles;
@@ -49,7 +50,7 @@ struct Volume {
   float limit;
 };
 
-// Per-tile bookkeeping of the owned tiles (index = owned tile id, x fastest, own_tz0 first):
+// Per-tile bookkeeping of the integrated tiles (index = tile id, x fastest, int_tz0 first):
 //   active  this frame: some voxel of the tile is in the voxel list of an occupied brick
 //   cls     what the tile's 2 KiB in HBM hold: 0 = every voxel is -limit (the clear value), 1 = every voxel is +limit,
 //           2 = anything else / unknown
@@ -132,5 +133,7 @@ void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_c
 void launch_clear_image(hipStream_t st, float4* color, float* depth, size_t n, float4 c, float d);
 void launch_export_partial(hipStream_t st, const RayTarget& R, int w, int h, void* dst);
 void launch_composite(hipStream_t st, const void* gathered, int n, const RayTarget& R, int w, int h);
+void launch_export_hits(hipStream_t st, const RayTarget& R, int w, const void* hit_list, const uint32_t* hit_count, void* dst, uint32_t capacity);
+void launch_composite_hits(hipStream_t st, const void* gathered, size_t stride_bytes, int n, const RayTarget& R, int w, int h, unsigned long long* key);
 
 }  // namespace rr

@@ -43,6 +43,7 @@ struct ReconInputs {
   int device = 0;
   std::array<unsigned, 3> explicit_res{{0, 0, 0}};    // 0: res = ceil(bbox / voxel_size) like setVoxelSize()
   unsigned slab_z0 = 0, slab_z1 = 0;                  // multi-GPU Z-slab (0,0 = whole volume)
+  bool slab_recompute_halo = false;                   // integrate the halo layers locally instead of exchanging them
 };
 
 class ReconIntegrationHip {
@@ -62,6 +63,7 @@ class ReconIntegrationHip {
     cfg.view_w = (uint32_t)width; cfg.view_h = (uint32_t)height;
     cfg.device = in.device;
     cfg.slab_z0 = in.slab_z0; cfg.slab_z1 = in.slab_z1;
+    cfg.slab_recompute_halo = in.slab_recompute_halo ? 1u : 0u;
     if (tsdf_create(&cfg, &m_ctx) != TSDF_OK) throw std::runtime_error(std::string("ReconIntegrationHip: ") + tsdf_last_error(nullptr));
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::memcpy(m_mv, id, sizeof(id));

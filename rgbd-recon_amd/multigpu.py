@@ -6,11 +6,14 @@ no multi-GPU path at all; what is partitioned here is the reference's single vol
   * K1 (integrate) shards by voxels: rank g owns Z planes [z0_g, z1_g) -- no communication.
   * brick occupancy (K6) is replicated: every rank marks all bricks from the (replicated) frame images;
     2 atomics per depth pixel are cheaper than any collective.
-  * K2 needs ONE exchange before it: trilinear + gradient taps reach across a slab face, so each rank's
-    boundary tile layers are all-gathered and the two neighbours' faces land in the local halo.
+  * K2 needs the voxels just across a slab face (trilinear + gradient taps).  Either each rank's boundary tile layers
+    are all-gathered and the neighbours' faces land in the local halo (halo="exchange"), or every rank simply integrates
+    its halo layers itself (halo="recompute": K1's voxels are independent, one extra tile layer per face costs less than
+    any collective).
   * every rank steps the SAME global ray (identical fp32 position sequence) and samples only the
-    positions inside its slab; the partial images are gathered on rank 0 and the hit with the smallest
-    sample count wins, which is exactly the single-GPU first zero crossing.
+    positions inside its slab; the partial results are gathered on rank 0 -- as full images (composite="dense") or as
+    one 32-byte record per hit ray (composite="compact") -- and the hit with the smallest sample count wins, which is
+    exactly the single-GPU first zero crossing.
   * K3/K4 (hole filling) are image space and tiny: rank 0 only.
 
 The exchange works on plain device pointers across the C ABI (tsdf_halo_*_dev, tsdf_export_partial_dev,
@@ -34,23 +37,36 @@ def slab_range(res_z: int, rank: int, world: int):
 class SlabDriver:
     """Runs the per-frame call order of source/kinect_client.cpp:569-599,614 on one slab.
 
-    `backend` is a ReconIntegrationHip created with slab=slab_range(...) (tests inject an oracle-backed fake
-    with the same hook methods).  `buf_device` is where exchange buffers live ("cuda:N"; "cpu" for the fake);
-    with a gloo group and CUDA buffers the collective is staged through host memory.
+    `backend` is a ReconIntegrationHip created with slab=slab_range(...) (tests inject a stand-in with the same hook
+    methods).  `buf_device` is where exchange buffers live ("cuda:N"; "cpu" for the stand-in); with a gloo group and
+    CUDA buffers the collective is staged through host memory.
+
+    halo       "exchange": all-gather of the boundary tile layers before the raymarch (the backend must NOT have been
+               created with recompute_halo); "recompute": the backend integrates its own halo layers, no collective.
+    composite  "dense": every rank ships 24 B per view pixel to rank 0; "compact": one 32-byte record per ray that hit in
+               the slab (the counts travel first so that only max(count) records per rank are gathered).
     """
 
-    def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720)):
+    def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense"):
+        assert halo in ("exchange", "recompute") and composite in ("dense", "compact")
         self.b, self.rank, self.world, self.dev, self.group = backend, rank, world, torch.device(buf_device), group
-        self.view = view
+        self.view, self.halo, self.composite = view, halo, composite
         self.stage_cpu = world > 1 and dist.get_backend(group) == "gloo" and self.dev.type == "cuda"
         if world > 1:
-            layers, nbytes = backend.halo_info()
-            n = nbytes // 4
-            self.send = torch.empty((2, n), dtype=torch.float32, device=self.dev)
-            self.gath = torch.empty((world, 2, n), dtype=torch.float32, device=self.dev)
             npx = view[0] * view[1]
-            self.part = torch.empty(npx * 6, dtype=torch.float32, device=self.dev)          # 24 B / pixel
-            self.parts = torch.empty((world, npx * 6), dtype=torch.float32, device=self.dev) if rank == 0 else None
+            if halo == "exchange":
+                layers, nbytes = backend.halo_info()
+                n = nbytes // 4
+                self.send = torch.empty((2, n), dtype=torch.float32, device=self.dev)
+                self.gath = torch.empty((world, 2, n), dtype=torch.float32, device=self.dev)
+            if composite == "dense":
+                self.part = torch.empty(npx * 6, dtype=torch.float32, device=self.dev)          # 24 B / pixel
+                self.parts = torch.empty((world, npx * 6), dtype=torch.float32, device=self.dev) if rank == 0 else None
+            else:
+                self.cap = npx                                                                   # a slab cannot hit more rays than there are pixels
+                self.hitbuf = torch.zeros(8 + npx * 8, dtype=torch.float32, device=self.dev)     # 32 B header + 32 B records
+                self.hitparts = torch.zeros((world, 8 + npx * 8), dtype=torch.float32, device=self.dev) if rank == 0 else None
+                self.counts = torch.zeros((world, 2), dtype=torch.int32, device=self.dev)
 
     def _all_gather(self, out, inp):
         if self.stage_cpu:
@@ -60,15 +76,16 @@ class SlabDriver:
         else:
             dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
 
-    def _gather0(self, out, inp):
+    def _gather0(self, out_rows, inp):
+        """gather `inp` (1-D) of every rank into out_rows[r] (1-D views of equal length) on rank 0"""
         if self.stage_cpu:
             lst = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(self.world)] if self.rank == 0 else None
             dist.gather(inp.cpu(), lst, dst=0, group=self.group)
             if self.rank == 0:
-                out.copy_(torch.stack(lst))
+                for row, t in zip(out_rows, lst):
+                    row.copy_(t)
         else:
-            lst = list(out.unbind(0)) if self.rank == 0 else None
-            dist.gather(inp, lst, dst=0, group=self.group)
+            dist.gather(inp, out_rows if self.rank == 0 else None, dst=0, group=self.group)
 
     def exchange_halo(self):
         b = self.b
@@ -87,37 +104,56 @@ class SlabDriver:
         if self.world == 1:
             b.drawF(mv, proj)
             return
-        self.exchange_halo()
+        if self.halo == "exchange":
+            self.exchange_halo()
         b.draw(mv, proj)
-        b.export_partial_dev(self.part.data_ptr())
-        self._gather0(self.parts, self.part)
+        if self.composite == "dense":
+            b.export_partial_dev(self.part.data_ptr())
+            self._gather0(list(self.parts.unbind(0)) if self.rank == 0 else None, self.part)
+            if self.rank == 0:
+                b.composite_dev(self.parts.data_ptr(), self.world)
+                b.fillColors()
+            return
+        b.export_hits_dev(self.hitbuf.data_ptr(), self.cap)
+        self._all_gather(self.counts, self.hitbuf[:2].view(torch.int32))
+        m = int(self.counts[:, 0].max().item())                        # the one host synchronisation of the exchange
+        n = 8 + m * 8
+        self._gather0([self.hitparts[r, :n] for r in range(self.world)] if self.rank == 0 else None, self.hitbuf[:n])
         if self.rank == 0:
-            b.composite_dev(self.parts.data_ptr(), self.world)
+            b.composite_hits_dev(self.hitparts.data_ptr(), self.world, self.hitparts.stride(0) * 4)
             b.fillColors()
 
 
-def frame_slabs_on_one_device(backends, mv, proj, device):
+def frame_slabs_on_one_device(backends, mv, proj, device, halo="exchange", composite="dense"):
     """The same partition with ONE visible device (SURVEY.md §8e fallback): the slabs run one after another and the
     "collectives" are device-to-device copies.  Used to check slab results against the unpartitioned volume on a 1-GPU box.
     backends[k] owns slab k; the composite lands in backends[0]."""
     world = len(backends)
-    layers, nbytes = backends[0].halo_info()
-    n = nbytes // 4
-    faces = torch.empty((world, 2, n), dtype=torch.float32, device=device)
     npx = backends[0].view[0] * backends[0].view[1]
-    parts = torch.empty((world, npx * 6), dtype=torch.float32, device=device)
+    if halo == "exchange":
+        layers, nbytes = backends[0].halo_info()
+        faces = torch.empty((world, 2, nbytes // 4), dtype=torch.float32, device=device)
     for k, b in enumerate(backends):
         b.clearOccupiedBricks(); b.markBricks(); b.updateOccupiedBricks(False)
         b.integrate()
-        b.halo_pack_dev(faces[k, 0].data_ptr(), faces[k, 1].data_ptr())
+        if halo == "exchange":
+            b.halo_pack_dev(faces[k, 0].data_ptr(), faces[k, 1].data_ptr())
         b.sync()
+    parts = torch.zeros((world, npx * 6 if composite == "dense" else 8 + npx * 8), dtype=torch.float32, device=device)
     for k, b in enumerate(backends):
-        below = faces[k - 1, 1].data_ptr() if k > 0 else 0
-        above = faces[k + 1, 0].data_ptr() if k < world - 1 else 0
-        b.halo_unpack_dev(below, above)
+        if halo == "exchange":
+            below = faces[k - 1, 1].data_ptr() if k > 0 else 0
+            above = faces[k + 1, 0].data_ptr() if k < world - 1 else 0
+            b.halo_unpack_dev(below, above)
         b.draw(mv, proj)
-        b.export_partial_dev(parts[k].data_ptr())
+        if composite == "dense":
+            b.export_partial_dev(parts[k].data_ptr())
+        else:
+            b.export_hits_dev(parts[k].data_ptr(), npx)
         b.sync()
-    backends[0].composite_dev(parts.data_ptr(), world)
+    if composite == "dense":
+        backends[0].composite_dev(parts.data_ptr(), world)
+    else:
+        backends[0].composite_hits_dev(parts.data_ptr(), world, parts.stride(0) * 4)
     backends[0].fillColors()
     backends[0].sync()

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 KW = dict(res=(64, 64, 64), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(160, 90))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, halo, composite):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
@@ -24,9 +24,9 @@ def _worker(rank, world, port, q):
         torch.cuda.set_device(0)
         scene = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
         mv, pr = rr.scene.default_view(*KW["view"])
-        hip = rr.ReconIntegrationHip(scene, slab=mgpu.slab_range(KW["res"][2], rank, world), **KW)
+        hip = rr.ReconIntegrationHip(scene, slab=mgpu.slab_range(KW["res"][2], rank, world), recompute_halo=(halo == "recompute"), **KW)
         hip.set_stream(torch.cuda.current_stream().cuda_stream)
-        drv = mgpu.SlabDriver(hip, rank, world, "cuda:0", view=KW["view"])
+        drv = mgpu.SlabDriver(hip, rank, world, "cuda:0", view=KW["view"], halo=halo, composite=composite)
         for _ in range(2):                       # two frames: buffers are reused
             drv.frame(mv, pr)
         torch.cuda.synchronize()
@@ -47,12 +47,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_slab_driver_matches_single_context():
+@pytest.mark.parametrize("halo,composite", [("exchange", "dense"), ("recompute", "compact")])
+def test_two_rank_slab_driver_matches_single_context(halo, composite):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, halo, composite)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -183,8 +183,9 @@ def test_errors_are_codes_not_crashes(rr, small_scene):
         hip.setShadeMode(7)
 
 
+@pytest.mark.parametrize("halo,composite", [("exchange", "dense"), ("recompute", "compact"), ("exchange", "compact")])
 @pytest.mark.parametrize("world", [2, 4])
-def test_slab_partition_equals_whole_volume_bit_for_bit(rr, small_scene, world):
+def test_slab_partition_equals_whole_volume_bit_for_bit(rr, small_scene, world, halo, composite):
     """Z-slabs + halo exchange + nearest-hit composite reproduce the single-volume frame exactly
     (the slabs run sequentially on the one GPU of this box; the exchange hooks are the ones the RCCL driver uses)."""
     import torch
@@ -196,8 +197,8 @@ def test_slab_partition_equals_whole_volume_bit_for_bit(rr, small_scene, world):
     run_bricks(whole)
     whole.integrate()
     whole.drawF(mv, pr)
-    slabs = [rr.ReconIntegrationHip(small_scene, slab=mgpu.slab_range(RES[2], k, world), **kw) for k in range(world)]
-    mgpu.frame_slabs_on_one_device(slabs, mv, pr, "cuda:0")
+    slabs = [rr.ReconIntegrationHip(small_scene, slab=mgpu.slab_range(RES[2], k, world), recompute_halo=(halo == "recompute"), **kw) for k in range(world)]
+    mgpu.frame_slabs_on_one_device(slabs, mv, pr, "cuda:0", halo=halo, composite=composite)
     # each slab holds exactly its planes of the whole volume
     ref = whole.tsdf()
     for k, s in enumerate(slabs):
