@@ -46,10 +46,12 @@ def _worker(rank, world, port, q, halo, composite):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(1200)
 @pytest.mark.parametrize("halo,composite", [("exchange", "dense"), ("recompute", "compact")])
 def test_two_rank_slab_driver_matches_single_context(halo, composite):
+    import torch                     # first import on a fresh box takes minutes: pay it here, not in both children at once
     import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -57,6 +59,6 @@ def test_two_rank_slab_driver_matches_single_context(halo, composite):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(240)
+        p.join(900)
         assert p.exitcode == 0
     assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}

@@ -118,7 +118,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(120)
+@pytest.mark.timeout(900)
 def test_slab_driver_world_size_2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -127,7 +127,7 @@ def test_slab_driver_world_size_2_gloo():
     for p in procs:
         p.start()
     for p in procs:
-        p.join(100)
+        p.join(600)
         assert p.exitcode == 0
     got = dict(q.get(timeout=5) for _ in range(2))
     assert got == {0: True, 1: True}
