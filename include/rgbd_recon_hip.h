@@ -84,6 +84,21 @@ int32_t tsdf_set_calibration(tsdf_ctx* ctx, uint32_t stream,
 int32_t tsdf_upload_frame(tsdf_ctx* ctx, const float* depth_rg, const float* quality,
                           const float* silhouette, const uint8_t* colour_rgb);
 
+/* ---- image pre-processing: NetKinectArray::processTextures(), framework/NetKinectArray.cpp:309-426
+ * Alternative to tsdf_upload_frame: hand over the RAW sensor frame (m_depthArray_raw R32F metres [N][H][W], colour RGB8,
+ * NetKinectArray.cpp:147-176) and let tsdf_process_textures produce depth / quality / silhouette (and normals, Lab colour)
+ * with the reference's passes: pre_morph.fs (3x3 dilate), pre_depth.fs (13x13 bilateral + RGB->Lab), pre_boundary.fs,
+ * pre_normal.fs (which also calls mark_brick(): call it between tsdf_clear_bricks and tsdf_update_occupied, like
+ * process_textures() in source/kinect_client.cpp:569-577, and do NOT call tsdf_mark_bricks as well), pre_quality.fs. */
+int32_t tsdf_upload_raw_frame(tsdf_ctx* ctx, const float* depth_raw_m, const uint8_t* colour_rgb);
+int32_t tsdf_set_depth_limits(tsdf_ctx* ctx, uint32_t stream, float cv_min_d, float cv_max_d);   /* CalibVolumes::getDepthLimits, CalibVolumes.cpp:91-93 */
+int32_t tsdf_set_camera_position(tsdf_ctx* ctx, uint32_t stream, const float xyz[3]);            /* CalibVolumes::getCameraPositions, :224-230 */
+/* filterTextures / useProcessedDepths / refineBoundary, NetKinectArray.cpp:466-480 (all default true, :63-69) */
+int32_t tsdf_set_preprocess(tsdf_ctx* ctx, int32_t filter_textures, int32_t processed_depth, int32_t refine_boundary);
+int32_t tsdf_process_textures(tsdf_ctx* ctx);
+/* products, any pointer may be NULL: depth2 [N][H][W], depth_rg [..][2], lab [..][3], depth_b [..][2], silhouette, normals [..][3], quality */
+int32_t tsdf_download_preprocessed(tsdf_ctx* ctx, float* depth2, float* depth_rg, float* lab, float* depth_b, float* silhouette, float* normals, float* quality);
+
 /* ---- brick occupancy: clearOccupiedBricks / mark_brick / updateOccupiedBricks -------------------- */
 int32_t tsdf_clear_bricks(tsdf_ctx* ctx);                       /* recon_integration.cpp:271-277 */
 int32_t tsdf_mark_bricks(tsdf_ctx* ctx);                        /* pre_normal.fs:22-33 -> inc_bricks.glsl:40-58 */

@@ -116,6 +116,29 @@ class OracleRecon:
     def updateOccupiedBricks(self): return self._L.orc_update_occupied(self._c)
     def integrate(self): self._L.orc_integrate(self._c)
 
+    # --- NetKinectArray side (framework/NetKinectArray.cpp): raw frame -> processTextures()
+    def upload_raw_frame(self, scene):
+        raw, col = _f32(scene["depth_raw"]), np.ascontiguousarray(scene["color"], np.uint8)
+        self._raw = (raw, col)
+        self._L.orc_set_raw_frame(self._c, _p(raw), _p(col, C.c_uint8))
+        for i in range(scene["n"]):
+            self._L.orc_set_depth_limits(self._c, i, C.c_float(float(scene["depth_limits"][0])), C.c_float(float(scene["depth_limits"][1])))
+            self._L.orc_set_camera_position(self._c, i, _p(_f32(scene["camera_positions"][i])))
+
+    def setPreprocess(self, filter_textures=True, processed_depth=True, refine=True):
+        self._L.orc_set_preprocess_flags(self._c, int(filter_textures), int(processed_depth), int(refine))
+
+    def processTextures(self): self._L.orc_process_textures(self._c)
+
+    def preprocessed(self):
+        n, h, w = self.scene["n"], self.scene["height"], self.scene["width"]
+        out = dict(depth2=np.zeros((n, h, w), np.float32), depth_rg=np.zeros((n, h, w, 2), np.float32), lab=np.zeros((n, h, w, 3), np.float32),
+                   depth_b=np.zeros((n, h, w, 2), np.float32), silhouette=np.zeros((n, h, w), np.float32),
+                   normals=np.zeros((n, h, w, 3), np.float32), quality=np.zeros((n, h, w), np.float32))
+        self._L.orc_get_preprocessed(self._c, _p(out["depth2"]), _p(out["depth_rg"]), _p(out["lab"]), _p(out["depth_b"]), _p(out["silhouette"]),
+                                     _p(out["normals"]), _p(out["quality"]))
+        return out
+
     def draw(self, mv, proj):
         self._L.orc_draw(self._c, _p(_f32(mv)), _p(_f32(proj)))
 

@@ -177,6 +177,12 @@ struct orc_ctx {
   const float* xyz[16] = {};     uint32_t xyz_res[16][3];
   const float *depth = nullptr, *quality = nullptr, *silhouette = nullptr;
   const uint8_t* color = nullptr;
+  // pre-processing (NetKinectArray::processTextures, framework/NetKinectArray.cpp:309-426): raw inputs, flags, products
+  const float* raw_depth = nullptr;                    // [N][H][W] metres (m_depthArray_raw, R32F, NEAREST)
+  float cv_min_d[16], cv_max_d[16];                    // CalibVolumes::getDepthLimits(i)
+  vec3 cam_pos[16];                                    // CalibVolumes::getCameraPositions()
+  bool filter_textures = true, use_processed_depth = true, refine_bound = true;   // NetKinectArray.cpp:63-69
+  std::vector<float> pp_depth2, pp_depth_rg, pp_lab, pp_depth_b, pp_sil, pp_normal, pp_quality;
   // view state
   uint32_t vw, vh, aw;                        // view size, atlas width (1.5 w)
   std::vector<uint32_t> lod_off, lod_res;     // ViewLod tables, 2 uints per level
@@ -819,6 +825,220 @@ void orc_set_view(orc_ctx* c, const float* rgba, const float* depth) {
     memcpy(&ac[(size_t)y * c->aw * 4], rgba + (size_t)y * c->vw * 4, (size_t)c->vw * 16);
     memcpy(&ad[(size_t)y * c->aw], depth + (size_t)y * c->vw, (size_t)c->vw * 4);
   }
+}
+
+// ================================================================= image pre-processing
+// Literal restatement of glsl/pre_{morph,depth,boundary,normal,quality}.fs + inc_color.glsl as driven by
+// NetKinectArray::processDepth / processTextures (framework/NetKinectArray.cpp:249-288, :309-426).
+// Every pass runs per layer over the depth resolution; pass_TexCoord = (pixel + .5) / size; texSizeInv = 1 / size.
+void orc_set_raw_frame(orc_ctx* c, const float* raw_depth, const uint8_t* color_rgb) { c->raw_depth = raw_depth; c->color = color_rgb; }
+void orc_set_depth_limits(orc_ctx* c, uint32_t i, float mn, float mx) { c->cv_min_d[i] = mn; c->cv_max_d[i] = mx; }
+void orc_set_camera_position(orc_ctx* c, uint32_t i, const float* p) { c->cam_pos[i] = {p[0], p[1], p[2]}; }
+void orc_set_preprocess_flags(orc_ctx* c, int filter_textures, int processed_depth, int refine) {
+  c->filter_textures = filter_textures; c->use_processed_depth = processed_depth; c->refine_bound = refine;
+}
+
+namespace {
+// inc_color.glsl:8-46 (the shader divides an already normalised colour by 255 again, :14-16: restated as written)
+inline float pivot_rgb(float n) { return (n > 0.04045f ? powf((n + 0.055f) / 1.055f, 2.4f) : n / 12.92f) * 100.0f; }
+inline float pivot_xyz(float n) { return n > 0.008856f ? powf(n, (float)(1.0 / 3.0)) : (903.3f * n + 16.0f) / 116.0f; }
+inline vec3 rgb_to_lab(vec3 rgb) {
+  const float r = pivot_rgb(rgb.x / 255.0f), g = pivot_rgb(rgb.y / 255.0f), b = pivot_rgb(rgb.z / 255.0f);
+  const float X = r * 0.4124f + g * 0.3576f + b * 0.1805f, Y = r * 0.2126f + g * 0.7152f + b * 0.0722f, Z = r * 0.0193f + g * 0.1192f + b * 0.9505f;
+  const float x = pivot_xyz(X / 95.047f), y = pivot_xyz(Y / 100.000f), z = pivot_xyz(Z / 108.883f);
+  return {fmaxf(0.0f, 116.0f * y - 16.0f), 500.0f * (x - y), 200.0f * (y - z)};
+}
+inline bool in_bbox(const orc_ctx* c, vec3 p) {   // inc_bbox_test.glsl:11-21
+  return p.x >= c->cfg.bbox_min[0] && p.y >= c->cfg.bbox_min[1] && p.z >= c->cfg.bbox_min[2] && p.x <= c->cfg.bbox_max[0] && p.y <= c->cfg.bbox_max[1] && p.z <= c->cfg.bbox_max[2];
+}
+inline float len2(float x, float y) { return sqrtf(x * x + y * y); }
+}  // namespace
+
+void orc_process_textures(orc_ctx* c) {
+  const int W = (int)c->cfg.depth_w, H = (int)c->cfg.depth_h, N = (int)c->cfg.num_streams, CW = (int)c->cfg.color_w, CH = (int)c->cfg.color_h;
+  const size_t P = (size_t)W * H;
+  const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;                      // texSizeInv, NetKinectArray.cpp:195
+  c->pp_depth2.assign(N * P, 0.0f); c->pp_depth_rg.assign(N * P * 2, 0.0f); c->pp_lab.assign(N * P * 3, 0.0f);
+  c->pp_depth_b.assign(N * P * 2, 0.0f); c->pp_sil.assign(N * P, 0.0f); c->pp_normal.assign(N * P * 3, 0.0f); c->pp_quality.assign(N * P, 0.0f);
+  auto tc = [&](int x, int y, float& u, float& v) { u = ((float)x + 0.5f) / (float)W; v = ((float)y + 0.5f) / (float)H; };
+
+  // ---- "morph": pre_morph.fs mode 0 = dilate(coords, 1) on the raw depth (:73-112, :123-127); mode 1 copies (:130-131)
+  const float min_depth = 0.5f, max_depth = 4.5f, max_dist = 0.2f;                 // :32-33, :54
+  auto valid_m = [&](float d) { return d > min_depth && d < max_depth; };           // in_bbox(texcoord, depth) returns true (:48)
+#pragma omp parallel for collapse(2)
+  for (int l = 0; l < N; ++l)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        float u, v; tc(x, y, u, v);
+        auto smp = [&](float uu, float vv) { return tex2d_nearest(c->raw_depth, 1, W, H, l, uu, vv, 0); };
+        const float depth = smp(u, v);
+        float out;
+        if (valid_m(depth)) out = depth;
+        else {
+          float avg = 0.0f, num = 0.0f; bool valid = false;
+          for (int dy = -1; dy < 2; ++dy) for (int dx = -1; dx < 2; ++dx) {
+            const float ds = smp(u + (float)dx * tsx, v + (float)dy * tsy);
+            if (valid_m(ds)) { valid = true; avg += ds; num += 1.0f; }
+          }
+          if (!valid) out = 0.0f;
+          else {
+            avg /= num;
+            float nd = 0.0f; num = 0.0f; valid = false;
+            for (int dy = -1; dy < 2; ++dy) for (int dx = -1; dx < 2; ++dx) {
+              const float ds = smp(u + (float)dx * tsx, v + (float)dy * tsy);
+              if (valid_m(ds) && fabsf(avg - ds) < max_dist) { valid = true; nd += ds; num += 1.0f; }
+            }
+            out = valid ? nd / num : 0.0f;
+          }
+        }
+        c->pp_depth2[(size_t)l * P + (size_t)y * W + x] = out;
+      }
+  // the filter pass reads the processed (dilated) depth when m_use_processed_depth, else the raw array (:286-288, :194)
+  const float* fdepth = c->use_processed_depth ? c->pp_depth2.data() : c->raw_depth;
+
+  // ---- "filter": pre_depth.fs main() :129-154, bilateral_filter :85-127
+#pragma omp parallel for collapse(2)
+  for (int l = 0; l < N; ++l)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        float u, v; tc(x, y, u, v);
+        const float mn = c->cv_min_d[l], mx = c->cv_max_d[l];
+        auto smp = [&](float uu, float vv) { return tex2d_nearest(fdepth, 1, W, H, l, uu, vv, 0); };
+        auto norm = [&](float d) { return (d - mn) / (mx - mn); };
+        const float depth = smp(u, v);
+        const float dn = norm(depth);
+        float wp[3];
+        tex3d(c->xyz[l], 3, c->xyz_res[l], u, v, dn, wp);
+        const bool is_in_box = in_bbox(c, {wp[0], wp[1], wp[2]});
+        // out_Color = rgb_to_lab(get_color(vec3(tc, (dn <= 0 || dn >= 1) ? 1 : dn)))   :136
+        float cc[2], col[3];
+        tex3d(c->uv[l], 2, c->uv_res[l], u, v, (dn <= 0.0f || dn >= 1.0f) ? 1.0f : dn, cc);
+        tex2d_linear_u8(c->color, CW, CH, l, cc[0], cc[1], col);
+        const vec3 lab = rgb_to_lab({col[0], col[1], col[2]});
+        const size_t o = (size_t)l * P + (size_t)y * W + x;
+        c->pp_lab[3 * o] = lab.x; c->pp_lab[3 * o + 1] = lab.y; c->pp_lab[3 * o + 2] = lab.z;
+        float od[2] = {0.0f, 0.0f};
+        if (is_in_box) {
+          if (!c->filter_textures) { od[0] = dn; od[1] = 1.0f; }
+          else {
+            const float dist_range_max = 0.35f * (depth / 4.5f), dist_range_max_inv = 1.0f / dist_range_max;   // :89-92
+            float depth_bf = 0.0f, w = 0.0f, w_range = 0.0f, num = 0.0f;
+            for (int dy = -6; dy < 7; ++dy) for (int dx = -6; dx < 7; ++dx) {
+              num += 1.0f;
+              const float ds = smp(u + (float)dx * tsx, v + (float)dy * tsy);
+              const float dr = fabsf(ds - depth);
+              if ((ds < mn) || (ds > mx) || (dr > dist_range_max)) continue;                     // is_outside :74-76
+              const float gs = 1.0f - len2((float)dx, (float)dy) * (1.0f / 6.0f);               // computeGaussSpace :37-41
+              const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;           // computeGaussRange :43-48
+              const float ws = gs * gr;
+              depth_bf += ws * ds; w += ws; w_range += gr;
+            }
+            od[0] = norm(depth_bf / w); od[1] = w_range / num;                                   // :124-126
+          }
+        }
+        c->pp_depth_rg[2 * o] = od[0]; c->pp_depth_rg[2 * o + 1] = od[1];
+      }
+
+  // ---- "boundary": pre_boundary.fs main() :86-117, get_color_diff :37-55
+#pragma omp parallel for collapse(2)
+  for (int l = 0; l < N; ++l)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        float u, v; tc(x, y, u, v);
+        const size_t o = (size_t)l * P + (size_t)y * W + x;
+        float dx_ = tex2d_nearest(c->pp_depth_rg.data(), 2, W, H, l, u, v, 0), dy_ = tex2d_nearest(c->pp_depth_rg.data(), 2, W, H, l, u, v, 1);
+        float sil = 1.0f;
+        if (dx_ <= 0.0f) { dy_ = 0.0f; sil = 0.0f; }
+        else if (!(dy_ > 0.65f)) {                                                               // valid_range :27-30
+          sil = 0.0f;
+          float color[3];
+          tex2d_linear(c->pp_lab.data(), 3, W, H, l, u, v, color);
+          float total = 0.0f, num = 0.0f;
+          for (int ky = -2; ky < 3; ++ky) for (int kx = -2; kx < 3; ++kx) {
+            const float us = u + (float)kx * tsx, vs = v + (float)ky * tsy;
+            const float sx = tex2d_nearest(c->pp_depth_rg.data(), 2, W, H, l, us, vs, 0), sy = tex2d_nearest(c->pp_depth_rg.data(), 2, W, H, l, us, vs, 1);
+            if (sx > 0.0f && sy > 0.65f) {
+              num += 1.0f;
+              float cs[3];
+              tex2d_linear(c->pp_lab.data(), 3, W, H, l, us, vs, cs);
+              total += length(vec3{color[0] - cs[0], color[1] - cs[1], color[2] - cs[2]});
+            }
+          }
+          const float color_dist = (num < 16.0f * 0.5f) ? 1.0f : total / num;                   // total_samples = 16 (:23, :53)
+          if (color_dist > 0.5f || !c->refine_bound) { dx_ = -1.0f; dy_ = 0.1f; sil = 0.0f; }
+          else dy_ = 1.0f;
+        } else dy_ = 0.0f;
+        c->pp_depth_b[2 * o] = dx_; c->pp_depth_b[2 * o + 1] = dy_; c->pp_sil[o] = sil;
+      }
+
+  // ---- "normal": pre_normal.fs :26-56 (+ mark_brick :33); serial because of the counters
+  for (int l = 0; l < N; ++l)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        float u, v; tc(x, y, u, v);
+        const size_t o = (size_t)l * P + (size_t)y * W + x;
+        auto dsm = [&](float uu, float vv) { return tex2d_nearest(c->pp_depth_b.data(), 2, W, H, l, uu, vv, 0); };
+        auto outside = [](float d) { return d <= 0.0f || d >= 1.0f; };
+        const float depth = dsm(u, v);
+        vec3 n = {0, 0, 0};
+        if (!outside(depth)) {
+          float wp[3];
+          tex3d(c->xyz[l], 3, c->xyz_res[l], u, v, depth, wp);
+          mark_brick(c, {wp[0], wp[1], wp[2]});
+          float dt = dsm(u, v + tsy), db = dsm(u, v - tsy), dl = dsm(u - tsx, v), dr = dsm(u + tsx, v);
+          dt = outside(dt) ? depth : dt; db = outside(db) ? depth : db; dl = outside(dl) ? depth : dl; dr = outside(dr) ? depth : dr;
+          float wt[3], wb[3], wl[3], wr[3];
+          tex3d(c->xyz[l], 3, c->xyz_res[l], u, v + tsy, dt, wt);
+          tex3d(c->xyz[l], 3, c->xyz_res[l], u, v - tsy, db, wb);
+          tex3d(c->xyz[l], 3, c->xyz_res[l], u - tsx, v, dl, wl);
+          tex3d(c->xyz[l], 3, c->xyz_res[l], u + tsx, v, dr, wr);
+          const vec3 a = {wb[0] - wt[0], wb[1] - wt[1], wb[2] - wt[2]}, b = {wl[0] - wr[0], wl[1] - wr[1], wl[2] - wr[2]};
+          n = normalize(vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x});
+        }
+        c->pp_normal[3 * o] = n.x; c->pp_normal[3 * o + 1] = n.y; c->pp_normal[3 * o + 2] = n.z;
+      }
+
+  // ---- "quality": pre_quality.fs bilateral_filter :65-119, normal_angle :43-48.  pow() of a negative base is undefined
+  // in GLSL; powf is used as is (angle < 0 only for back-facing noise).
+#pragma omp parallel for collapse(2)
+  for (int l = 0; l < N; ++l)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        float u, v; tc(x, y, u, v);
+        const size_t o = (size_t)l * P + (size_t)y * W + x;
+        auto dsm = [&](float uu, float vv) { return tex2d_nearest(c->pp_depth_b.data(), 2, W, H, l, uu, vv, 0); };
+        auto outside = [](float d) { return d <= 0.0f || d >= 1.0f; };
+        const float depth = dsm(u, v);
+        float q = 0.0f;
+        if (!outside(depth)) {
+          const float dist_range_max = 0.35f * (depth / 1.0f), dist_range_max_inv = 1.0f / dist_range_max;
+          float w_range = 0.0f, border = 0.0f, num = 0.0f;
+          for (int dy = -6; dy < 7; ++dy) for (int dx = -6; dx < 7; ++dx) {
+            num += 1.0f;
+            const float ds = dsm(u + (float)dx * tsx, v + (float)dy * tsy);
+            const float dr = fabsf(ds - depth);
+            if (outside(ds) || dr > dist_range_max) { border += 1.0f; continue; }
+            w_range += 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+          }
+          const float lateral = 1.0f - border / num;
+          q = powf(lateral, 6.0f);
+          q *= powf(w_range / num, 6.0f);
+          q /= depth * 6.5f;
+          float wn[3], wp[3];
+          tex2d_linear(c->pp_normal.data(), 3, W, H, l, u, v, wn);
+          tex3d(c->xyz[l], 3, c->xyz_res[l], u, v, depth, wp);
+          const vec3 tocam = normalize(c->cam_pos[l] - vec3{wp[0], wp[1], wp[2]});
+          const float angle = dot(tocam, vec3{wn[0], wn[1], wn[2]});
+          q *= powf(angle, 2.0f);
+        }
+        c->pp_quality[o] = q;
+      }
+  // the path now reads the products (texture units 2, 3, 5 of NetKinectArray::bindToTextureUnits, :451-462)
+  c->depth = c->pp_depth_b.data(); c->quality = c->pp_quality.data(); c->silhouette = c->pp_sil.data();
+}
+void orc_get_preprocessed(orc_ctx* c, float* depth2, float* depth_rg, float* lab, float* depth_b, float* sil, float* normal, float* quality) {
+  auto cp = [](float* d, const std::vector<float>& s) { if (d) memcpy(d, s.data(), s.size() * 4); };
+  cp(depth2, c->pp_depth2); cp(depth_rg, c->pp_depth_rg); cp(lab, c->pp_lab); cp(depth_b, c->pp_depth_b); cp(sil, c->pp_sil); cp(normal, c->pp_normal); cp(quality, c->pp_quality);
 }
 
 // ---------------------------------------------------------------- sampling primitives for unit tests

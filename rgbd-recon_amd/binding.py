@@ -145,6 +145,29 @@ class ReconIntegrationHip:
         self._ck(self._L.tsdf_upload_frame(self._c, _fp(_f32(scene["depth"])), _fp(_f32(scene["quality"])),
                                            _fp(_f32(scene["silhouette"])), col.ctypes.data_as(C.POINTER(C.c_uint8))))
 
+    # ------------------------------------------------------------------ NetKinectArray side: raw frame -> processTextures()
+    def upload_raw_frame(self, scene):
+        col = np.ascontiguousarray(scene["color"], np.uint8)
+        self._ck(self._L.tsdf_upload_raw_frame(self._c, _fp(_f32(scene["depth_raw"])), col.ctypes.data_as(C.POINTER(C.c_uint8))))
+        for i in range(self.n):
+            self._ck(self._L.tsdf_set_depth_limits(self._c, i, C.c_float(float(scene["depth_limits"][0])), C.c_float(float(scene["depth_limits"][1]))))
+            self._ck(self._L.tsdf_set_camera_position(self._c, i, _fp(_f32(scene["camera_positions"][i]))))
+        self._pp_shape = (self.n, scene["height"], scene["width"])
+
+    def setPreprocess(self, filter_textures=True, processed_depth=True, refine=True):
+        self._ck(self._L.tsdf_set_preprocess(self._c, int(filter_textures), int(processed_depth), int(refine)))
+
+    def processTextures(self): self._ck(self._L.tsdf_process_textures(self._c))
+
+    def preprocessed(self):
+        n, h, w = self._pp_shape
+        out = dict(depth2=np.zeros((n, h, w), np.float32), depth_rg=np.zeros((n, h, w, 2), np.float32), lab=np.zeros((n, h, w, 3), np.float32),
+                   depth_b=np.zeros((n, h, w, 2), np.float32), silhouette=np.zeros((n, h, w), np.float32),
+                   normals=np.zeros((n, h, w, 3), np.float32), quality=np.zeros((n, h, w), np.float32))
+        self._ck(self._L.tsdf_download_preprocessed(self._c, _fp(out["depth2"]), _fp(out["depth_rg"]), _fp(out["lab"]), _fp(out["depth_b"]),
+                                                    _fp(out["silhouette"]), _fp(out["normals"]), _fp(out["quality"])))
+        return out
+
     # ------------------------------------------------------------------ reference operator surface
     def clearOccupiedBricks(self): self._ck(self._L.tsdf_clear_bricks(self._c))
     def markBricks(self): self._ck(self._L.tsdf_mark_bricks(self._c))

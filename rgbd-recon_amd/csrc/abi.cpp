@@ -59,6 +59,11 @@ struct tsdf_ctx {
   float* d_depth_plane = nullptr;
   float* d_stage_depth = nullptr; float* d_stage_q = nullptr; float* d_stage_s = nullptr; uint8_t* d_stage_col = nullptr;
   bool have_frame = false;
+  // pre-processing state (NetKinectArray side)
+  PreParams pre{};
+  float* d_raw = nullptr; float* d_depth2 = nullptr; float2* d_depth_rg = nullptr; float4* d_lab = nullptr; float2* d_depth_b = nullptr; float4* d_normal = nullptr;
+  bool have_raw = false, use_processed_depth = true;
+  bool have_limits[TSDF_MAX_STREAMS]{}, have_cam[TSDF_MAX_STREAMS]{};
   // view
   int vw = 0, vh = 0;
   Atlas atlas{};
@@ -423,6 +428,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if ((rc = tryhip(hipMalloc(&c->d_stage_col, nc * 3), "hipMalloc(stage)"))) return fail(rc);
   hipMemsetAsync((void*)F.color, 0, nc * sizeof(uchar4), c->stream);
   c->luts.n = (int)cfg->num_streams;
+  c->pre.filter_textures = 1; c->pre.refine = 1;                      // NetKinectArray.cpp:63-69
   if ((rc = setup_view(c, cfg->view_w, cfg->view_h))) return fail(rc);
   if ((rc = tryhip(hipStreamSynchronize(c->stream), "hipStreamSynchronize"))) return fail(rc);
   *out = c;
@@ -436,6 +442,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   release_view(c); release_bricks(c);
   hipFree(c->tiles.active); hipFree(c->d_cls_all); hipFree(c->d_pyr); hipFree(c->tiles.list);
   hipFree(c->vol.data); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
+  hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal);
   hipFree(c->d_depth_plane); hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
   for (void* p : c->lut_allocs) hipFree(p);
   if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
@@ -516,6 +523,87 @@ int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quali
   }
   HIP_TRY(c, hipGetLastError());
   c->have_frame = true;
+  return TSDF_OK;
+}
+
+// ---- image pre-processing (NetKinectArray::processTextures)
+int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour) {
+  CHECK_CTX(c);
+  if (!depth_raw || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "raw depth and colour are required");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const FrameImages& F = c->frame;
+  const size_t np = (size_t)c->cfg.num_streams * F.w * F.h, nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
+  if (!c->d_raw) {
+    HIP_TRY(c, hipMalloc(&c->d_raw, np * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->d_depth2, np * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->d_depth_rg, np * sizeof(float2)));
+    HIP_TRY(c, hipMalloc(&c->d_lab, np * sizeof(float4)));
+    HIP_TRY(c, hipMalloc(&c->d_depth_b, np * sizeof(float2)));
+    HIP_TRY(c, hipMalloc(&c->d_normal, np * sizeof(float4)));
+    HIP_TRY(c, hipMemsetAsync((void*)F.dqs, 0, np * sizeof(float4), c->stream));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_raw, depth_raw, np * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
+  launch_pack_color(c->stream, c->d_stage_col, (uchar4*)F.color, nc);
+  HIP_TRY(c, hipGetLastError());
+  c->have_raw = true;
+  return TSDF_OK;
+}
+int32_t tsdf_set_depth_limits(tsdf_ctx* c, uint32_t i, float mn, float mx) {
+  CHECK_CTX(c);
+  if (i >= c->cfg.num_streams || !(mx > mn)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "bad stream index or depth limits");
+  c->pre.cv_min[i] = mn; c->pre.cv_max[i] = mx; c->have_limits[i] = true;
+  return TSDF_OK;
+}
+int32_t tsdf_set_camera_position(tsdf_ctx* c, uint32_t i, const float xyz[3]) {
+  CHECK_CTX(c);
+  if (i >= c->cfg.num_streams || !xyz) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "bad stream index");
+  for (int a = 0; a < 3; ++a) c->pre.cam[i][a] = xyz[a];
+  c->have_cam[i] = true;
+  return TSDF_OK;
+}
+int32_t tsdf_set_preprocess(tsdf_ctx* c, int32_t filter_textures, int32_t processed_depth, int32_t refine) {
+  CHECK_CTX(c);
+  c->pre.filter_textures = filter_textures != 0; c->use_processed_depth = processed_depth != 0; c->pre.refine = refine != 0;
+  return TSDF_OK;
+}
+int32_t tsdf_process_textures(tsdf_ctx* c) {
+  CHECK_CTX(c);
+  if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "no raw frame uploaded (tsdf_upload_raw_frame)");
+  for (uint32_t i = 0; i < c->cfg.num_streams; ++i) {
+    if (!c->have_calib[i] || !c->luts.s[i].xyz || !c->luts.s[i].uv) FAIL(c, TSDF_ERR_STATE, "stream %u needs cv_xyz and cv_uv (tsdf_set_calibration)", i);
+    if (!c->have_limits[i] || !c->have_cam[i]) FAIL(c, TSDF_ERR_STATE, "stream %u needs tsdf_set_depth_limits and tsdf_set_camera_position", i);
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  PreParams& P = c->pre;
+  P.W = c->frame.w; P.H = c->frame.h; P.N = (int)c->cfg.num_streams;
+  for (int a = 0; a < 3; ++a) { P.bbox_min[a] = c->cfg.bbox_min[a]; P.bbox_max[a] = c->cfg.bbox_max[a]; }
+  PreBuffers B{};
+  B.raw = c->d_raw; B.depth2 = c->d_depth2; B.fdepth = c->use_processed_depth ? c->d_depth2 : c->d_raw;
+  B.depth_rg = c->d_depth_rg; B.lab = c->d_lab; B.depth_b = c->d_depth_b; B.normal = c->d_normal;
+  B.dqs = (float4*)c->frame.dqs; B.depth_plane = c->d_depth_plane;
+  timer_begin(c, "1preprocess");
+  launch_preprocess(c->stream, P, B, c->luts, c->frame, c->br);
+  timer_end(c, "1preprocess");
+  HIP_TRY(c, hipGetLastError());
+  c->have_frame = true;
+  return TSDF_OK;
+}
+int32_t tsdf_download_preprocessed(tsdf_ctx* c, float* depth2, float* depth_rg, float* lab, float* depth_b, float* sil, float* normals, float* quality) {
+  CHECK_CTX(c);
+  if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "nothing was pre-processed yet");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h;
+  if (depth2) HIP_TRY(c, hipMemcpy(depth2, c->d_depth2, np * 4, hipMemcpyDeviceToHost));
+  if (depth_rg) HIP_TRY(c, hipMemcpy(depth_rg, c->d_depth_rg, np * 8, hipMemcpyDeviceToHost));
+  if (depth_b) HIP_TRY(c, hipMemcpy(depth_b, c->d_depth_b, np * 8, hipMemcpyDeviceToHost));
+  std::vector<float4> tmp;
+  auto fetch4 = [&](const void* src) -> int32_t { tmp.resize(np); HIP_TRY(c, hipMemcpy(tmp.data(), src, np * 16, hipMemcpyDeviceToHost)); return TSDF_OK; };
+  int32_t rc;
+  if (lab) { if ((rc = fetch4(c->d_lab))) return rc; for (size_t i = 0; i < np; ++i) { lab[3 * i] = tmp[i].x; lab[3 * i + 1] = tmp[i].y; lab[3 * i + 2] = tmp[i].z; } }
+  if (normals) { if ((rc = fetch4(c->d_normal))) return rc; for (size_t i = 0; i < np; ++i) { normals[3 * i] = tmp[i].x; normals[3 * i + 1] = tmp[i].y; normals[3 * i + 2] = tmp[i].z; } }
+  if (sil || quality) { if ((rc = fetch4(c->frame.dqs))) return rc; for (size_t i = 0; i < np; ++i) { if (quality) quality[i] = tmp[i].y; if (sil) sil[i] = tmp[i].z; } }
   return TSDF_OK;
 }
 

@@ -3,6 +3,7 @@
 //   mark_bricks             : pre_normal.fs:22-33 call site of mark_brick(), inc_bricks.glsl:40-58
 //   update_occupied         : updateOccupiedBricks(), recon_integration.cpp:430-445, without the host round trip
 #include "sampling.hpp"
+#include "bricks_dev.hpp"
 
 namespace rr {
 
@@ -36,23 +37,6 @@ void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n) {
   hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
 }
 
-// texture(sampler3D RGB32F (stored RGBA), p).xyz -- forward LUT cv_xyz
-__device__ __forceinline__ float sgnf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
-
-// counters[id] += (number of lanes holding id), one atomic per distinct id in the wave.  Neighbouring pixels of a
-// row fall into the same few bricks, so a wave issues a handful of atomics instead of up to 64 contended ones.
-__device__ __forceinline__ void wave_count(uint32_t* __restrict__ counters, uint32_t id, bool valid) {
-  const int lane = threadIdx.x & 63;
-  unsigned long long todo = __ballot(valid);
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t lid = __shfl(id, leader);
-    const unsigned long long same = __ballot(valid && id == lid) & todo;
-    if (lane == leader) atomicAdd(&counters[lid], (uint32_t)__popcll(same));
-    todo &= ~same;
-  }
-}
-
 // One thread per depth pixel and stream (pre_normal.fs:22-33 runs per fragment of every layer).
 __global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages F, Bricks B) {
   const int px = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -67,26 +51,7 @@ __global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages 
     if (!(d <= 0.0f || d >= 1.0f)) {                                    // is_outside(), pre_normal.fs:22-24
       const StreamLut& L = T.s[layer];
       const float3 pos = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, d);     // world position, :32
-      // mark_brick(pos), inc_bricks.glsl:40-58
-      const float relx = pos.x - B.bbox_min[0], rely = pos.y - B.bbox_min[1], relz = pos.z - B.bbox_min[2];
-      const float fx = floorf(relx / B.size[0]), fy = floorf(rely / B.size[1]), fz = floorf(relz / B.size[2]);
-      if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)B.res[0] && fy < (float)B.res[1] && fz < (float)B.res[2]) {
-        const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-        const float cx = (float)ix * B.size[0] + B.bbox_min[0] + 0.5f * B.size[0];
-        const float cy = (float)iy * B.size[1] + B.bbox_min[1] + 0.5f * B.size[1];
-        const float cz = (float)iz * B.size[2] + B.bbox_min[2] + 0.5f * B.size[2];
-        const float dx = pos.x - cx, dy = pos.y - cy, dz = pos.z - cz;
-        const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
-        const float mv = fmaxf(ax, fmaxf(ay, az));
-        const int ox = (int)sgnf(dx * (ax < mv ? 0.0f : 1.0f));
-        const int oy = (int)sgnf(dy * (ay < mv ? 0.0f : 1.0f));
-        const int oz = (int)sgnf(dz * (az < mv ? 0.0f : 1.0f));
-        const int nbx = clampi(ix + ox, 0, B.res[0] - 1), nby = clampi(iy + oy, 0, B.res[1] - 1), nbz = clampi(iz + oz, 0, B.res[2] - 1);
-        nbr = ax > B.size[0] * 0.1f;                                    // the neighbour add is 0 otherwise (:52)
-        id_nbr = (uint32_t)(((size_t)nbz * B.res[1] + nby) * B.res[0] + nbx);
-        own = true;
-        id_own = (uint32_t)(((size_t)iz * B.res[1] + iy) * B.res[0] + ix);
-      }
+      mark_brick_ids(B, pos, own, id_own, nbr, id_nbr);
     }
   }
   wave_count(B.counters, id_nbr, nbr);

@@ -1,0 +1,242 @@
+// Image pre-processing P1..P5: glsl/pre_{morph,depth,boundary,normal,quality}.fs + inc_color.glsl as
+// driven by NetKinectArray::processDepth / processTextures (framework/NetKinectArray.cpp:249-288, :309-426).
+// One thread per depth pixel and layer; pass_TexCoord = (pixel + .5) / size, texSizeInv = 1 / size (:195).  A tap at
+// pass_TexCoord + (dx, dy) * texSizeInv of a NEAREST array is the texel (x + dx, y + dy) clamped to the image (the coordinate
+// is half a texel away from any texel border), LINEAR fetches go through the generic fp32 bilinear sampler.
+// The products land directly in the layouts the path reads: the packed {depth, quality, silhouette} texel and the depth plane.
+#include "sampling.hpp"
+#include "bricks_dev.hpp"
+
+namespace rr {
+
+__device__ __forceinline__ int clamp_tap(int v, int n) { return min(max(v, 0), n - 1); }
+// NEAREST fetch at pass_TexCoord + (dx,dy)*texSizeInv, written with the same fp32 coordinate arithmetic as the shader
+__device__ __forceinline__ int tap_x(int x, int dx, int W) { return axis_nearest(((float)x + 0.5f) / (float)W + (float)dx * (1.0f / (float)W), W); }
+__device__ __forceinline__ int tap_y(int y, int dy, int H) { return axis_nearest(((float)y + 0.5f) / (float)H + (float)dy * (1.0f / (float)H), H); }
+
+// ---- pre_morph.fs: mode 0 = dilate(coords, 1) (:73-112, :123-127); mode 1 is a copy (:130-131)
+__global__ __launch_bounds__(256) void k_pre_morph(PreParams P, PreBuffers B) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), l = blockIdx.z;
+  if (x >= P.W || y >= P.H) return;
+  const float* __restrict__ src = B.raw + (size_t)l * P.W * P.H;
+  const float min_depth = 0.5f, max_depth = 4.5f, max_dist = 0.2f;
+  const float depth = src[(size_t)tap_y(y, 0, P.H) * P.W + tap_x(x, 0, P.W)];
+  float out;
+  if (depth > min_depth && depth < max_depth) out = depth;              // is_valid && in_bbox (which returns true, :48)
+  else {
+    float s[9];
+#pragma unroll
+    for (int dy = -1; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = -1; dx < 2; ++dx) s[(dy + 1) * 3 + dx + 1] = src[(size_t)tap_y(y, dy, P.H) * P.W + tap_x(x, dx, P.W)];
+    float avg = 0.0f, num = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) if (s[k] > min_depth && s[k] < max_depth) { avg += s[k]; num += 1.0f; }
+    if (num == 0.0f) out = 0.0f;
+    else {
+      avg /= num;
+      float nd = 0.0f;
+      num = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) if (s[k] > min_depth && s[k] < max_depth && fabsf(avg - s[k]) < max_dist) { nd += s[k]; num += 1.0f; }
+      out = num > 0.0f ? nd / num : 0.0f;
+    }
+  }
+  B.depth2[(size_t)l * P.W * P.H + (size_t)y * P.W + x] = out;
+}
+
+// inc_color.glsl:8-46 (the shader divides an already normalised colour by 255 again, :14-16: restated as written)
+__device__ __forceinline__ float pivot_rgb(float n) { return (n > 0.04045f ? powf((n + 0.055f) / 1.055f, 2.4f) : n / 12.92f) * 100.0f; }
+__device__ __forceinline__ float pivot_xyz(float n) { return n > 0.008856f ? powf(n, (float)(1.0 / 3.0)) : (903.3f * n + 16.0f) / 116.0f; }
+__device__ __forceinline__ float3 rgb_to_lab(float3 rgb) {
+  const float r = pivot_rgb(rgb.x / 255.0f), g = pivot_rgb(rgb.y / 255.0f), b = pivot_rgb(rgb.z / 255.0f);
+  const float X = r * 0.4124f + g * 0.3576f + b * 0.1805f, Y = r * 0.2126f + g * 0.7152f + b * 0.0722f, Z = r * 0.0193f + g * 0.1192f + b * 0.9505f;
+  const float x = pivot_xyz(X / 95.047f), y = pivot_xyz(Y / 100.000f), z = pivot_xyz(Z / 108.883f);
+  return make_float3(fmaxf(0.0f, 116.0f * y - 16.0f), 500.0f * (x - y), 200.0f * (y - z));
+}
+__device__ __forceinline__ float3 color_bilinear_pre(const FrameImages& F, int layer, float u, float v) {   // RGB8 LINEAR
+  const Axis X = axis_linear(u, F.cw), Y = axis_linear(v, F.ch);
+  const uchar4* __restrict__ b = F.color + (size_t)layer * F.cw * F.ch;
+  const uchar4 t00 = b[(size_t)Y.i0 * F.cw + X.i0], t10 = b[(size_t)Y.i0 * F.cw + X.i1];
+  const uchar4 t01 = b[(size_t)Y.i1 * F.cw + X.i0], t11 = b[(size_t)Y.i1 * F.cw + X.i1];
+  return make_float3(lerpf(lerpf(t00.x / 255.0f, t10.x / 255.0f, X.a), lerpf(t01.x / 255.0f, t11.x / 255.0f, X.a), Y.a),
+                     lerpf(lerpf(t00.y / 255.0f, t10.y / 255.0f, X.a), lerpf(t01.y / 255.0f, t11.y / 255.0f, X.a), Y.a),
+                     lerpf(lerpf(t00.z / 255.0f, t10.z / 255.0f, X.a), lerpf(t01.z / 255.0f, t11.z / 255.0f, X.a), Y.a));
+}
+
+// ---- pre_depth.fs main() :129-154 with bilateral_filter :85-127.  The 13x13 window of a 16x16 pixel block is staged in
+// LDS (28x28 depths, clamped taps), so the 169 taps per pixel are LDS reads.
+__global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, StreamTable T, FrameImages F) {
+  __shared__ float s_d[28][29];
+  const int l = blockIdx.z, bx = blockIdx.x * 16, by = blockIdx.y * 16;
+  const float* __restrict__ src = B.fdepth + (size_t)l * P.W * P.H;
+  for (int i = threadIdx.x; i < 28 * 28; i += 256) {
+    const int ty = i / 28, tx = i % 28;
+    s_d[ty][tx] = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, x = bx + lx, y = by + ly;
+  if (x >= P.W || y >= P.H) return;
+  const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
+  const float mn = P.cv_min[l], mx = P.cv_max[l];
+  const float depth = s_d[ly + 6][lx + 6];
+  const float dn = (depth - mn) / (mx - mn);
+  const StreamLut& L = T.s[l];
+  const float3 wp = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, dn);
+  const bool in_box = wp.x >= P.bbox_min[0] && wp.y >= P.bbox_min[1] && wp.z >= P.bbox_min[2] && wp.x <= P.bbox_max[0] && wp.y <= P.bbox_max[1] && wp.z <= P.bbox_max[2];
+  const float2 cc = tex3d_rg(L.uv, L.uv_res, u, v, (dn <= 0.0f || dn >= 1.0f) ? 1.0f : dn);     // :136
+  const float3 lab = rgb_to_lab(color_bilinear_pre(F, l, cc.x, cc.y));
+  const size_t o = (size_t)l * P.W * P.H + (size_t)y * P.W + x;
+  B.lab[o] = make_float4(lab.x, lab.y, lab.z, 0.0f);
+  float2 od = make_float2(0.0f, 0.0f);
+  if (in_box) {
+    if (!P.filter_textures) od = make_float2(dn, 1.0f);
+    else {
+      const float dist_range_max = 0.35f * (depth / 4.5f), dist_range_max_inv = 1.0f / dist_range_max;   // :89-92
+      float depth_bf = 0.0f, w = 0.0f, w_range = 0.0f, num = 0.0f;
+      for (int dy = -6; dy < 7; ++dy)
+        for (int dx = -6; dx < 7; ++dx) {
+          num += 1.0f;
+          const float ds = s_d[ly + 6 + dy][lx + 6 + dx];
+          const float dr = fabsf(ds - depth);
+          if ((ds < mn) || (ds > mx) || (dr > dist_range_max)) continue;                               // is_outside, :74-76
+          const float gs = 1.0f - sqrtf((float)dx * (float)dx + (float)dy * (float)dy) * (1.0f / 6.0f); // computeGaussSpace
+          const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;                       // computeGaussRange
+          const float ws = gs * gr;
+          depth_bf += ws * ds; w += ws; w_range += gr;
+        }
+      od = make_float2((depth_bf / w - mn) / (mx - mn), w_range / num);                                 // :124-126
+    }
+  }
+  B.depth_rg[o] = od;
+}
+
+__device__ __forceinline__ float3 lab_bilinear(const float4* __restrict__ lab, int W, int H, float u, float v) {   // RGB32F LINEAR
+  const Axis X = axis_linear(u, W), Y = axis_linear(v, H);
+  const float4 t00 = lab[(size_t)Y.i0 * W + X.i0], t10 = lab[(size_t)Y.i0 * W + X.i1], t01 = lab[(size_t)Y.i1 * W + X.i0], t11 = lab[(size_t)Y.i1 * W + X.i1];
+  return make_float3(lerpf(lerpf(t00.x, t10.x, X.a), lerpf(t01.x, t11.x, X.a), Y.a), lerpf(lerpf(t00.y, t10.y, X.a), lerpf(t01.y, t11.y, X.a), Y.a),
+                     lerpf(lerpf(t00.z, t10.z, X.a), lerpf(t01.z, t11.z, X.a), Y.a));
+}
+
+// ---- pre_boundary.fs main() :86-117, get_color_diff :37-55
+__global__ __launch_bounds__(256) void k_pre_boundary(PreParams P, PreBuffers B) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), l = blockIdx.z;
+  if (x >= P.W || y >= P.H) return;
+  const size_t base = (size_t)l * P.W * P.H, o = base + (size_t)y * P.W + x;
+  const float2* __restrict__ drg = B.depth_rg + base;
+  const float4* __restrict__ lab = B.lab + base;
+  const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
+  const float tsx = 1.0f / (float)P.W, tsy = 1.0f / (float)P.H;
+  float2 d = drg[(size_t)tap_y(y, 0, P.H) * P.W + tap_x(x, 0, P.W)];
+  float sil = 1.0f;
+  if (d.x <= 0.0f) { d.y = 0.0f; sil = 0.0f; }
+  else if (!(d.y > 0.65f)) {                                                             // valid_range, :27-30
+    sil = 0.0f;
+    const float3 color = lab_bilinear(lab, P.W, P.H, u, v);
+    float total = 0.0f, num = 0.0f;
+    for (int ky = -2; ky < 3; ++ky)
+      for (int kx = -2; kx < 3; ++kx) {
+        const float2 s = drg[(size_t)tap_y(y, ky, P.H) * P.W + tap_x(x, kx, P.W)];
+        if (s.x > 0.0f && s.y > 0.65f) {
+          num += 1.0f;
+          const float3 cs = lab_bilinear(lab, P.W, P.H, u + (float)kx * tsx, v + (float)ky * tsy);
+          const float ex = color.x - cs.x, ey = color.y - cs.y, ez = color.z - cs.z;
+          total += sqrtf(ex * ex + ey * ey + ez * ez);
+        }
+      }
+    const float color_dist = (num < 16.0f * 0.5f) ? 1.0f : total / num;                  // total_samples = 16 (:23, :53)
+    if (color_dist > 0.5f || !P.refine) { d.x = -1.0f; d.y = 0.1f; sil = 0.0f; }
+    else d.y = 1.0f;
+  } else d.y = 0.0f;
+  B.depth_b[o] = d;
+  B.depth_plane[o] = d.x;
+  float4 t = B.dqs[o];
+  t.x = d.x; t.z = sil; t.w = 0.0f;
+  B.dqs[o] = t;
+}
+
+// ---- pre_normal.fs :26-56 including the mark_brick() call (:32-33)
+__global__ __launch_bounds__(256) void k_pre_normal(PreParams P, PreBuffers B, StreamTable T, Bricks BR) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), l = blockIdx.z;
+  bool own = false, nbr = false;
+  uint32_t id_own = 0, id_nbr = 0;
+  if (x < P.W && y < P.H) {
+    const size_t base = (size_t)l * P.W * P.H;
+    const float* __restrict__ dp = B.depth_plane + base;
+    const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
+    const float tsx = 1.0f / (float)P.W, tsy = 1.0f / (float)P.H;
+    const float depth = dp[(size_t)tap_y(y, 0, P.H) * P.W + tap_x(x, 0, P.W)];
+    float3 n = make_float3(0, 0, 0);
+    if (!(depth <= 0.0f || depth >= 1.0f)) {
+      const StreamLut& L = T.s[l];
+      const float3 wp = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, depth);
+      mark_brick_ids(BR, wp, own, id_own, nbr, id_nbr);
+      float dt = dp[(size_t)axis_nearest(v + tsy, P.H) * P.W + axis_nearest(u, P.W)], db = dp[(size_t)axis_nearest(v - tsy, P.H) * P.W + axis_nearest(u, P.W)];
+      float dl = dp[(size_t)axis_nearest(v, P.H) * P.W + axis_nearest(u - tsx, P.W)], dr = dp[(size_t)axis_nearest(v, P.H) * P.W + axis_nearest(u + tsx, P.W)];
+      dt = (dt <= 0.0f || dt >= 1.0f) ? depth : dt; db = (db <= 0.0f || db >= 1.0f) ? depth : db;
+      dl = (dl <= 0.0f || dl >= 1.0f) ? depth : dl; dr = (dr <= 0.0f || dr >= 1.0f) ? depth : dr;
+      const float3 wt = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v + tsy, dt), wb = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v - tsy, db);
+      const float3 wl = tex3d_rgba_xyz(L.xyz, L.xyz_res, u - tsx, v, dl), wr = tex3d_rgba_xyz(L.xyz, L.xyz_res, u + tsx, v, dr);
+      const float3 a = make_float3(wb.x - wt.x, wb.y - wt.y, wb.z - wt.z), b = make_float3(wl.x - wr.x, wl.y - wr.y, wl.z - wr.z);
+      n = normalize3(make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x));
+    }
+    B.normal[base + (size_t)y * P.W + x] = make_float4(n.x, n.y, n.z, 0.0f);
+  }
+  wave_count(BR.counters, id_nbr, nbr);
+  wave_count(BR.counters, id_own, own);
+}
+
+// ---- pre_quality.fs bilateral_filter :65-119 with normal_angle :43-48; same LDS staging as the filter pass
+__global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, StreamTable T) {
+  __shared__ float s_d[28][29];
+  const int l = blockIdx.z, bx = blockIdx.x * 16, by = blockIdx.y * 16;
+  const size_t base = (size_t)l * P.W * P.H;
+  const float* __restrict__ src = B.depth_plane + base;
+  for (int i = threadIdx.x; i < 28 * 28; i += 256) {
+    const int ty = i / 28, tx = i % 28;
+    s_d[ty][tx] = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, x = bx + lx, y = by + ly;
+  if (x >= P.W || y >= P.H) return;
+  const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
+  const float depth = s_d[ly + 6][lx + 6];
+  float q = 0.0f;
+  if (!(depth <= 0.0f || depth >= 1.0f)) {
+    const float dist_range_max = 0.35f * (depth / 1.0f), dist_range_max_inv = 1.0f / dist_range_max;
+    float w_range = 0.0f, border = 0.0f, num = 0.0f;
+    for (int dy = -6; dy < 7; ++dy)
+      for (int dx = -6; dx < 7; ++dx) {
+        num += 1.0f;
+        const float ds = s_d[ly + 6 + dy][lx + 6 + dx];
+        const float dr = fabsf(ds - depth);
+        if ((ds <= 0.0f || ds >= 1.0f) || dr > dist_range_max) { border += 1.0f; continue; }
+        w_range += 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+      }
+    const float lateral = 1.0f - border / num;
+    q = powf(lateral, 6.0f);
+    q *= powf(w_range / num, 6.0f);
+    q /= depth * 6.5f;
+    const Axis X = axis_linear(u, P.W), Y = axis_linear(v, P.H);                          // kinect_normals LINEAR
+    const float4* __restrict__ nm = B.normal + base;
+    const float4 t00 = nm[(size_t)Y.i0 * P.W + X.i0], t10 = nm[(size_t)Y.i0 * P.W + X.i1], t01 = nm[(size_t)Y.i1 * P.W + X.i0], t11 = nm[(size_t)Y.i1 * P.W + X.i1];
+    const float3 wn = make_float3(lerpf(lerpf(t00.x, t10.x, X.a), lerpf(t01.x, t11.x, X.a), Y.a), lerpf(lerpf(t00.y, t10.y, X.a), lerpf(t01.y, t11.y, X.a), Y.a),
+                                  lerpf(lerpf(t00.z, t10.z, X.a), lerpf(t01.z, t11.z, X.a), Y.a));
+    const float3 wp = tex3d_rgba_xyz(T.s[l].xyz, T.s[l].xyz_res, u, v, depth);
+    const float3 tc = normalize3(make_float3(P.cam[l][0] - wp.x, P.cam[l][1] - wp.y, P.cam[l][2] - wp.z));
+    const float angle = tc.x * wn.x + tc.y * wn.y + tc.z * wn.z;
+    q *= powf(angle, 2.0f);
+  }
+  B.dqs[base + (size_t)y * P.W + x].y = q;
+}
+
+void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR) {
+  const dim3 rows((P.W + 63) / 64, (P.H + 3) / 4, P.N), tiles((P.W + 15) / 16, (P.H + 15) / 16, P.N);
+  hipLaunchKernelGGL(k_pre_morph, rows, dim3(256), 0, st, P, B);
+  hipLaunchKernelGGL(k_pre_filter, tiles, dim3(256), 0, st, P, B, T, F);
+  hipLaunchKernelGGL(k_pre_boundary, rows, dim3(256), 0, st, P, B);
+  hipLaunchKernelGGL(k_pre_normal, rows, dim3(256), 0, st, P, B, T, BR);
+  hipLaunchKernelGGL(k_pre_quality, tiles, dim3(256), 0, st, P, B, T);
+}
+
+}  // namespace rr

@@ -112,6 +112,27 @@ struct Atlas {
   int res[TSDF_MAX_LODS][2];
 };
 
+// image pre-processing (k_preprocess.hip)
+struct PreParams {
+  int W, H, N;
+  float cv_min[TSDF_MAX_STREAMS], cv_max[TSDF_MAX_STREAMS];   // CalibVolumes::getDepthLimits
+  float cam[TSDF_MAX_STREAMS][3];                              // CalibVolumes::getCameraPositions
+  float bbox_min[3], bbox_max[3];
+  int filter_textures, refine;
+};
+struct PreBuffers {
+  const float* raw;       // [N][H][W] metres
+  float* depth2;          // morph output
+  const float* fdepth;    // what the filter pass samples: depth2 or raw (use_processed_depth)
+  float2* depth_rg;       // filter output (normalised depth, range quality)
+  float4* lab;            // filter output, Lab colour
+  float2* depth_b;        // boundary output
+  float4* normal;         // normal output
+  float4* dqs;            // packed {depth.r, quality, silhouette, 0}
+  float* depth_plane;
+};
+void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR);
+
 // launchers (one per kernel family, defined in the .hip files)
 void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, size_t n);
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);

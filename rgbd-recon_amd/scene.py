@@ -8,6 +8,8 @@ smoke() all feed the path from this closed-form generator:
 * colour LUT   ``cv_uv``      RG32F   identity on (u, v)
 * inverse LUT  ``cv_xyz_inv`` RGBA32F unit-cube voxel -> (u, v, d_norm, 1), (-1,-1,-1,-1) outside the
   frustum (framework/calibration/calibration_inverter.cpp:87-101)
+* raw sensor input for the pre-processing passes: ``depth_raw`` R32F metres (1 % random holes), ``color`` RGB8,
+  ``camera_positions`` (CalibVolumes::getCameraPositions)
 * per stream images in the formats NetKinectArray hands to the path (framework/NetKinectArray.cpp:159-188):
   depth RG32F (r = normalised depth, 0 = invalid), quality R32F, silhouette R32F, normals RGB32F, colour RGB8
 
@@ -163,8 +165,10 @@ def make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128, see
     quality = np.zeros((n_streams, height, width), np.float32)
     silhouette = np.zeros((n_streams, height, width), np.float32)
     normals = np.zeros((n_streams, height, width, 3), np.float32)
+    depth_raw = np.zeros((n_streams, height, width), np.float32)
     color = np.zeros((n_streams, ch, cw, 3), np.uint8)
     noise = rng.integers(0, 4, size=(n_streams, ch, cw, 3), dtype=np.uint8)
+    drop = rng.random((n_streams, height, width)) < 0.01                      # sensor holes for the morph pass to close (drawn after `noise`: golden fixtures)
     for k, cam in enumerate(cams):
         a = (px - cam.cx) / cam.f
         b = (py - cam.cy) / cam.f
@@ -188,6 +192,7 @@ def make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128, see
         cos_t = np.clip(np.einsum("...k,...k->...", nrm, to_cam), 0.0, 1.0)
         with np.errstate(divide="ignore", invalid="ignore"):
             q = np.clip(cos_t ** 2 / (6.5 * dnorm), 0.05, 4.0)                 # shape of pre_quality.fs:107-114
+        depth_raw[k] = np.where(hit & ~drop[k], tt, 0.0)                              # metres along the optical axis, 0 = no return
         depth[k, ..., 0] = np.where(valid, dnorm, 0.0)
         quality[k] = np.where(valid, q, 0.0)
         silhouette[k] = valid.astype(np.float32)
@@ -202,5 +207,6 @@ def make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128, see
         base = base + (np.array([0, 8 * (k + 1), 0]))                          # per-stream tint
         col = np.where(vc[..., None], base, 16) + noise[k]
         color[k] = np.clip(col, 0, 255).astype(np.uint8)
-    out.update(depth=depth, quality=quality, silhouette=silhouette, normals=normals, color=color)
+    out.update(depth=depth, quality=quality, silhouette=silhouette, normals=normals, color=color, depth_raw=depth_raw,
+               camera_positions=np.stack([c.pos for c in cams]).astype(np.float32))
     return out
