@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"], help="N > 1: integrate the halo layers locally, or RCCL all-gather them")
     ap.add_argument("--composite", default="compact", choices=["compact", "dense"], help="N > 1: gather hit records, or whole partial images")
+    ap.add_argument("--preprocess", action="store_true", help="also run the image pre-processing passes (f1) every frame, from the raw depth/colour")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true", help="leave the per-kernel HIP event timers off")
     args = ap.parse_args()
@@ -122,7 +123,9 @@ def main():
     hip.setUseBricks(cfg["use_bricks"]); hip.setSpaceSkip(cfg["skip_space"]); hip.setColorFilling(cfg["fill_holes"])
     stream = torch.cuda.current_stream()
     hip.set_stream(stream.cuda_stream)         # kernels, HIP event timers and the collectives share one stream
-    drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite)
+    if args.preprocess:
+        hip.upload_raw_frame(scene)
+    drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite, preprocess=args.preprocess)
     mv, pr = rr.scene.default_view(*VIEW)
 
     def barrier():
@@ -155,7 +158,7 @@ def main():
     # per-kernel device time from HIP events recorded on the launch stream during the timed region
     stages = {}
     if not args.no_timers:
-        for name in ("bricks", "2integrate", "brickdraw", "draw", "holefill", "3recon"):
+        for name in ("1preprocess", "bricks", "2integrate", "brickdraw", "draw", "holefill", "3recon"):
             n, ms = hip.timer_stats(name)
             if n:
                 stages[name] = ms / n
@@ -167,7 +170,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "config": args.config, "streams": cfg["streams"], "res": list(cfg["res"]),
-                   "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio,
+                   "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
                    "parallelism": "single GPU" if world == 1 else f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0"},
         "stage_ms": stages,
         "upload_ms_per_frame": upload_ms,

@@ -47,10 +47,11 @@ class SlabDriver:
                the slab (the counts travel first so that only max(count) records per rank are gathered).
     """
 
-    def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense"):
+    def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense", preprocess=False):
         assert halo in ("exchange", "recompute") and composite in ("dense", "compact")
         self.b, self.rank, self.world, self.dev, self.group = backend, rank, world, torch.device(buf_device), group
         self.view, self.halo, self.composite = view, halo, composite
+        self.preprocess = preprocess          # frames start from the raw sensor images: processTextures() instead of markBricks()
         self.stage_cpu = world > 1 and dist.get_backend(group) == "gloo" and self.dev.type == "cuda"
         if world > 1:
             npx = view[0] * view[1]
@@ -98,7 +99,10 @@ class SlabDriver:
     def frame(self, mv, proj):
         b = self.b
         b.clearOccupiedBricks()
-        b.markBricks()
+        if self.preprocess:
+            b.processTextures()
+        else:
+            b.markBricks()
         b.updateOccupiedBricks(False)
         b.integrate()
         if self.world == 1:
