@@ -25,6 +25,11 @@ CONFIGS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on (512^3 x 4 streams, cull + inpaint)
     "c2": dict(res=(512, 512, 512), streams=4, use_bricks=True, skip_space=True, fill_holes=True,
                name="512^3 TSDF x 4 streams 640x480, 1280x720 view, brick cull (8^3-voxel bricks) + inpaint"),
+    # BASELINE.json configs[3] / configs[4] (quoted on 8 GPUs; they also fit one MI355X: 1024^3 is a 4 GiB volume)
+    "c3": dict(res=(512, 512, 512), streams=8, use_bricks=True, skip_space=True, fill_holes=True,
+               name="512^3 TSDF x 8 streams 640x480, 1280x720 view, brick cull (8^3-voxel bricks) + inpaint"),
+    "c4": dict(res=(1024, 1024, 1024), streams=8, use_bricks=True, skip_space=True, fill_holes=True,
+               name="1024^3 TSDF x 8 streams 640x480, 1280x720 view, brick cull (8^3-voxel bricks) + inpaint"),
     # BASELINE.json configs[1]
     "c1": dict(res=(256, 256, 256), streams=4, use_bricks=False, skip_space=False, fill_holes=False,
                name="256^3 TSDF x 4 streams 640x480, 1280x720 view, dense integrate + raymarch"),
@@ -165,7 +170,7 @@ def main():
     ratio = hip.occupiedRatio()
     ab = algorithmic_bytes(cfg, cfg["streams"], world)
     out = {
-        "metric": "frames/sec (integrate+raymarch) at 512^3 x 4 streams" if args.config == "c2" else "frames/sec (integrate+raymarch) at 256^3 x 4 streams",
+        "metric": "frames/sec (integrate+raymarch) at %d^3 x %d streams" % (cfg["res"][0], cfg["streams"]),
         "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

@@ -84,6 +84,15 @@ int32_t tsdf_set_calibration(tsdf_ctx* ctx, uint32_t stream,
 int32_t tsdf_upload_frame(tsdf_ctx* ctx, const float* depth_rg, const float* quality,
                           const float* silhouette, const uint8_t* colour_rgb);
 
+/* ---- calibration volume files (format only): kinect::CalibrationVolume<T>::read / write,
+ * framework/calibration/calibration_volume.hpp:30-38,62-78 -- u32 res[3]; f32 depth_min, depth_max; T[res.x*res.y*res.z].
+ * texel_floats: 3 for *.cv_xyz (CalibrationVolume<xyz>), 2 for *.cv_uv, 4 for *.cv_xyz_inv (CalibVolumes.cpp:64-80,115-130).
+ * Host only, no context; errors: negative status + tsdf_calib_last_error(). */
+int32_t tsdf_calib_volume_info(const char* path, uint32_t texel_floats, uint32_t res[3], float depth_limits[2]);
+int32_t tsdf_calib_volume_read(const char* path, uint32_t texel_floats, float* data, uint64_t capacity_floats);
+int32_t tsdf_calib_volume_write(const char* path, uint32_t texel_floats, const uint32_t res[3], const float depth_limits[2], const float* data);
+const char* tsdf_calib_last_error(void);
+
 /* ---- image pre-processing: NetKinectArray::processTextures(), framework/NetKinectArray.cpp:309-426
  * Alternative to tsdf_upload_frame: hand over the RAW sensor frame (m_depthArray_raw R32F metres [N][H][W], colour RGB8,
  * NetKinectArray.cpp:147-176) and let tsdf_process_textures produce depth / quality / silhouette (and normals, Lab colour)

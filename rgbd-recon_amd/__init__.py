@@ -10,5 +10,5 @@ The directory name carries a hyphen (project naming); import it as ``rgbd_recon_
 the repository root) or with importlib.
 """
 from .binding import (ReconIntegrationHip, TsdfConfig, TsdfError, build_library, declared_symbols,  # noqa: F401
-                      load_library, LIB_PATH, HEADER_PATH)
+                      load_library, LIB_PATH, HEADER_PATH, read_calib_volume, write_calib_volume)
 from . import scene  # noqa: F401

@@ -71,6 +71,36 @@ def _f32(a):
     return np.ascontiguousarray(a, np.float32)
 
 
+# ---------------------------------------------------------------------- calibration volume files (host only)
+_TEXEL = {"cv_xyz": 3, "cv_uv": 2, "cv_xyz_inv": 4}
+
+
+def read_calib_volume(path, kind):
+    """Reads a *.cv_xyz / *.cv_uv / *.cv_xyz_inv file (calibration_volume.hpp:62-78) -> (array [rz][ry][rx][c], depth limits)."""
+    L = load_library()
+    L.tsdf_calib_last_error.restype = C.c_char_p
+    c = _TEXEL[kind]
+    res, lim = (C.c_uint32 * 3)(), (C.c_float * 2)()
+    if L.tsdf_calib_volume_info(path.encode(), c, res, lim) != 0:
+        raise TsdfError(-1, L.tsdf_calib_last_error().decode())
+    out = np.empty((res[2], res[1], res[0], c), np.float32)
+    if L.tsdf_calib_volume_read(path.encode(), c, _fp(out), C.c_uint64(out.size)) != 0:
+        raise TsdfError(-1, L.tsdf_calib_last_error().decode())
+    return out, (lim[0], lim[1])
+
+
+def write_calib_volume(path, kind, volume, depth_limits):
+    """Writes volume [rz][ry][rx][c] in the reference's on-disk format (calibration_volume.hpp:30-38)."""
+    L = load_library()
+    L.tsdf_calib_last_error.restype = C.c_char_p
+    v = _f32(volume)
+    assert v.ndim == 4 and v.shape[3] == _TEXEL[kind]
+    res = (C.c_uint32 * 3)(v.shape[2], v.shape[1], v.shape[0])
+    lim = (C.c_float * 2)(*[float(x) for x in depth_limits])
+    if L.tsdf_calib_volume_write(path.encode(), _TEXEL[kind], res, lim, _fp(v)) != 0:
+        raise TsdfError(-1, L.tsdf_calib_last_error().decode())
+
+
 class ReconIntegrationHip:
     """HIP drop-in for kinect::ReconIntegration.  `scene` supplies what CalibrationFiles / CalibVolumes /
     NetKinectArray hold in the reference (rgbd-recon_amd/scene.py layout)."""
