@@ -95,9 +95,14 @@ def main():
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"], help="N > 1: integrate the halo layers locally, or RCCL all-gather them")
     ap.add_argument("--composite", default="compact", choices=["compact", "dense"], help="N > 1: gather hit records, or whole partial images")
     ap.add_argument("--preprocess", action="store_true", help="also run the image pre-processing passes (f1) every frame, from the raw depth/colour")
+    ap.add_argument("--ingest", default=None, choices=["f32-rgb8", "f32-dxt1", "u8-rgb8", "u8-dxt1", "u8-dxt5"],
+                    help="also measure the wire path (f2): every frame arrives as one host message, is copied through the pinned double "
+                         "buffer, unpacked/decoded on the GPU and pre-processed (implies --preprocess); reported beside `value`, never as it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true", help="leave the per-kernel HIP event timers off")
     args = ap.parse_args()
+    if args.ingest:
+        args.preprocess = True
 
     import numpy as np
     import torch                      # first: the HIP runtime torch bundles is the one the library binds to
@@ -194,6 +199,34 @@ def main():
         frame_bytes = ab["integrate"] + ab["raymarch"] + (ab["inpaint"] if cfg["fill_holes"] else 0)
         out["frame_roofline"] = {"algorithmic_bytes": frame_bytes, "achieved": frame_bytes / (dt / args.steps) / 1e9,
                                  "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
+    if args.ingest and world == 1:
+        dfmt, cfmt = args.ingest.split("-")
+        cf, df = {"rgb8": rr.COLOR_RGB8, "dxt1": rr.COLOR_DXT1, "dxt5": rr.COLOR_DXT5}[cfmt], {"f32": rr.DEPTH_F32, "u8": rr.DEPTH_U8}[dfmt]
+        msg = rr.scene.make_wire_message(scene, cf, df, timestamp=1.0)
+        hip.setWireFormat(cf, df)
+        for i in range(cfg["streams"]):
+            hip.setDepthCompression(i, df == rr.DEPTH_U8, 0.5, 4.5)
+        if df == rr.DEPTH_U8:
+            # pre_morph.fs validates the normalised 8-bit codes against 0.5..4.5 "metres" (reference quirk):
+            # with processed depth on, everything nearer than code 128 is dropped.  Run the 8-bit path the way it works.
+            hip.setPreprocess(processed_depth=False)
+        k = max(10, args.steps // 4)
+        for _ in range(3):
+            hip.upload_wire_frame(msg, scene); drv.frame(mv, pr)
+        barrier()
+        hip.enable_timers(not args.no_timers)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            hip.upload_wire_frame(msg)
+            drv.frame(mv, pr)
+        barrier()
+        dti = (time.perf_counter() - t0) / k
+        hip.enable_timers(False)
+        n_u, ms_u = hip.timer_stats("0ingest") if not args.no_timers else (0, 0.0)
+        out["ingest"] = {"format": args.ingest, "message_bytes": len(msg), "frames": k, "wire_to_frame_ms": dti * 1e3,
+                         "wire_inclusive_frames_per_s": 1.0 / dti, "gpu_unpack_ms": (ms_u / n_u) if n_u else None,
+                         "note": "host message -> pinned copy -> H2D -> GPU unpack/DXT decode -> pre-process -> integrate -> drawF, "
+                                 "one frame in flight; `value` above stays the HBM-resident rate"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, cfg, limit, brick)
     if rank == 0:

@@ -93,6 +93,31 @@ int32_t tsdf_calib_volume_read(const char* path, uint32_t texel_floats, float* d
 int32_t tsdf_calib_volume_write(const char* path, uint32_t texel_floats, const uint32_t res[3], const float depth_limits[2], const float* data);
 const char* tsdf_calib_last_error(void);
 
+/* host-only reader of recordings/<sensor>.stream (sys::FileBuffer as used by NetKinectArray::readFromFiles,
+ * framework/NetKinectArray.cpp:709-749; framework/io/FileBuffer.cpp:60-62,90-110): raw records [colour][depth] back to back.
+ * One record of every sensor's file, concatenated in sensor order, is exactly one wire message for tsdf_upload_wire_frame. */
+int32_t tsdf_stream_num_frames(const char* path, uint64_t record_bytes, uint64_t* frames);
+int32_t tsdf_stream_read_record(const char* path, uint64_t record_bytes, uint64_t frame, void* out);
+
+/* ---- frame ingest: NetKinectArray::init / readLoop / update,
+ * framework/NetKinectArray.cpp:113-142 (sizes), :482-529 (message layout), :225-236 (upload).
+ * A message is, per sensor, [colour: colorsize bytes][depth: depthsize bytes]; its first 8 bytes double as the frame's
+ * timestamp (:510 -- they overlay the first colour bytes, offset starts at 0 at :513).
+ * tsdf_upload_wire_frame copies the message through a pinned double buffer to HBM (asynchronous on the context's stream)
+ * and unpacks it on the GPU into what tsdf_process_textures reads; it replaces tsdf_upload_raw_frame for wire input. */
+#define TSDF_COLOR_RGB8 0u   /* CalibrationFiles::isCompressedRGB() == 0: w*h*3 bytes                      (:129) */
+#define TSDF_COLOR_DXT1 1u   /*  == 1: S3TC DXT1 blocks, w*h/2 bytes                                     (:118-121) */
+#define TSDF_COLOR_DXT5 5u   /*  == 5: S3TC DXT5 blocks, w*h bytes                                       (:123-126) */
+#define TSDF_DEPTH_F32 0u    /* isCompressedDepth() false: float32 metres                                  (:138-141) */
+#define TSDF_DEPTH_U8 1u     /* true: 8 bit, read normalised (c/255); metres = uncompress(), glsl/pre_depth.fs:51-61 */
+int32_t tsdf_set_wire_format(tsdf_ctx* ctx, uint32_t color_format, uint32_t depth_format);
+int32_t tsdf_wire_sizes(tsdf_ctx* ctx, uint64_t* colorsize, uint64_t* depthsize, uint64_t* message_bytes);
+/* per sensor: KinectCalibrationFile::isCompressedDepth(), getNear(), getFar() (NetKinectArray.cpp:343-349) */
+int32_t tsdf_set_depth_compression(tsdf_ctx* ctx, uint32_t stream, int32_t compressed, float near_m, float far_m);
+int32_t tsdf_upload_wire_frame(tsdf_ctx* ctx, const void* message, uint64_t bytes, double* timestamp /* may be NULL */);
+/* what the unpack produced: raw depth [N][H][W] float, colour [N][ch][cw][4] RGBA8 (either may be NULL) */
+int32_t tsdf_download_raw_frame(tsdf_ctx* ctx, float* depth_raw, uint8_t* colour_rgba);
+
 /* ---- image pre-processing: NetKinectArray::processTextures(), framework/NetKinectArray.cpp:309-426
  * Alternative to tsdf_upload_frame: hand over the RAW sensor frame (m_depthArray_raw R32F metres [N][H][W], colour RGB8,
  * NetKinectArray.cpp:147-176) and let tsdf_process_textures produce depth / quality / silhouette (and normals, Lab colour)

@@ -125,6 +125,27 @@ class OracleRecon:
             self._L.orc_set_depth_limits(self._c, i, C.c_float(float(scene["depth_limits"][0])), C.c_float(float(scene["depth_limits"][1])))
             self._L.orc_set_camera_position(self._c, i, _p(_f32(scene["camera_positions"][i])))
 
+    # --- frame ingest (readLoop / readFromFiles / update(), NetKinectArray.cpp:482-529, :709-749, :225-236)
+    def setDepthCompression(self, stream, compress, near, far):
+        self._L.orc_set_depth_compression(self._c, stream, int(compress), C.c_float(near), C.c_float(far))
+
+    def upload_wire_frame(self, message, color_format=0, depth_format=0):
+        """message: bytes of one ZMQ message / one record per .stream file, per sensor [colour][depth]."""
+        sc = self.scene
+        n, w, h, cw, ch = sc["n"], sc["width"], sc["height"], sc["color_width"], sc["color_height"]
+        ts, cols, deps = wire_split(message, n, *wire_sizes(w, h, cw, ch, color_format, depth_format))
+        col = np.zeros((n, ch, cw, 3), np.uint8)
+        raw = np.zeros((n, h, w), np.float32)
+        for i in range(n):
+            col[i] = cols[i].reshape(ch, cw, 3) if color_format == 0 else decode_dxt(cols[i], cw, ch, color_format)[..., :3]
+            if depth_format == 0:
+                raw[i] = deps[i].view(np.float32).reshape(h, w)
+            else:   # GL_LUMINANCE from GL_UNSIGNED_BYTE: normalised, c / 255 (NetKinectArray.cpp:171)
+                raw[i] = (deps[i].astype(np.float32) / np.float32(255.0)).reshape(h, w)
+        self._raw = (np.ascontiguousarray(raw), np.ascontiguousarray(col))
+        self._L.orc_set_raw_frame(self._c, _p(self._raw[0]), _p(self._raw[1], C.c_uint8))
+        return ts
+
     def setPreprocess(self, filter_textures=True, processed_depth=True, refine=True):
         self._L.orc_set_preprocess_flags(self._c, int(filter_textures), int(processed_depth), int(refine))
 
@@ -213,6 +234,31 @@ class OracleRecon:
         out = np.zeros(35, np.float32)
         self._L.orc_view_matrices(self._c, _p(_f32(mv)), _p(_f32(proj)), _p(out))
         return out[:16].copy(), out[16:32].copy(), out[32:35].copy()
+
+
+# --- frame ingest helpers
+def wire_sizes(w, h, cw, ch, color_format, depth_format):
+    """(m_colorsize, m_depthsize), NetKinectArray::init, NetKinectArray.cpp:118-139."""
+    cs = {0: cw * ch * 3, 1: cw * ch // 2, 5: cw * ch}[color_format]        # RGB8 / DXT1 (fastdxt w*h*4/8) / DXT5 (307200 at 640x480)
+    ds = w * h * (1 if depth_format else 4)
+    return cs, ds
+
+
+def wire_split(message, n, cs, ds):
+    """readLoop(), NetKinectArray.cpp:513-523: the timestamp is the first 8 bytes OF the first colour image (offset starts at 0)."""
+    m = np.frombuffer(message, np.uint8)
+    assert m.size == (cs + ds) * n
+    ts = float(m[:8].view(np.float64)[0])
+    cols = [m[i * (cs + ds): i * (cs + ds) + cs] for i in range(n)]
+    deps = [m[i * (cs + ds) + cs: (i + 1) * (cs + ds)] for i in range(n)]
+    return ts, cols, deps
+
+
+def decode_dxt(blocks, w, h, fmt):
+    b = np.ascontiguousarray(blocks, np.uint8)
+    out = np.zeros((h, w, 4), np.uint8)
+    lib().orc_decode_dxt(_p(b, C.c_uint8), w, h, fmt, _p(out, C.c_uint8))
+    return out
 
 
 # --- sampling primitives (unit tests)

@@ -181,6 +181,8 @@ struct orc_ctx {
   const float* raw_depth = nullptr;                    // [N][H][W] metres (m_depthArray_raw, R32F, NEAREST)
   float cv_min_d[16], cv_max_d[16];                    // CalibVolumes::getDepthLimits(i)
   vec3 cam_pos[16];                                    // CalibVolumes::getCameraPositions()
+  bool compress[16] = {};                              // KinectCalibrationFile::isCompressedDepth(), NetKinectArray.cpp:343
+  float dc_near[16] = {}, dc_scale[16] = {}, dc_scaled_near[16] = {};   // uniforms near / scale / scaled_near, :344-349
   bool filter_textures = true, use_processed_depth = true, refine_bound = true;   // NetKinectArray.cpp:63-69
   std::vector<float> pp_depth2, pp_depth_rg, pp_lab, pp_depth_b, pp_sil, pp_normal, pp_quality;
   // view state
@@ -834,6 +836,11 @@ void orc_set_view(orc_ctx* c, const float* rgba, const float* depth) {
 void orc_set_raw_frame(orc_ctx* c, const float* raw_depth, const uint8_t* color_rgb) { c->raw_depth = raw_depth; c->color = color_rgb; }
 void orc_set_depth_limits(orc_ctx* c, uint32_t i, float mn, float mx) { c->cv_min_d[i] = mn; c->cv_max_d[i] = mx; }
 void orc_set_camera_position(orc_ctx* c, uint32_t i, const float* p) { c->cam_pos[i] = {p[0], p[1], p[2]}; }
+// NetKinectArray.cpp:343-349: compress = isCompressedDepth(); scale = far - near; scaled_near = scale / 255.0f
+void orc_set_depth_compression(orc_ctx* c, uint32_t i, int compress, float near_, float far_) {
+  const float scale = far_ - near_;
+  c->compress[i] = compress != 0; c->dc_near[i] = near_; c->dc_scale[i] = scale; c->dc_scaled_near[i] = scale / 255.0f;
+}
 void orc_set_preprocess_flags(orc_ctx* c, int filter_textures, int processed_depth, int refine) {
   c->filter_textures = filter_textures; c->use_processed_depth = processed_depth; c->refine_bound = refine;
 }
@@ -903,7 +910,13 @@ void orc_process_textures(orc_ctx* c) {
       for (int x = 0; x < W; ++x) {
         float u, v; tc(x, y, u, v);
         const float mn = c->cv_min_d[l], mx = c->cv_max_d[l];
-        auto smp = [&](float uu, float vv) { return tex2d_nearest(fdepth, 1, W, H, l, uu, vv, 0); };
+        // sample(), pre_depth.fs:63-72, with uncompress() :51-61 (sqrt mapping of the 8-bit wire depth)
+        auto smp = [&](float uu, float vv) {
+          const float t = tex2d_nearest(fdepth, 1, W, H, l, uu, vv, 0);
+          if (!c->compress[l]) return t;
+          if (t < c->dc_scaled_near[l]) return 0.0f;
+          return (t * t + 0.15f * c->dc_scaled_near[l]) * c->dc_scale[l] + c->dc_near[l];
+        };
         auto norm = [&](float d) { return (d - mn) / (mx - mn); };
         const float depth = smp(u, v);
         const float dn = norm(depth);
@@ -1048,6 +1061,60 @@ float orc_tex2d_nearest(const float* t, int nc, int w, int h, int layer, float u
 void orc_view_matrices(orc_ctx* c, const float* mv, const float* proj, float* out /* img_to_eye, normal, cam_vol(3) */) {
   view_mats V = make_view(c, mv, proj);
   memcpy(out, V.img_to_eye.m, 64); memcpy(out + 16, V.normal.m, 64); out[32] = V.cam_vol.x; out[33] = V.cam_vol.y; out[34] = V.cam_vol.z;
+}
+
+
+// ================================================================= frame ingest
+// S3TC block decode.  The reference hands DXT1/DXT5 colour to GL as GL_COMPRESSED_RGBA_S3TC_DXT{1,5}_EXT
+// (NetKinectArray.cpp:147-154) and decodes the same blocks on the CPU with its vendored squish
+// (external/squish, NetKinectArray.cpp:620).  GL leaves the interpolation precision to the implementation; the
+// integer decode of squish is the definition used here (colourblock.cpp:160-212, alpha.cpp:297-348: 565 endpoints
+// expanded by bit replication, (2a+b)/3 and (a+b)/2 in integer arithmetic; DXT1 three-colour mode -> transparent black).
+// blocks: row-major 4x4 blocks, 8 bytes (DXT1) or 16 bytes (DXT5: alpha block then colour block); rgba: [h][w][4].
+static void dxt_endpoint(const uint8_t* b, int out[3]) {
+  const int v = b[0] | (b[1] << 8);
+  const int r = (v >> 11) & 31, g = (v >> 5) & 63, bl = v & 31;
+  out[0] = (r << 3) | (r >> 2); out[1] = (g << 2) | (g >> 4); out[2] = (bl << 3) | (bl >> 2);
+}
+void orc_decode_dxt(const uint8_t* blocks, int w, int h, int format, uint8_t* rgba) {
+  const int bpb = format == 1 ? 8 : 16;
+  size_t k = 0;
+  for (int by = 0; by < h; by += 4)
+    for (int bx = 0; bx < w; bx += 4, ++k) {
+      const uint8_t* blk = blocks + k * bpb;
+      const uint8_t* cb = format == 1 ? blk : blk + 8;
+      int e0[3], e1[3];
+      dxt_endpoint(cb, e0); dxt_endpoint(cb + 2, e1);
+      const int a = cb[0] | (cb[1] << 8), b = cb[2] | (cb[3] << 8);
+      const bool three = format == 1 && a <= b;
+      uint8_t pal[4][4];
+      for (int i = 0; i < 3; ++i) {
+        pal[0][i] = (uint8_t)e0[i]; pal[1][i] = (uint8_t)e1[i];
+        pal[2][i] = (uint8_t)(three ? (e0[i] + e1[i]) / 2 : (2 * e0[i] + e1[i]) / 3);
+        pal[3][i] = (uint8_t)(three ? 0 : (e0[i] + 2 * e1[i]) / 3);
+      }
+      pal[0][3] = pal[1][3] = pal[2][3] = 255; pal[3][3] = three ? 0 : 255;
+      uint8_t alpha[16];
+      if (format != 1) {
+        const int a0 = blk[0], a1 = blk[1];
+        uint8_t at[8];
+        at[0] = (uint8_t)a0; at[1] = (uint8_t)a1;
+        if (a0 <= a1) { for (int i = 1; i < 5; ++i) at[1 + i] = (uint8_t)(((5 - i) * a0 + i * a1) / 5); at[6] = 0; at[7] = 255; }
+        else for (int i = 1; i < 7; ++i) at[1 + i] = (uint8_t)(((7 - i) * a0 + i * a1) / 7);
+        uint64_t bits = 0;
+        for (int i = 0; i < 6; ++i) bits |= (uint64_t)blk[2 + i] << (8 * i);
+        for (int i = 0; i < 16; ++i) alpha[i] = at[(bits >> (3 * i)) & 7];
+      }
+      for (int py = 0; py < 4; ++py)
+        for (int px = 0; px < 4; ++px) {
+          const int x = bx + px, y = by + py;
+          if (x >= w || y >= h) continue;
+          const int idx = (cb[4 + py] >> (2 * px)) & 3;
+          uint8_t* o = rgba + 4 * ((size_t)y * w + x);
+          o[0] = pal[idx][0]; o[1] = pal[idx][1]; o[2] = pal[idx][2];
+          o[3] = format == 1 ? pal[idx][3] : alpha[4 * py + px];
+        }
+    }
 }
 
 }  // extern "C"

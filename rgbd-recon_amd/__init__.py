@@ -10,5 +10,6 @@ The directory name carries a hyphen (project naming); import it as ``rgbd_recon_
 the repository root) or with importlib.
 """
 from .binding import (ReconIntegrationHip, TsdfConfig, TsdfError, build_library, declared_symbols,  # noqa: F401
-                      load_library, LIB_PATH, HEADER_PATH, read_calib_volume, write_calib_volume)
+                      load_library, LIB_PATH, HEADER_PATH, read_calib_volume, write_calib_volume,
+                      read_stream_record, stream_num_frames, COLOR_RGB8, COLOR_DXT1, COLOR_DXT5, DEPTH_F32, DEPTH_U8)
 from . import scene  # noqa: F401

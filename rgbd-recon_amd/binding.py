@@ -101,6 +101,30 @@ def write_calib_volume(path, kind, volume, depth_limits):
         raise TsdfError(-1, L.tsdf_calib_last_error().decode())
 
 
+def stream_num_frames(path, record_bytes):
+    """FileBuffer::calcNumFrames for recordings/<sensor>.stream."""
+    L = load_library()
+    L.tsdf_calib_last_error.restype = C.c_char_p
+    n = C.c_uint64()
+    if L.tsdf_stream_num_frames(path.encode(), C.c_uint64(record_bytes), C.byref(n)) != 0:
+        raise TsdfError(-1, L.tsdf_calib_last_error().decode())
+    return n.value
+
+
+def read_stream_record(path, record_bytes, frame):
+    """Record `frame` ([colour][depth]) of one sensor's .stream file (NetKinectArray::readFromFiles)."""
+    L = load_library()
+    L.tsdf_calib_last_error.restype = C.c_char_p
+    out = np.empty(record_bytes, np.uint8)
+    if L.tsdf_stream_read_record(path.encode(), C.c_uint64(record_bytes), C.c_uint64(frame), out.ctypes.data_as(C.c_void_p)) != 0:
+        raise TsdfError(-1, L.tsdf_calib_last_error().decode())
+    return out
+
+
+COLOR_RGB8, COLOR_DXT1, COLOR_DXT5 = 0, 1, 5
+DEPTH_F32, DEPTH_U8 = 0, 1
+
+
 class ReconIntegrationHip:
     """HIP drop-in for kinect::ReconIntegration.  `scene` supplies what CalibrationFiles / CalibVolumes /
     NetKinectArray hold in the reference (rgbd-recon_amd/scene.py layout)."""
@@ -131,6 +155,7 @@ class ReconIntegrationHip:
         self._c = ctx
         self.view = tuple(view)
         self.n = scene["n"]
+        self._dims = (scene["height"], scene["width"], scene["color_height"], scene["color_width"])
         r3, b3, s3 = (C.c_uint32 * 3)(), (C.c_uint32 * 3)(), (C.c_float * 3)()
         self._ck(self._L.tsdf_get_resolution(self._c, r3, b3, s3))
         self.res, self.res_bricks, self.brick_size = tuple(r3), tuple(b3), tuple(s3)
@@ -183,6 +208,38 @@ class ReconIntegrationHip:
             self._ck(self._L.tsdf_set_depth_limits(self._c, i, C.c_float(float(scene["depth_limits"][0])), C.c_float(float(scene["depth_limits"][1]))))
             self._ck(self._L.tsdf_set_camera_position(self._c, i, _fp(_f32(scene["camera_positions"][i]))))
         self._pp_shape = (self.n, scene["height"], scene["width"])
+
+    # ------------------------------------------------------------------ frame ingest: wire message -> raw frame (readLoop / update)
+    def setWireFormat(self, color_format=COLOR_RGB8, depth_format=DEPTH_F32):
+        self._ck(self._L.tsdf_set_wire_format(self._c, int(color_format), int(depth_format)))
+
+    def wireSizes(self):
+        cs, ds, total = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ck(self._L.tsdf_wire_sizes(self._c, C.byref(cs), C.byref(ds), C.byref(total)))
+        return cs.value, ds.value, total.value
+
+    def setDepthCompression(self, stream, compressed, near, far):
+        self._ck(self._L.tsdf_set_depth_compression(self._c, int(stream), int(compressed), C.c_float(near), C.c_float(far)))
+
+    def upload_wire_frame(self, message, scene=None):
+        """message: bytes-like, per sensor [colour][depth]; returns the timestamp in its first 8 bytes."""
+        m = np.frombuffer(message, np.uint8)
+        ts = C.c_double()
+        self._ck(self._L.tsdf_upload_wire_frame(self._c, m.ctypes.data_as(C.c_void_p), C.c_uint64(m.size), C.byref(ts)))
+        if scene is not None:
+            for i in range(self.n):
+                self._ck(self._L.tsdf_set_depth_limits(self._c, i, C.c_float(float(scene["depth_limits"][0])), C.c_float(float(scene["depth_limits"][1]))))
+                self._ck(self._L.tsdf_set_camera_position(self._c, i, _fp(_f32(scene["camera_positions"][i]))))
+            self._pp_shape = (self.n, scene["height"], scene["width"])
+        return ts.value
+
+    def raw_frame(self):
+        """(raw depth [N][H][W], colour RGBA8 [N][ch][cw][4]) as unpacked on the GPU."""
+        h, w, ch, cw = self._dims
+        d = np.zeros((self.n, h, w), np.float32)
+        col = np.zeros((self.n, ch, cw, 4), np.uint8)
+        self._ck(self._L.tsdf_download_raw_frame(self._c, _fp(d), col.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return d, col
 
     def setPreprocess(self, filter_textures=True, processed_depth=True, refine=True):
         self._ck(self._L.tsdf_set_preprocess(self._c, int(filter_textures), int(processed_depth), int(refine)))

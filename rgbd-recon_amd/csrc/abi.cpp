@@ -64,6 +64,10 @@ struct tsdf_ctx {
   float* d_raw = nullptr; float* d_depth2 = nullptr; float2* d_depth_rg = nullptr; float4* d_lab = nullptr; float2* d_depth_b = nullptr; float4* d_normal = nullptr;
   bool have_raw = false, use_processed_depth = true;
   bool have_limits[TSDF_MAX_STREAMS]{}, have_cam[TSDF_MAX_STREAMS]{};
+  // frame ingest (readLoop / update): wire formats, pinned double buffer (the reference's double_pbo), device copy of the message
+  uint32_t color_format = TSDF_COLOR_RGB8, depth_format = TSDF_DEPTH_F32;
+  uint8_t* h_wire[2]{}; hipEvent_t wire_done[2]{}; bool wire_pending[2]{}; int wire_slot = 0;
+  uint8_t* d_wire = nullptr; size_t wire_capacity = 0;
   // view
   int vw = 0, vh = 0;
   Atlas atlas{};
@@ -446,6 +450,8 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipFree(c->d_depth_plane); hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
   for (void* p : c->lut_allocs) hipFree(p);
   if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
+  for (int k = 0; k < 2; ++k) { if (c->h_wire[k]) hipHostFree(c->h_wire[k]); if (c->wire_done[k]) hipEventDestroy(c->wire_done[k]); }
+  hipFree(c->d_wire);
   for (auto& kv : c->timers) for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -527,12 +533,9 @@ int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quali
 }
 
 // ---- image pre-processing (NetKinectArray::processTextures)
-int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour) {
-  CHECK_CTX(c);
-  if (!depth_raw || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "raw depth and colour are required");
-  HIP_TRY(c, hipSetDevice(c->device));
+static int32_t ensure_pre_buffers(tsdf_ctx* c) {
   const FrameImages& F = c->frame;
-  const size_t np = (size_t)c->cfg.num_streams * F.w * F.h, nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
+  const size_t np = (size_t)c->cfg.num_streams * F.w * F.h;
   if (!c->d_raw) {
     HIP_TRY(c, hipMalloc(&c->d_raw, np * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->d_depth2, np * sizeof(float)));
@@ -542,6 +545,15 @@ int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t
     HIP_TRY(c, hipMalloc(&c->d_normal, np * sizeof(float4)));
     HIP_TRY(c, hipMemsetAsync((void*)F.dqs, 0, np * sizeof(float4), c->stream));
   }
+  return TSDF_OK;
+}
+int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour) {
+  CHECK_CTX(c);
+  if (!depth_raw || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "raw depth and colour are required");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const FrameImages& F = c->frame;
+  const size_t np = (size_t)c->cfg.num_streams * F.w * F.h, nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
+  if (int32_t rc = ensure_pre_buffers(c)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_raw, depth_raw, np * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
   launch_pack_color(c->stream, c->d_stage_col, (uchar4*)F.color, nc);
@@ -560,6 +572,89 @@ int32_t tsdf_set_camera_position(tsdf_ctx* c, uint32_t i, const float xyz[3]) {
   if (i >= c->cfg.num_streams || !xyz) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "bad stream index");
   for (int a = 0; a < 3; ++a) c->pre.cam[i][a] = xyz[a];
   c->have_cam[i] = true;
+  return TSDF_OK;
+}
+
+// ---- frame ingest (NetKinectArray::init sizes :118-139, readLoop :482-529, update :225-236)
+static void wire_sizes(const tsdf_ctx* c, uint32_t cf, uint32_t df, uint64_t* cs, uint64_t* ds) {
+  const uint64_t cp = (uint64_t)c->frame.cw * c->frame.ch, dp = (uint64_t)c->frame.w * c->frame.h;
+  *cs = cf == TSDF_COLOR_DXT1 ? cp * 4 / 8 : (cf == TSDF_COLOR_DXT5 ? cp : cp * 3);     // :118-130 (DXT5: the literal 307200 = 640*480)
+  *ds = df == TSDF_DEPTH_U8 ? dp : dp * 4;                                               // :134-141
+}
+int32_t tsdf_set_wire_format(tsdf_ctx* c, uint32_t color_format, uint32_t depth_format) {
+  CHECK_CTX(c);
+  if (color_format != TSDF_COLOR_RGB8 && color_format != TSDF_COLOR_DXT1 && color_format != TSDF_COLOR_DXT5) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "colour format must be 0 (RGB8), 1 (DXT1) or 5 (DXT5)");
+  if (depth_format != TSDF_DEPTH_F32 && depth_format != TSDF_DEPTH_U8) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "depth format must be 0 (float32) or 1 (8 bit)");
+  uint64_t cs, ds;
+  wire_sizes(c, color_format, depth_format, &cs, &ds);
+  if ((cs & 15) || (ds & 15)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "image sizes give records that are not 16-byte multiples (colour %llu, depth %llu bytes)", (unsigned long long)cs, (unsigned long long)ds);
+  if (color_format != TSDF_COLOR_RGB8 && ((c->frame.cw | c->frame.ch) & 3)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "DXT colour needs a resolution that is a multiple of 4 (the wire size w*h/2 assumes it)");
+  c->color_format = color_format; c->depth_format = depth_format;
+  return TSDF_OK;
+}
+int32_t tsdf_wire_sizes(tsdf_ctx* c, uint64_t* colorsize, uint64_t* depthsize, uint64_t* message_bytes) {
+  CHECK_CTX(c);
+  uint64_t cs, ds;
+  wire_sizes(c, c->color_format, c->depth_format, &cs, &ds);
+  if (colorsize) *colorsize = cs;
+  if (depthsize) *depthsize = ds;
+  if (message_bytes) *message_bytes = (cs + ds) * c->cfg.num_streams;
+  return TSDF_OK;
+}
+int32_t tsdf_set_depth_compression(tsdf_ctx* c, uint32_t i, int32_t compressed, float near_, float far_) {
+  CHECK_CTX(c);
+  if (i >= c->cfg.num_streams) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "stream %u out of range", i);
+  const float scale = far_ - near_;                                      // NetKinectArray.cpp:346-349
+  c->pre.compress[i] = compressed != 0; c->pre.dc_near[i] = near_; c->pre.dc_scale[i] = scale; c->pre.dc_scaled_near[i] = scale / 255.0f;
+  return TSDF_OK;
+}
+int32_t tsdf_upload_wire_frame(tsdf_ctx* c, const void* message, uint64_t bytes, double* timestamp) {
+  CHECK_CTX(c);
+  uint64_t cs, ds;
+  wire_sizes(c, c->color_format, c->depth_format, &cs, &ds);
+  const uint64_t want = (cs + ds) * c->cfg.num_streams;
+  if (!message || bytes != want) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "wire message must be %llu bytes (%u x (colour %llu + depth %llu)), got %llu", (unsigned long long)want, c->cfg.num_streams, (unsigned long long)cs, (unsigned long long)ds, (unsigned long long)bytes);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int32_t rc = ensure_pre_buffers(c)) return rc;
+  if (c->wire_capacity < want) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k) {
+      if (c->h_wire[k]) HIP_TRY(c, hipHostFree(c->h_wire[k]));
+      c->h_wire[k] = nullptr; c->wire_pending[k] = false;
+      HIP_TRY(c, hipHostMalloc((void**)&c->h_wire[k], want, hipHostMallocDefault));
+      if (!c->wire_done[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->wire_done[k], hipEventDisableTiming));
+    }
+    HIP_TRY(c, hipFree(c->d_wire)); c->d_wire = nullptr;
+    HIP_TRY(c, hipMalloc(&c->d_wire, want));
+    c->wire_capacity = want;
+  }
+  // double buffer: the copy out of slot k may still be in flight from two frames ago
+  const int k = c->wire_slot; c->wire_slot ^= 1;
+  if (c->wire_pending[k]) HIP_TRY(c, hipEventSynchronize(c->wire_done[k]));
+  memcpy(c->h_wire[k], message, want);                                   // readLoop's memcpy into the mapped PBO, :516-520
+  if (timestamp) memcpy(timestamp, c->h_wire[k], sizeof(double));        // the first 8 bytes of the message, :510
+  HIP_TRY(c, hipMemcpyAsync(c->d_wire, c->h_wire[k], want, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->wire_done[k], c->stream));
+  c->wire_pending[k] = true;
+  WireLayout L{};
+  L.msg = c->d_wire; L.rec = (uint32_t)(cs + ds); L.cs = (uint32_t)cs; L.n = (int)c->cfg.num_streams;
+  L.cw = c->frame.cw; L.ch = c->frame.ch; L.w = c->frame.w; L.h = c->frame.h;
+  L.cfmt = (int)c->color_format; L.dfmt = (int)c->depth_format;
+  timer_begin(c, "0ingest");
+  launch_wire_unpack(c->stream, L, (uchar4*)c->frame.color, c->d_raw);
+  timer_end(c, "0ingest");
+  HIP_TRY(c, hipGetLastError());
+  c->have_raw = true;
+  return TSDF_OK;
+}
+int32_t tsdf_download_raw_frame(tsdf_ctx* c, float* depth_raw, uint8_t* colour_rgba) {
+  CHECK_CTX(c);
+  if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "no raw frame uploaded");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h, nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
+  if (depth_raw) HIP_TRY(c, hipMemcpy(depth_raw, c->d_raw, np * 4, hipMemcpyDeviceToHost));
+  if (colour_rgba) HIP_TRY(c, hipMemcpy(colour_rgba, c->frame.color, nc * 4, hipMemcpyDeviceToHost));
   return TSDF_OK;
 }
 int32_t tsdf_set_preprocess(tsdf_ctx* c, int32_t filter_textures, int32_t processed_depth, int32_t refine) {

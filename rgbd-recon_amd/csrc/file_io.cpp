@@ -1,3 +1,6 @@
+// Host-only file formats of the reference.  No GPU involved; pinned against the reference's own readers/writers
+// (oracle/_ref, tests/test_calib_io.py, tests/test_oracle_ingest.py).
+//
 // Calibration volume files (*.cv_xyz RGB32F, *.cv_uv RG32F, *.cv_xyz_inv RGBA32F): the on-disk format of
 // kinect::CalibrationVolume<T>::read / write (framework/calibration/calibration_volume.hpp:30-38, :62-78):
 //   u32 res.x, res.y, res.z; f32 depth_min, depth_max; T volume[res.x * res.y * res.z]   (x fastest, :57-59)
@@ -72,6 +75,31 @@ int32_t tsdf_calib_volume_write(const char* path, uint32_t texel_floats, const u
   const bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(data, sizeof(float), n, f) == n;
   if (fclose(f) != 0 || !ok) return fail(std::string(path) + ": write failed");
   return TSDF_OK;
+}
+
+// ---- recordings/<sensor>.stream: sys::FileBuffer (framework/io/FileBuffer.cpp) as driven by NetKinectArray::readFromFiles
+// (framework/NetKinectArray.cpp:709-749): records of colorsize + depthsize bytes back to back, no header.
+int32_t tsdf_stream_num_frames(const char* path, uint64_t record_bytes, uint64_t* frames) {   // FileBuffer::calcNumFrames, :60-62
+  if (!path || !record_bytes || !frames) return fail("bad argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(std::string(path) + ": cannot open");
+  fseek(f, 0, SEEK_END);
+  *frames = (uint64_t)ftell(f) / record_bytes;
+  fclose(f);
+  return TSDF_OK;
+}
+int32_t tsdf_stream_read_record(const char* path, uint64_t record_bytes, uint64_t frame, void* out) {
+  if (!path || !record_bytes || !out) return fail("bad argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(std::string(path) + ": cannot open");
+  fseek(f, 0, SEEK_END);
+  const uint64_t size = (uint64_t)ftell(f);
+  int32_t rc = TSDF_OK;
+  // FileBuffer::read returns 0 bytes when the request runs past the end and looping is off (:96-106)
+  if ((frame + 1) * record_bytes > size) rc = fail(std::string(path) + ": frame " + std::to_string(frame) + " is past the end of the stream");
+  else if (fseek(f, (long)(frame * record_bytes), SEEK_SET) != 0 || fread(out, 1, record_bytes, f) != record_bytes) rc = fail(std::string(path) + ": short read");
+  fclose(f);
+  return rc;
 }
 
 }  // extern "C"

@@ -70,9 +70,13 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
   __shared__ float s_d[28][29];
   const int l = blockIdx.z, bx = blockIdx.x * 16, by = blockIdx.y * 16;
   const float* __restrict__ src = B.fdepth + (size_t)l * P.W * P.H;
+  const bool compress = P.compress[l] != 0;                      // sample() / uncompress(), pre_depth.fs:51-72
+  const float sn = P.dc_scaled_near[l], scale = P.dc_scale[l], nearv = P.dc_near[l];
   for (int i = threadIdx.x; i < 28 * 28; i += 256) {
     const int ty = i / 28, tx = i % 28;
-    s_d[ty][tx] = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
+    float t = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
+    if (compress) t = t < sn ? 0.0f : (t * t + 0.15f * sn) * scale + nearv;
+    s_d[ty][tx] = t;
   }
   __syncthreads();
   const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, x = bx + lx, y = by + ly;

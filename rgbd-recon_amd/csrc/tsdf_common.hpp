@@ -119,6 +119,9 @@ struct PreParams {
   float cam[TSDF_MAX_STREAMS][3];                              // CalibVolumes::getCameraPositions
   float bbox_min[3], bbox_max[3];
   int filter_textures, refine;
+  // 8-bit wire depth: compress = isCompressedDepth(); uniforms near / scale / scaled_near (NetKinectArray.cpp:343-349)
+  int compress[TSDF_MAX_STREAMS];
+  float dc_near[TSDF_MAX_STREAMS], dc_scale[TSDF_MAX_STREAMS], dc_scaled_near[TSDF_MAX_STREAMS];
 };
 struct PreBuffers {
   const float* raw;       // [N][H][W] metres
@@ -131,6 +134,14 @@ struct PreBuffers {
   float4* dqs;            // packed {depth.r, quality, silhouette, 0}
   float* depth_plane;
 };
+// one wire message in HBM: per sensor [colour: cs bytes][depth], rec bytes per sensor (k_ingest.hip)
+struct WireLayout {
+  const uint8_t* msg;
+  uint32_t rec, cs;
+  int n, cw, ch, w, h;
+  int cfmt, dfmt;         // TSDF_COLOR_* / TSDF_DEPTH_*
+};
+void launch_wire_unpack(hipStream_t st, const WireLayout& L, uchar4* rgba, float* raw);
 void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR);
 
 // launchers (one per kernel family, defined in the .hip files)

@@ -210,3 +210,86 @@ def make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128, see
     out.update(depth=depth, quality=quality, silhouette=silhouette, normals=normals, color=color, depth_raw=depth_raw,
                camera_positions=np.stack([c.pos for c in cams]).astype(np.float32))
     return out
+
+
+# ---------------------------------------------------------------------- the SENDER side of the wire (synthetic input only)
+# The reference's server (not part of this project) compresses colour with fastdxt and depth to 8 bit; these helpers
+# produce well-formed messages for tests and bench.py.  They are plain range-fit encoders, not the reference's.
+def _pack565(rgb):
+    r, g, b = (rgb[..., 0].astype(np.uint32) >> 3), (rgb[..., 1].astype(np.uint32) >> 2), (rgb[..., 2].astype(np.uint32) >> 3)
+    return (r << 11) | (g << 5) | b
+
+
+def _expand565(v):
+    r, g, b = (v >> 11) & 31, (v >> 5) & 63, v & 31
+    return np.stack([(r << 3) | (r >> 2), (g << 2) | (g >> 4), (b << 3) | (b >> 2)], -1).astype(np.int32)
+
+
+def encode_dxt1(rgb: np.ndarray) -> np.ndarray:
+    """[h][w][3] uint8 (h, w multiples of 4) -> DXT1 blocks (8 bytes each, four-colour mode), row-major block order."""
+    h, w = rgb.shape[:2]
+    assert h % 4 == 0 and w % 4 == 0
+    blk = rgb.reshape(h // 4, 4, w // 4, 4, 3).transpose(0, 2, 1, 3, 4).reshape(-1, 16, 3).astype(np.int32)
+    lum = blk @ np.array([2, 5, 1])
+    hi = np.take_along_axis(blk, lum.argmax(1)[:, None, None], 1)[:, 0]
+    lo = np.take_along_axis(blk, lum.argmin(1)[:, None, None], 1)[:, 0]
+    c0, c1 = _pack565(hi), _pack565(lo)
+    swap = c0 < c1
+    c0, c1 = np.where(swap, c1, c0), np.where(swap, c0, c1)
+    e0, e1 = _expand565(c0), _expand565(c1)
+    flat = c0 == c1                                                   # equal endpoints select the three-colour mode: index 0 everywhere
+    pal = np.stack([e0, e1, (2 * e0 + e1) // 3, (e0 + 2 * e1) // 3], 1)                       # [B][4][3]
+    err = ((blk[:, :, None, :] - pal[:, None, :, :]) ** 2).sum(-1)                             # [B][16][4]
+    idx = np.where(flat[:, None], 0, err.argmin(-1)).astype(np.uint32)
+    bits = (idx << (2 * np.arange(16, dtype=np.uint32))[None, :]).sum(1).astype(np.uint32)
+    out = np.zeros((blk.shape[0], 2), np.uint32)
+    out[:, 0] = c0 | (c1 << 16)
+    out[:, 1] = bits
+    return out.view(np.uint8).reshape(-1)
+
+
+def encode_dxt5(rgba: np.ndarray) -> np.ndarray:
+    """[h][w][4] uint8 -> DXT5 blocks (16 bytes: 8 alpha + the DXT1-style colour block)."""
+    h, w = rgba.shape[:2]
+    col = encode_dxt1(rgba[..., :3]).reshape(-1, 8)
+    a = rgba[..., 3].reshape(h // 4, 4, w // 4, 4).transpose(0, 2, 1, 3).reshape(-1, 16).astype(np.int32)
+    a0, a1 = a.max(1), a.min(1)                                       # a0 > a1: seven-step table; a0 == a1: five-step table, codes 0
+    tab = np.stack([a0, a1] + [((7 - i) * a0 + i * a1) // 7 for i in range(1, 7)], 1)
+    idx = np.where((a0 == a1)[:, None], 0, np.abs(a[:, :, None] - tab[:, None, :]).argmin(-1)).astype(np.uint64)
+    bits = (idx << (3 * np.arange(16, dtype=np.uint64))[None, :]).sum(1).astype(np.uint64)
+    ab = np.zeros((a.shape[0], 8), np.uint8)
+    ab[:, 0], ab[:, 1] = a0, a1
+    for k in range(6):
+        ab[:, 2 + k] = (bits >> np.uint64(8 * k)) & np.uint64(0xFF)
+    return np.concatenate([ab, col], 1).reshape(-1)
+
+
+def compress_depth_u8(depth_m: np.ndarray, near: float, far: float) -> np.ndarray:
+    """Inverse of uncompress() (glsl/pre_depth.fs:51-61): metres -> 8-bit code of the sqrt mapping; 0 = no measurement."""
+    scale = np.float32(far - near)
+    sn = scale / np.float32(255.0)
+    t = (depth_m.astype(np.float32) - np.float32(near)) / scale - np.float32(0.15) * sn
+    code = np.rint(np.sqrt(np.clip(t, 0.0, 1.0)) * 255.0)
+    return np.where(depth_m > 0, np.clip(code, 5, 255), 0).astype(np.uint8)
+
+
+def make_wire_message(scene, color_format=0, depth_format=0, timestamp=None, near=0.5, far=4.5) -> bytes:
+    """One ZMQ message as NetKinectArray::readLoop expects it (framework/NetKinectArray.cpp:513-523): per sensor
+    [colour][depth].  A timestamp, if given, overwrites the first 8 bytes as the reference's sender does."""
+    parts = []
+    for i in range(scene["n"]):
+        col = np.ascontiguousarray(scene["color"][i], np.uint8)
+        if color_format == 1:
+            parts.append(encode_dxt1(col).tobytes())
+        elif color_format == 5:
+            a = np.full(col.shape[:2] + (1,), 255, np.uint8)
+            a[::7, ::5] = 64                                           # some alpha structure to decode
+            parts.append(encode_dxt5(np.concatenate([col, a], -1)).tobytes())
+        else:
+            parts.append(col.tobytes())
+        d = np.ascontiguousarray(scene["depth_raw"][i], np.float32)
+        parts.append(compress_depth_u8(d, near, far).tobytes() if depth_format else d.tobytes())
+    msg = bytearray(b"".join(parts))
+    if timestamp is not None:
+        msg[:8] = np.float64(timestamp).tobytes()
+    return bytes(msg)
