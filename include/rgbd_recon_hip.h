@@ -93,6 +93,21 @@ int32_t tsdf_calib_volume_read(const char* path, uint32_t texel_floats, float* d
 int32_t tsdf_calib_volume_write(const char* path, uint32_t texel_floats, const uint32_t res[3], const float depth_limits[2], const float* data);
 const char* tsdf_calib_last_error(void);
 
+/* ---- inverse calibration volumes: the offline tool source/calib_inverter.cpp.
+ * tsdf_frustum_from_volume: kinect::Frustum built from the 8 corner texels of a forward volume (getCornerPoints,
+ *   calibration_inverter.cpp:117-133; planes + inside(): frustum.cpp) -> planes[6][4] (near far left right top bottom,
+ *   inside = dot(plane, (p,1)) >= 0) and Frustum::getCameraPos(), the value CalibVolumes::getCameraPositions()
+ *   (CalibVolumes.cpp:224-230) hands to the quality pass, i.e. the input of tsdf_set_camera_position.  Host only.
+ * tsdf_inverse_volume_resolution: res = ceil(bbox extent / voxel_size), source/calib_inverter.cpp:60-63 (default 0.007 m).
+ * tsdf_invert_calibration: CalibrationInverter::calculateInverseVolumes for one sensor (calibration_inverter.cpp:68-115):
+ *   exact 8 nearest forward samples + inverse-distance weighting per output voxel, -1 outside the frustum, on GPU `device`.
+ *   cv_xyz: [rz][ry][rx][3] host floats; cv_xyz_inv: [res_inv z][y][x][4] host floats (write with tsdf_calib_volume_write,
+ *   depth limits 0.5 / 4.5 as :112).  gpu_ms (may be NULL): device time of build + query. */
+int32_t tsdf_frustum_from_volume(const float* cv_xyz, const uint32_t res[3], float planes[24], float camera_pos[3]);
+int32_t tsdf_inverse_volume_resolution(const float bbox_min[3], const float bbox_max[3], float voxel_size, uint32_t res[3]);
+int32_t tsdf_invert_calibration(int32_t device, const float* cv_xyz, const uint32_t res_xyz[3], const float bbox_min[3], const float bbox_max[3],
+                                const uint32_t res_inv[3], float* cv_xyz_inv, float* gpu_ms);
+
 /* host-only reader of recordings/<sensor>.stream (sys::FileBuffer as used by NetKinectArray::readFromFiles,
  * framework/NetKinectArray.cpp:709-749; framework/io/FileBuffer.cpp:60-62,90-110): raw records [colour][depth] back to back.
  * One record of every sensor's file, concatenated in sensor order, is exactly one wire message for tsdf_upload_wire_frame. */

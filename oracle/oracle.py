@@ -261,6 +261,26 @@ def decode_dxt(blocks, w, h, fmt):
     return out
 
 
+# --- inverse calibration volumes
+def frustum(cv_xyz):
+    """cv_xyz [rz][ry][rx][3] -> (planes [6][4], camera position [3]); kinect::Frustum, frustum.cpp."""
+    v = _f32(cv_xyz)
+    res = (C.c_uint32 * 3)(v.shape[2], v.shape[1], v.shape[0])
+    planes, cam = np.zeros((6, 4), np.float32), np.zeros(3, np.float32)
+    lib().orc_frustum(_p(v), res, _p(planes), _p(cam))
+    return planes, cam
+
+
+def invert_calibration(cv_xyz, bbox_min, bbox_max, res_inv):
+    """CalibrationInverter::calculateInverseVolumes for one sensor -> [rz][ry][rx][4] (brute-force 8-NN: small sizes only)."""
+    v = _f32(cv_xyz)
+    res = (C.c_uint32 * 3)(v.shape[2], v.shape[1], v.shape[0])
+    ri = (C.c_uint32 * 3)(*[int(x) for x in res_inv])
+    out = np.zeros((res_inv[2], res_inv[1], res_inv[0], 4), np.float32)
+    lib().orc_invert_calibration(_p(v), res, _p(_f32(bbox_min)), _p(_f32(bbox_max)), ri, _p(out))
+    return out
+
+
 # --- sampling primitives (unit tests)
 def tex3d(t, u, v, w):
     t = _f32(t)

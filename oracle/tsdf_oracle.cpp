@@ -1117,4 +1117,111 @@ void orc_decode_dxt(const uint8_t* blocks, int w, int h, int format, uint8_t* rg
     }
 }
 
+
+// ================================================================= inverse calibration volumes
+// kinect::Frustum (framework/calibration/frustum.cpp) from the 8 corner texels of a forward volume
+// (getCornerPoints, calibration_inverter.cpp:117-133), restated in glm's fp32 operation order
+// (external/glm-0.9.5.3 detail/func_geometric.inl: dot = x+y+z left to right, vec4 dot = (x+y)+(z+w),
+// normalize = v * (1/sqrt(dot)), cross as written there).
+namespace {
+struct Frustum { vec3 corner[8]; float plane[6][4]; };
+inline vec3 v_cross(vec3 x, vec3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+inline float v_dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline vec3 v_normalize(vec3 v) { const float s = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); return {v.x * s, v.y * s, v.z * s}; }
+inline vec3 v_avg4(vec3 a, vec3 b, vec3 c, vec3 d) { return (a + b + c + d) / 4.0f; }
+Frustum make_frustum(const float* xyz, const uint32_t res[3]) {
+  Frustum f;
+  const uint32_t ex = res[0] - 1, ey = res[1] - 1, ez = res[2] - 1;
+  auto at = [&](uint32_t x, uint32_t y, uint32_t z) { const float* t = xyz + 3 * ((size_t)z * res[0] * res[1] + (size_t)y * res[0] + x); return vec3{t[0], t[1], t[2]}; };
+  f.corner[0] = at(0, 0, 0); f.corner[1] = at(0, ey, 0); f.corner[2] = at(ex, ey, 0); f.corner[3] = at(ex, 0, 0);
+  f.corner[4] = at(0, 0, ez); f.corner[5] = at(0, ey, ez); f.corner[6] = at(ex, ey, ez); f.corner[7] = at(ex, 0, ez);
+  const vec3* c = f.corner;
+  vec3 e[12];                                                             // getEdgeCenters, frustum.cpp
+  for (int i = 0; i < 4; ++i) { e[i] = (c[i] + c[(i + 1) & 3]) * 0.5f; e[4 + i] = (c[4 + i] + c[4 + ((i + 1) & 3)]) * 0.5f; e[8 + i] = (c[i] + c[4 + i]) * 0.5f; }
+  const vec3 centre[6] = {v_avg4(c[0], c[1], c[2], c[3]), v_avg4(c[4], c[5], c[6], c[7]), v_avg4(c[0], c[1], c[4], c[5]),
+                          v_avg4(c[2], c[3], c[6], c[7]), v_avg4(c[1], c[2], c[5], c[6]), v_avg4(c[0], c[3], c[4], c[7])};   // getSideCenters
+  const vec3 normal[6] = {v_normalize(v_cross(e[0] - e[2], e[3] - e[2])), v_normalize(v_cross(e[4] - e[6], e[5] - e[7])),
+                          v_normalize(v_cross(e[0] - e[4], e[9] - e[8])), v_normalize(v_cross(e[2] - e[6], e[11] - e[10])),
+                          v_normalize(v_cross(e[9] - e[10], e[1] - e[5])), v_normalize(v_cross(e[8] - e[11], e[7] - e[3]))};  // getSideNormals
+  for (int i = 0; i < 6; ++i) { f.plane[i][0] = normal[i].x; f.plane[i][1] = normal[i].y; f.plane[i][2] = normal[i].z; f.plane[i][3] = -v_dot(normal[i], centre[i]); }
+  return f;
+}
+inline bool frustum_inside(const Frustum& f, vec3 p) {                    // Frustum::inside: dot(plane, vec4(p, 1)) < 0 -> outside
+  for (int i = 0; i < 6; ++i) {
+    const float* pl = f.plane[i];
+    if ((pl[0] * p.x + pl[1] * p.y) + (pl[2] * p.z + pl[3] * 1.0f) < 0.0f) return false;
+  }
+  return true;
+}
+vec3 closest_point(vec3 p, vec3 u, vec3 q, vec3 v) {                      // closestPoint(), frustum.cpp
+  const vec3 w0 = p - q;
+  const float a = v_dot(u, u), b = v_dot(u, v), c = v_dot(v, v), d = v_dot(u, w0), e = v_dot(v, w0);
+  const float sc = (b * e - c * d) / (a * c - b * b), tc = (a * e - b * d) / (a * c - b * b);
+  return ((p + u * sc) + (q + v * tc)) * 0.5f;
+}
+}  // namespace
+
+// planes[6][4], camera[3] (Frustum::getCameraPos -> CalibVolumes::getCameraPositions, CalibVolumes.cpp:224-230)
+void orc_frustum(const float* xyz, const uint32_t res[3], float* planes, float* camera) {
+  const Frustum f = make_frustum(xyz, res);
+  memcpy(planes, f.plane, sizeof(f.plane));
+  const vec3* c = f.corner;
+  const vec3 cn = v_avg4(c[0], c[1], c[2], c[3]), cf = v_avg4(c[4], c[5], c[6], c[7]), dir = cf - cn;
+  const vec3 s = (closest_point(c[0], c[0] - c[4], cn, dir) + closest_point(c[1], c[1] - c[5], cn, dir) +
+                  closest_point(c[2], c[2] - c[6], cn, dir) + closest_point(c[3], c[3] - c[7], cn, dir)) / 4.0f;
+  camera[0] = s.x; camera[1] = s.y; camera[2] = s.z;
+}
+
+// CalibrationInverter::calculateInverseVolumes for ONE sensor, calibration_inverter.cpp:68-115.
+// The 8-NN comes from CGAL::Orthogonal_k_neighbor_search (third-party, not vendored: CGAL 4.x as pulled in by
+// framework/CMakeLists.txt) with the EPICK kernel: exact k nearest by squared distance in DOUBLE over the float
+// coordinates, reported in ascending distance.  CGAL leaves the order of equidistant samples open; here ties go to
+// the sample enumerated first by getXyzSamples (:40-55: x outer, z inner).  This restatement is a brute-force scan.
+// inverseDistance (:57-66): fp32, weight = 1 / distance (a coincident sample gives inf -> NaN, as in the reference).
+void orc_invert_calibration(const float* xyz, const uint32_t res[3], const float bbox_min[3], const float bbox_max[3], const uint32_t rinv[3], float* out) {
+  const Frustum fr = make_frustum(xyz, res);
+  const size_t n = (size_t)res[0] * res[1] * res[2];
+  std::vector<double> px(n), py(n), pz(n);
+  std::vector<uint32_t> ix(n), iy(n), iz(n);
+  {
+    size_t k = 0;                                                         // getXyzSamples enumeration order
+    for (uint32_t x = 0; x < res[0]; ++x) for (uint32_t y = 0; y < res[1]; ++y) for (uint32_t z = 0; z < res[2]; ++z, ++k) {
+      const float* t = xyz + 3 * ((size_t)z * res[0] * res[1] + (size_t)y * res[0] + x);
+      px[k] = t[0]; py[k] = t[1]; pz[k] = t[2]; ix[k] = x; iy[k] = y; iz[k] = z;
+    }
+  }
+  const vec3 dims = {bbox_max[0] - bbox_min[0], bbox_max[1] - bbox_min[1], bbox_max[2] - bbox_min[2]};
+  const vec3 vstep = {1.0f / (float)rinv[0], 1.0f / (float)rinv[1], 1.0f / (float)rinv[2]};
+  const vec3 sstep = {dims.x * vstep.x, dims.y * vstep.y, dims.z * vstep.z};
+  const vec3 start = {bbox_min[0] + sstep.x * 0.5f, bbox_min[1] + sstep.y * 0.5f, bbox_min[2] + sstep.z * 0.5f};
+  const vec3 cd = {(float)res[0], (float)res[1], (float)res[2]};
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+  for (uint32_t z = 0; z < rinv[2]; ++z)
+    for (uint32_t y = 0; y < rinv[1]; ++y)
+      for (uint32_t x = 0; x < rinv[0]; ++x) {
+        float* o = out + 4 * ((size_t)z * rinv[0] * rinv[1] + (size_t)y * rinv[0] + x);
+        const vec3 p = {start.x + (float)x * sstep.x, start.y + (float)y * sstep.y, start.z + (float)z * sstep.z};
+        if (!frustum_inside(fr, p)) { o[0] = o[1] = o[2] = o[3] = -1.0f; continue; }
+        double bd[8]; size_t bi[8]; int cnt = 0;
+        for (size_t k = 0; k < n; ++k) {
+          const double dx = (double)p.x - px[k], dy = (double)p.y - py[k], dz = (double)p.z - pz[k];
+          double d = 0.0; d += dx * dx; d += dy * dy; d += dz * dz;
+          if (cnt == 8 && !(d < bd[7])) continue;                         // later index loses ties
+          int j = cnt < 8 ? cnt++ : 7;
+          while (j > 0 && d < bd[j - 1]) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+          bd[j] = d; bi[j] = k;
+        }
+        float tw = 0.0f; vec3 wi = {0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < cnt; ++j) {
+          const size_t k = bi[j];
+          const vec3 dv = {(float)px[k] - p.x, (float)py[k] - p.y, (float)pz[k] - p.z};            // glm::distance = length(p1 - p0)
+          const float w = 1.0f / sqrtf(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
+          wi = {wi.x + w * (float)ix[k], wi.y + w * (float)iy[k], wi.z + w * (float)iz[k]};
+          tw += w;
+        }
+        wi = {wi.x / tw, wi.y / tw, wi.z / tw};
+        o[0] = (wi.x + 0.5f) / cd.x; o[1] = (wi.y + 0.5f) / cd.y; o[2] = (wi.z + 0.5f) / cd.z; o[3] = 1.0f;
+      }
+}
+
 }  // extern "C"

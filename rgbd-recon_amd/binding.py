@@ -101,6 +101,42 @@ def write_calib_volume(path, kind, volume, depth_limits):
         raise TsdfError(-1, L.tsdf_calib_last_error().decode())
 
 
+# ---------------------------------------------------------------------- inverse calibration volumes (source/calib_inverter.cpp)
+def frustum_from_volume(cv_xyz):
+    """cv_xyz [rz][ry][rx][3] -> (planes [6][4], camera position): kinect::Frustum of the volume's corner texels (host only)."""
+    L = load_library()
+    L.tsdf_calib_last_error.restype = C.c_char_p
+    v = _f32(cv_xyz)
+    assert v.ndim == 4 and v.shape[3] == 3
+    planes, cam = np.zeros((6, 4), np.float32), np.zeros(3, np.float32)
+    if L.tsdf_frustum_from_volume(_fp(v), (C.c_uint32 * 3)(v.shape[2], v.shape[1], v.shape[0]), _fp(planes), _fp(cam)) != 0:
+        raise TsdfError(-1, L.tsdf_calib_last_error().decode())
+    return planes, cam
+
+
+def inverse_volume_resolution(bbox_min, bbox_max, voxel_size=0.007):
+    L = load_library()
+    res = (C.c_uint32 * 3)()
+    if L.tsdf_inverse_volume_resolution(_fp(_f32(bbox_min)), _fp(_f32(bbox_max)), C.c_float(voxel_size), res) != 0:
+        raise TsdfError(-1, "bad argument")
+    return tuple(res)
+
+
+def invert_calibration(cv_xyz, bbox_min, bbox_max, res_inv, device=0):
+    """CalibrationInverter::calculateInverseVolumes for one sensor on the GPU -> ([rz][ry][rx][4], device milliseconds)."""
+    L = load_library()
+    L.tsdf_calib_last_error.restype = C.c_char_p
+    v = _f32(cv_xyz)
+    assert v.ndim == 4 and v.shape[3] == 3
+    out = np.empty((int(res_inv[2]), int(res_inv[1]), int(res_inv[0]), 4), np.float32)
+    ms = C.c_float()
+    rc = L.tsdf_invert_calibration(int(device), _fp(v), (C.c_uint32 * 3)(v.shape[2], v.shape[1], v.shape[0]), _fp(_f32(bbox_min)), _fp(_f32(bbox_max)),
+                                   (C.c_uint32 * 3)(*[int(x) for x in res_inv]), _fp(out), C.byref(ms))
+    if rc != 0:
+        raise TsdfError(rc, L.tsdf_calib_last_error().decode())
+    return out, ms.value
+
+
 def stream_num_frames(path, record_bytes):
     """FileBuffer::calcNumFrames for recordings/<sensor>.stream."""
     L = load_library()

@@ -497,6 +497,13 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
     c->lut_allocs.push_back(d);
     HIP_TRY(c, hipMemcpy(d, padded.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     L.xyz = d; for (int a = 0; a < 3; ++a) L.xyz_res[a] = (int)rx[a];
+    // CalibVolumes::addVolume builds the sensor's frustum from this volume (CalibVolumes.cpp:122) and getCameraPositions()
+    // (:224-230) feeds the quality pass: default camera position, until tsdf_set_camera_position overrides it
+    float cam[3];
+    if (tsdf_frustum_from_volume(xyz, rx, nullptr, cam) == TSDF_OK && std::isfinite(cam[0]) && std::isfinite(cam[1]) && std::isfinite(cam[2])) {
+      for (int a = 0; a < 3; ++a) c->pre.cam[i][a] = cam[a];
+      c->have_cam[i] = true;
+    }
   }
   // largest LUT texel box any 8^3 tile touches, with the kernel's own fp32 index arithmetic, against the LDS budget of
   // k_integrate_tiles_lds: box dx*dy*dz <= 512, x-pass rows dy*dz*8 <= 512, y-pass planes dz*64 <= 512

@@ -18,6 +18,9 @@ struct Header { uint32_t res[3]; float limits[2]; };
 static_assert(sizeof(Header) == 20, "20-byte header");
 
 int32_t fail(const std::string& m) { g_io_error = m; return TSDF_ERR_INVALID_ARGUMENT; }
+}  // namespace
+void rr_set_io_error(const std::string& m) { g_io_error = m; }
+namespace {
 
 int32_t read_header(FILE* f, const char* path, uint32_t texel_floats, Header* h) {
   if (fread(h, sizeof(Header), 1, f) != 1) return fail(std::string(path) + ": shorter than the 20-byte header");

@@ -134,6 +134,20 @@ struct PreBuffers {
   float4* dqs;            // packed {depth.r, quality, silhouette, 0}
   float* depth_plane;
 };
+// inverse calibration volume builder (k_inverter.hip)
+struct InverterGrid {
+  uint32_t rx, ry, rz, n;     // forward volume resolution, sample count
+  int g[3];                   // uniform grid over the samples
+  double gmin[3], cell[3], inv[3];
+};
+struct InverterQuery {
+  uint32_t res[3];            // output resolution
+  float start[3], step[3];    // sample_start, sample_step (calibration_inverter.cpp:74-78)
+  float plane[6][4];          // kinect::Frustum planes
+};
+void launch_inverter_build(hipStream_t st, const InverterGrid& G, const float* xyz, uint32_t* count, uint32_t* start, uint32_t* sums, float4* sorted);
+void launch_inverter_query(hipStream_t st, const InverterGrid& G, const InverterQuery& Q, const float* xyz, const uint32_t* start, const float4* sorted, float4* out);
+
 // one wire message in HBM: per sensor [colour: cs bytes][depth], rec bytes per sensor (k_ingest.hip)
 struct WireLayout {
   const uint8_t* msg;
