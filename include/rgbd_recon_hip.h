@@ -211,6 +211,9 @@ int32_t tsdf_composite_hits_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_
  * "holefill", "brickdraw", plus "bricks" (clear + mark + update).
  * "2integrate" brackets exactly the integrate kernel launch, "draw" exactly the raymarch kernel -------------------------------------------------------------- */
 int32_t tsdf_enable_timers(tsdf_ctx* ctx, int32_t active);
+/* every recorded event costs a few microseconds of stream time: restrict recording to a comma-separated list of timer names
+ * (e.g. "2integrate") while measuring throughput; NULL or "" = all */
+int32_t tsdf_set_timer_filter(tsdf_ctx* ctx, const char* names);
 int32_t tsdf_timer_ms(tsdf_ctx* ctx, const char* name, float* last_ms);   /* synchronises on that timer */
 /* every invocation since the previous call: count and summed device time; resets the timer */
 int32_t tsdf_timer_stats(tsdf_ctx* ctx, const char* name, uint32_t* count, float* total_ms);

@@ -392,6 +392,9 @@ class ReconIntegrationHip:
         self._ck(self._L.tsdf_timer_ms(self._c, name.encode(), C.byref(ms)))
         return ms.value
 
+    def set_timer_filter(self, names=None):
+        self._ck(self._L.tsdf_set_timer_filter(self._c, (",".join(names)).encode() if names else None))
+
     def timer_stats(self, name):
         n, ms = C.c_uint32(), C.c_float()
         self._ck(self._L.tsdf_timer_stats(self._c, name.encode(), C.byref(n), C.byref(ms)))

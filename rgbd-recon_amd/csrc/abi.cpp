@@ -80,6 +80,7 @@ struct tsdf_ctx {
   bool fill_holes = true, use_bricks = true, skip_space = true;
   int shade_mode = 0;
   bool timers_on = false;
+  std::string timer_filter;      // ",name,name," or empty = all
   std::map<std::string, Timer> timers;
 };
 
@@ -258,6 +259,7 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
 
 void timer_begin(tsdf_ctx* c, const char* name) {
   if (!c->timers_on) return;
+  if (!c->timer_filter.empty() && c->timer_filter.find(std::string(",") + name + ",") == std::string::npos) return;
   Timer& t = c->timers[name];
   if (t.used == t.ev.size()) {
     if (t.ev.size() >= kMaxTimerPairs) { t.used = t.ev.size() - 1; }      // saturate: overwrite the last pair
@@ -764,7 +766,10 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   timer_begin(c, "2integrate");
   bool lds = true;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = lds && c->lds_ok[i];
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->tile_count_zeroed ? 0 : 1);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->tile_count_zeroed ? 0 : 1, 1);
+  timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, 0, 2);
+  timer_end(c, "k_integrate_tiles");
   if (c->use_bricks) c->tile_count_zeroed = false;
   timer_end(c, "2integrate");
   HIP_TRY(c, hipGetLastError());
@@ -786,7 +791,10 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   }
   const bool partial = !(c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
   timer_begin(c, "draw");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, ray_target(c), partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity);
+  timer_begin(c, "k_march");
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, ray_target(c), partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2);
+  timer_end(c, "k_march");
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, ray_target(c), partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3);
   c->hit_parity ^= 1;
   timer_end(c, "draw");
   HIP_TRY(c, hipGetLastError());
@@ -1022,6 +1030,11 @@ int32_t tsdf_composite_hits_dev(tsdf_ctx* c, const void* gathered, uint32_t n, u
 
 // ---- timers
 int32_t tsdf_enable_timers(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->timers_on = a != 0; return TSDF_OK; }
+int32_t tsdf_set_timer_filter(tsdf_ctx* c, const char* names) {
+  CHECK_CTX(c);
+  c->timer_filter = (names && *names) ? "," + std::string(names) + "," : std::string();
+  return TSDF_OK;
+}
 int32_t tsdf_timer_ms(tsdf_ctx* c, const char* name, float* ms) {
   CHECK_CTX(c);
   if (!name || !ms) return TSDF_ERR_INVALID_ARGUMENT;

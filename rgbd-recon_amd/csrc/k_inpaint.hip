@@ -12,21 +12,24 @@ namespace rr {
 
 struct Texel { float4 c; float d; };
 
-// texelFetch from the squeezed copy S as it exists while level `lod + 1` is being built
-__device__ __forceinline__ Texel fetch_squeezed(const Atlas& A, int w, int lod, int s, int y) {
-  Texel t;
-  if (s < 0 || y < 0 || s >= A.aw || y >= A.h) {          // out-of-range texelFetch -> 0 (Appendix A)
-    t.c = make_float4(0, 0, 0, 0); t.d = 0.0f;
-    return t;
-  }
-  t.c = make_float4(0.0f, 1.0f, 0.0f, 0.0f); t.d = 1.0f;  // ViewLod::enable clear, view_lod.cpp:75-81
-  if (s >= w) return t;                                   // only the w-wide viewport of S is written
-  const float tu = ((float)s + 0.5f) / (float)w, tv = ((float)y + 0.5f) / (float)A.h;   // pass_TexCoord
-  const int c = (int)(tu * (float)A.aw), sy = (int)(tv * (float)A.h);                   // ivec2(pass_TexCoord * resolution_tex)
-  if (c >= w && !(lod >= 1 && sy >= A.off[lod][1])) return t;   // pyramid levels > lod: still cleared in the reference
-  if (c >= A.aw || sy >= A.h) { t.c = make_float4(0, 0, 0, 0); t.d = 0.0f; return t; }
-  const size_t o = (size_t)sy * A.aw + c;
-  t.c = A.color[o]; t.d = A.depth[o];
+// texelFetch from the squeezed copy S as it exists while level `lod + 1` is being built, split into address + class so
+// that all 16 taps of a pixel can be LOADED UNCONDITIONALLY and back to back (with early returns per tap the compiler waits
+// for each tap's loads before it evaluates the next tap's branches: 16 dependent L2 round trips per pixel, ~6 us per
+// pyramid level whatever its size).
+//   cls 0: out-of-range texelFetch -> 0 (Appendix A), also atlas column/row past the allocation
+//   cls 1: the freshly cleared copy's value (ViewLod::enable, view_lod.cpp:75-81): columns >= w of S are never written,
+//          and pyramid levels > lod are still cleared in the reference when this level is built
+//   cls 2: atlas texel at `off`: squeezed column s holds atlas column int(pass_TexCoord.x * resolution_tex.x)
+struct TapAddr { uint32_t off; int cls; };
+__device__ __forceinline__ TapAddr squeezed_addr(const Atlas& A, int w, int lod, int s, int y) {
+  const bool oob = s < 0 || y < 0 || s >= A.aw || y >= A.h;
+  const float tu = ((float)s + 0.5f) / (float)w, tv = ((float)y + 0.5f) / (float)A.h;
+  const int c = (int)(tu * (float)A.aw), sy = (int)(tv * (float)A.h);
+  const bool cleared = s >= w || (c >= w && !(lod >= 1 && sy >= A.off[lod][1]));
+  const bool zero2 = c >= A.aw || sy >= A.h;
+  TapAddr t;
+  t.cls = oob ? 0 : (cleared ? 1 : (zero2 ? 0 : 2));
+  t.off = t.cls == 2 ? (uint32_t)sy * (uint32_t)A.aw + (uint32_t)c : 0u;
   return t;
 }
 
@@ -38,23 +41,33 @@ __device__ __forceinline__ void inpaint_pixel(const Atlas& A, int w, int lod, in
   const int lx = (int)((float)A.off[lod][0] + (float)A.res[lod][0] * tcx);                           // to_lod_pos, :30-32
   const int ly = (int)((float)A.off[lod][1] + (float)A.res[lod][1] * tcy);
   const int pxi = (int)((float)lx * (float)(2.0 / 3.0)), pyi = (int)((float)ly * 1.0f);               // :38
+  TapAddr ta[16];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) ta[x + y * 4] = squeezed_addr(A, w, lod, pxi + x - 1, pyi + y - 1);   // :45-47
+  float4 tc[16];
+  float td_[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { tc[i] = A.color[ta[i].off]; td_[i] = A.depth[ta[i].off]; }
   float depth_av = 0.0f;
   int num = 0;
   float4 smp[16];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      Texel t = fetch_squeezed(A, w, lod, pxi + x - 1, pyi + y - 1);                                  // :45-47
-      if (t.c.w <= 0.0f) t.c.x = -1.0f;
-      else { depth_av += t.d; ++num; }
-      smp[x + y * 4] = make_float4(t.c.x, t.c.y, t.c.z, t.d);
-    }
+  for (int i = 0; i < 16; ++i) {
+    float4 c = tc[i];
+    float d = td_[i];
+    if (ta[i].cls == 1) { c = make_float4(0.0f, 1.0f, 0.0f, 0.0f); d = 1.0f; }   // ViewLod::enable clear, view_lod.cpp:75-81
+    if (ta[i].cls == 0) { c = make_float4(0.0f, 0.0f, 0.0f, 0.0f); d = 0.0f; }
+    if (c.w <= 0.0f) c.x = -1.0f;
+    else { depth_av += d; ++num; }
+    smp[i] = make_float4(c.x, c.y, c.z, d);
+  }
   const size_t o = (size_t)fy * A.aw + fx;
   if (num == 0) {                                                                                      // :59-68
-    const Texel t = fetch_squeezed(A, w, lod, pxi, pyi);
-    A.depth[o] = t.d;
-    A.color[o] = (t.d < 1.0f) ? make_float4(0.0f, 0.0f, 0.0f, -1.0f) : make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+    const float d = smp[1 + 1 * 4].w;                     // the centre tap (pxi, pyi)
+    A.depth[o] = d;
+    A.color[o] = (d < 1.0f) ? make_float4(0.0f, 0.0f, 0.0f, -1.0f) : make_float4(0.0f, 1.0f, 0.0f, 0.0f);
     return;
   }
   depth_av /= (float)num;

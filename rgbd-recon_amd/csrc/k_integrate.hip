@@ -322,14 +322,19 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
   }
 }
 
-void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count) {
+void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count, int phase) {
+  // phase 1: tile classification + stale-tile clear; phase 2: the integrate kernel; 0: both (the split lets the caller time the kernel alone)
   if (use_bricks) {
-    if (zero_count) hipMemsetAsync(S.count, 0, sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_classify_clear_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
+    if (phase != 2) {
+      if (zero_count) hipMemsetAsync(S.count, 0, sizeof(uint32_t), st);
+      hipLaunchKernelGGL(k_classify_clear_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
+    }
+    if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
     if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
   } else {
+    if (phase == 1) return;
     if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
   }

@@ -527,15 +527,19 @@ __global__ __launch_bounds__(256) void k_shade(ViewParams P, StreamTable T, Fram
   }
 }
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
-                     void* hit_list, uint32_t* hit_counters, int parity) {
-  if (kUseSkip) {
+                     void* hit_list, uint32_t* hit_counters, int parity, int phase) {
+  // phase 2: k_march alone; phase 3: k_shade alone; 0: everything (the split lets the caller time the march kernel alone)
+  if (kUseSkip && phase != 3) {
     hipMemsetAsync(V.pyr, 0, (size_t)V.pyr_off[0] * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_build_pyramid, dim3(V.pyr_n[4][0], V.pyr_n[4][1], V.pyr_n[4][2]), dim3(256), 0, st, V);
   }
   dim3 grid((P.w + 15) / 16, (P.h + 15) / 16);
   const size_t lds = kUseSkip ? (size_t)V.pyr_off[0] * sizeof(uint32_t) : 0;
-  if (partial) hipLaunchKernelGGL(k_march<true>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
-  else hipLaunchKernelGGL(k_march<false>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+  if (phase != 3) {
+    if (partial) hipLaunchKernelGGL(k_march<true>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+    else hipLaunchKernelGGL(k_march<false>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+  }
+  if (phase == 2) return;
   hipLaunchKernelGGL(k_shade, dim3(1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1));
 }
 

@@ -164,7 +164,7 @@ void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t 
 void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
 void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B);
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, int zero_count);
-void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count);
+void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count, int phase = 0);
 int integrate_box_cap();
 void launch_mark_all_mixed(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
@@ -172,7 +172,7 @@ void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* lin
 void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels);
 struct RayTarget { float4* color; float* depth; int stride; float* nsamples; const float4* peels; float clear[4]; };
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
-                     void* hit_list, uint32_t* hit_counters, int parity);   // hit_list: 16 B per view pixel; two counters used alternately
+                     void* hit_list, uint32_t* hit_counters, int parity, int phase = 0);   // hit_list: 16 B per view pixel; two counters used alternately
 void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod);
 void launch_inpaint_pyramid(hipStream_t st, const Atlas& A);
 void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth);

@@ -14,6 +14,9 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def rr():
+    # torch bundles its own HIP runtime: when a process uses both torch and the library (the multi-GPU tests do), torch has
+    # to be imported FIRST so that librgbd_recon_hip.so binds to the runtime that is already loaded (bench.py does the same)
+    import torch  # noqa: F401
     import rgbd_recon_amd
     return rgbd_recon_amd
 
