@@ -73,6 +73,10 @@ struct tsdf_ctx {
   Atlas atlas{};
   float4* d_peels = nullptr; float* d_nsamples = nullptr;
   void* d_hits = nullptr; uint32_t* d_hit_counters = nullptr; int hit_parity = 0;
+  uint8_t* d_touched[2]{}; int touched_parity = 0; bool tile_history = false;   // image-space dirty tiles (k_raymarch.hip); history is dropped
+                                                                                // whenever something else writes the march target
+  bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
+  void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
   unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
   float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
   float* d_linear = nullptr;     // scratch for volume up/download
@@ -125,6 +129,8 @@ Mat4 to_mat4(const double* d) { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (f
 
 void release_view(tsdf_ctx* c) {
   hipFree(c->atlas.color); hipFree(c->atlas.depth); hipFree(c->d_peels); hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
+  hipFree(c->d_long); c->d_long = nullptr;
+  hipFree(c->d_touched[0]); hipFree(c->d_touched[1]); c->d_touched[0] = c->d_touched[1] = nullptr; c->tile_history = false;
   hipFree(c->d_hits); hipFree(c->d_hit_counters); hipFree(c->d_comp_key); c->d_hits = nullptr; c->d_hit_counters = nullptr; c->d_comp_key = nullptr;
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
@@ -162,8 +168,14 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   HIP_TRY(c, hipMalloc(&c->d_fb_c, nv * sizeof(float4)));
   HIP_TRY(c, hipMalloc(&c->d_fb_d, nv * sizeof(float)));
   HIP_TRY(c, hipMalloc(&c->d_hits, nv * 16));
-  HIP_TRY(c, hipMalloc(&c->d_hit_counters, 2 * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemsetAsync(c->d_hit_counters, 0, 2 * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMalloc(&c->d_long, nv * sizeof(LongRay)));
+  const size_t n_img_tiles = (size_t)((c->vw + 7) / 8) * ((c->vh + 7) / 8);
+  for (int k = 0; k < 2; ++k) { HIP_TRY(c, hipMalloc(&c->d_touched[k], n_img_tiles)); HIP_TRY(c, hipMemsetAsync(c->d_touched[k], 0, n_img_tiles, c->stream)); }
+  c->tile_history = false;
+  HIP_TRY(c, hipMalloc(&c->d_hit_counters, 4 * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemsetAsync(c->d_hit_counters, 0, 4 * sizeof(uint32_t), c->stream));
+  if (const char* e = getenv("RR_MARCH_CAP")) c->march_cap = (uint32_t)atoi(e);
+  if (const char* e = getenv("RR_IMAGE_TILES")) c->use_tile_history = atoi(e) != 0;
   c->hit_parity = 0;
   // the atlas starts as ViewLod::enable() leaves it (colour (0,1,0,0), depth 1); regions no kernel writes keep that
   launch_clear_image(c->stream, A.color, A.depth, na, make_float4(0.0f, 1.0f, 0.0f, 0.0f), 1.0f);
@@ -784,17 +796,31 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   ViewParams P;
   if (!make_view_params(c, mv, pr, &P)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "singular modelview / projection matrix");
   if (outer_timer) timer_begin(c, "3recon");
+  const bool partial = !(c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
+  const bool use_tiles = P.skip && !partial && c->use_tile_history;
   if (P.skip) {
     timer_begin(c, "brickdraw");
-    launch_depth_limits(c->stream, P, c->br, c->d_peels);
+    if (use_tiles && !c->tile_history) {
+      const size_t n_img_tiles = (size_t)((c->vw + 7) / 8) * ((c->vh + 7) / 8);
+      HIP_TRY(c, hipMemsetAsync(c->d_touched[0], 0, n_img_tiles, c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_touched[1], 0, n_img_tiles, c->stream));
+    }
+    launch_depth_limits(c->stream, P, c->br, c->d_peels, use_tiles ? c->d_touched[c->touched_parity] : nullptr,
+                        use_tiles && c->tile_history ? c->d_touched[c->touched_parity ^ 1] : nullptr);
     timer_end(c, "brickdraw");
   }
-  const bool partial = !(c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
+  RayTarget RT = ray_target(c);
+  if (use_tiles) {
+    RT.touched_cur = c->d_touched[c->touched_parity]; RT.touched_prev = c->d_touched[c->touched_parity ^ 1];
+    RT.rewrite_all = c->tile_history ? 0 : 1;
+    c->touched_parity ^= 1;
+    c->tile_history = true;
+  } else c->tile_history = false;
   timer_begin(c, "draw");
   timer_begin(c, "k_march");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, ray_target(c), partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2);
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu);
   timer_end(c, "k_march");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, ray_target(c), partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3);
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3);
   c->hit_parity ^= 1;
   timer_end(c, "draw");
   HIP_TRY(c, hipGetLastError());
@@ -838,7 +864,7 @@ int32_t tsdf_set_tsdf_limit(tsdf_ctx* c, float limit) {
 }
 int32_t tsdf_set_use_bricks(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->use_bricks = a != 0; return TSDF_OK; }
 int32_t tsdf_set_space_skip(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->skip_space = a != 0; return TSDF_OK; }
-int32_t tsdf_set_color_filling(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->fill_holes = a != 0; return TSDF_OK; }
+int32_t tsdf_set_color_filling(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->fill_holes = a != 0; c->tile_history = false; return TSDF_OK; }   // the march target changes
 int32_t tsdf_set_min_voxels_per_brick(tsdf_ctx* c, uint32_t n) { CHECK_CTX(c); c->min_voxels = n; return TSDF_OK; }
 int32_t tsdf_set_shade_mode(tsdf_ctx* c, int32_t m) {
   CHECK_CTX(c);
@@ -940,6 +966,7 @@ int32_t tsdf_upload_image(tsdf_ctx* c, const float* rgba, const float* depth) {
   const size_t w = (size_t)c->vw, h = (size_t)c->vh;
   HIP_TRY(c, hipMemcpy2D(R.color, (size_t)R.stride * 16, rgba, w * 16, w * 16, h, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy2D(R.depth, (size_t)R.stride * 4, depth, w * 4, w * 4, h, hipMemcpyHostToDevice));
+  c->tile_history = false;                                               // the march target no longer holds what the last march left
   return TSDF_OK;
 }
 int32_t tsdf_download_framebuffer(tsdf_ctx* c, float* rgba, float* depth) {

@@ -173,12 +173,16 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 // of 7 three-component lerps per voxel and stream, and a voxel pays two dependent memory round trips per chunk.
 // Tuning knobs, values from A/B runs on MI355X (c2 / c1 integrate, ms): chunk 2, 4 waves/SIMD, 512-texel cap 0.139 / 0.509;
 // + both voxels of a thread in flight 0.108 / 0.463; + 384-texel cap, 5 waves 0.096 / 0.384; chunk 1, 6 waves/SIMD
-// 0.085 / 0.347 (chosen).  The kernel is bound by dependent-load latency per workgroup, so occupancy wins.
+// 0.085 / 0.347; 7 waves/SIMD (72 VGPRs, no spill) 0.070 / 0.324 (chosen; 8 waves spills: 0.081 / 0.388).  The kernel is bound
+// by dependent-load latency per workgroup, so occupancy wins.  A software-pipelined variant (phase A once per tile, next
+// stream's box prefetched into registers, double-buffered box, fusion deferred behind the next stream's X/Y passes: three
+// barriers per stream instead of five, both round trips off the critical path) was bit-identical and SLOWER (0.084 / 0.414 at
+// 80 VGPRs + 23 KB LDS): the extra live state costs more occupancy than the overlap returns.
 #ifndef RR_K1_BOXCAP
 #define RR_K1_BOXCAP 384
 #endif
 #ifndef RR_K1_BOUNDS
-#define RR_K1_BOUNDS 6
+#define RR_K1_BOUNDS 7
 #endif
 #ifndef RR_K1_UNROLL_H
 #define RR_K1_UNROLL_H 2

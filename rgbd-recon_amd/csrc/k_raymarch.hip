@@ -46,10 +46,20 @@ __global__ __launch_bounds__(256) void k_clear_peels(uint4* __restrict__ peels, 
   if (i < n) peels[i] = make_uint4(__float_as_uint(1.0f), 0u, __float_as_uint(1.0f), 0u);   // clear (1,0,1,0), recon_integration.cpp:144
 }
 
+// Image-space dirty tiles: k_depth_limits flags every 8x8-pixel tile it writes a peel into.  The next frame resets only the
+// peels of flagged tiles, and k_march neither reads peels nor rewrites clear values for tiles that are untouched in both
+// frames (c2: 1085 of 14400 tiles see a brick) -- the dense 15 MB peel clear and ~35 MB of per-frame clear traffic go away.
+__global__ __launch_bounds__(256) void k_clear_peel_tiles(uint4* __restrict__ peels, int w, int h, int ntx, int n_tiles, const uint8_t* __restrict__ touched_prev) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+  if (t >= n_tiles || !touched_prev[t]) return;
+  const int px = (t % ntx) * 8 + (ln & 7), py = (t / ntx) * 8 + (ln >> 3);
+  if (px < w && py < h) peels[(size_t)py * w + px] = make_uint4(__float_as_uint(1.0f), 0u, __float_as_uint(1.0f), 0u);
+}
+
 // One wave per occupied brick (persistent, pulling from the compacted list).  For each exposed face the wave
 // sweeps the pixel bounding box of the projected face and applies the reference's fragment rule to every pixel
 // centre whose ray crosses the face rectangle: z from the ray/plane intersection, near/far clip, MIN blend.
-__global__ __launch_bounds__(64) void k_depth_limits(ViewParams P, Bricks B, uint4* __restrict__ peels) {
+__global__ __launch_bounds__(64) void k_depth_limits(ViewParams P, Bricks B, uint4* __restrict__ peels, uint8_t* __restrict__ touched, int ntx) {
   const int lane = threadIdx.x;
   const int n_occ = (int)*B.num_occupied;
   const float o[3] = {P.cam_world[0], P.cam_world[1], P.cam_world[2]};
@@ -112,16 +122,19 @@ __global__ __launch_bounds__(64) void k_depth_limits(ViewParams P, Bricks B, uin
           atomicMin(pp + 0, zb);                                          // bricks.fs:6 with GL_MIN blending
           atomicMax(pp + 1, zb);
           if (!front) atomicMin(pp + 2, zb);
+          if (touched) touched[(py >> 3) * ntx + (px >> 3)] = 1;
         }
       }
     }
   }
 }
-void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels) {
-  const int n = P.w * P.h;
-  hipLaunchKernelGGL(k_clear_peels, dim3((n + 255) / 256), dim3(256), 0, st, (uint4*)peels, n);
+void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels, uint8_t* touched_cur, const uint8_t* touched_prev) {
+  const int n = P.w * P.h, ntx = (P.w + 7) / 8, n_tiles = ntx * ((P.h + 7) / 8);
+  // touched_prev == nullptr: no tile history (first frame, resized view, ...): reset every peel
+  if (touched_prev) hipLaunchKernelGGL(k_clear_peel_tiles, dim3((n_tiles + 3) / 4), dim3(256), 0, st, (uint4*)peels, P.w, P.h, ntx, n_tiles, touched_prev);
+  else hipLaunchKernelGGL(k_clear_peels, dim3((n + 255) / 256), dim3(256), 0, st, (uint4*)peels, n);
   const int grid = B.n < 8192 ? B.n : 8192;
-  hipLaunchKernelGGL(k_depth_limits, dim3(grid), dim3(64), 0, st, P, B, (uint4*)peels);
+  hipLaunchKernelGGL(k_depth_limits, dim3(grid), dim3(64), 0, st, P, B, (uint4*)peels, touched_cur, ntx);
 }
 
 // ------------------------------------------------------------------------------------------- K2
@@ -337,7 +350,8 @@ __device__ __forceinline__ uint32_t empty_run(const Volume& V, const uint32_t* p
 constexpr int kBatch = RR_MARCH_BATCH;   // samples in flight per ray
 
 template <bool kPartial>
-__global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
+__global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count,
+                                                                 LongRay* __restrict__ longs, uint32_t* __restrict__ long_count, uint32_t cap) {
   constexpr bool partial = kPartial;
   extern __shared__ uint32_t s_pyr[];
   if (kUseSkip) {
@@ -349,6 +363,23 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   const int px = blockIdx.x * 16 + (wv & 1) * 8 + (ln & 7);
   const int py = blockIdx.y * 16 + (wv >> 1) * 8 + (ln >> 3);
   const bool inside = px < P.w && py < P.h;
+  if (!partial && R.touched_cur) {
+    // this wave IS one 8x8 image tile: untouched now -> nothing to march; untouched before as well -> already holds clear values
+    const int ntx = (P.w + 7) >> 3, tx = blockIdx.x * 2 + (wv & 1), ty = blockIdx.y * 2 + (wv >> 1);
+    if (tx >= ntx || ty * 8 >= P.h) return;
+    const int t = ty * ntx + tx;
+    const uint8_t cur = R.touched_cur[t], before = R.touched_prev[t];
+    if (ln == 0) R.touched_prev[t] = 0;                                  // becomes the next frame's (empty) current mask
+    if (!cur) {
+      if ((before || R.rewrite_all) && inside) {
+        const size_t oi = (size_t)py * R.stride + px;
+        R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
+        R.depth[oi] = 1.0f;
+        R.nsamples[(size_t)py * P.w + px] = 0.0f;
+      }
+      return;
+    }
+  }
   const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
   const float3 dn = normalize3(pixel_dir_vol(P, fx, fy));
   const float3 step = make_float3(dn.x * sd, dn.y * sd, dn.z * sd);     // :64
@@ -395,6 +426,7 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   float3 pos_prev = pos;
   uint32_t n = 0;
   bool hit = false;
+  bool deferred = false;
   float3 hit_pos = pos;
   float hit_d = 0.0f;
   if (partial) {
@@ -461,6 +493,22 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
     try_skip = kUseSkip && all_minus;
     if (!hit) pos = make_float3(p[kBatch - 1].x + step.x, p[kBatch - 1].y + step.y, p[kBatch - 1].z + step.z);
     if (partial && !hit && !prev_valid) { n = max_n; break; }          // the batch ended outside the slab: nothing further is ours
+    if (!partial && !hit && n >= cap && n < max_n) { deferred = true; break; }   // a long ray: k_march_long finishes it, one wave per ray
+  }
+  // Long rays are few (c2: the mean ray has 8 samples, the longest 92) but a wave lasts as long as its longest ray and the
+  // launch as long as its slowest wave: hand them to a second kernel that puts 64 lanes on one ray.
+  const unsigned long long dm = __ballot(deferred);
+  if (dm) {
+    const int leader = __ffsll((long long)dm) - 1;
+    uint32_t base = 0;
+    if (ln == leader) base = atomicAdd(long_count, (uint32_t)__popcll(dm));
+    base = __shfl(base, leader);
+    if (deferred) {
+      LongRay r;
+      r.pix = (uint32_t)(py * P.w + px); r.n = n; r.max_n = max_n; r.prev = prev;
+      r.x = pos.x; r.y = pos.y; r.z = pos.z; r.pad = 0.0f;
+      longs[base + (uint32_t)__popcll(dm & ((1ull << ln) - 1ull))] = r;
+    }
   }
   if (hit) {                                                            // approximate ray-cell intersection, :99-101
     if (partial && !prev_valid) prev = tex3d_tsdf(V, pos_prev.x, pos_prev.y, pos_prev.z);   // sample n-1 is a neighbour's: read it from the halo
@@ -480,7 +528,7 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
       hits[base + (uint32_t)__popcll(hm & ((1ull << ln) - 1ull))] = h;
     }
   }
-  if (inside) {
+  if (inside && !deferred) {
     if (!hit) {                                                         // discard: the target keeps its clear value
       const size_t oi = (size_t)py * R.stride + px;
       R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
@@ -491,10 +539,102 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   }
 }
 
+// Second pass of the march: EIGHT LANES per long ray, eight consecutive samples per lane (64 samples of a ray per round trip,
+// eight rays per wave).  Lane j starts 8j samples further along the ray; it gets there by performing the reference's own
+// chain of `pos += step` additions, so positions, densities, the first positive sample and the sample count are exactly
+// those of the one-at-a-time loop (:89-110).  A single lane walking a 92-sample ray issues ~14 k dependent instructions;
+// here the same ray is two rounds of ~1.4 k.
+__global__ __launch_bounds__(256) void k_march_long(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count,
+                                                    const LongRay* __restrict__ longs, const uint32_t* __restrict__ long_count) {
+  const int ln = threadIdx.x & 63, g = ln >> 3, j = ln & 7;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  const uint32_t count = *long_count;
+  const float sd = V.limit * 0.5f;
+  for (uint32_t r0 = wave * 8u; r0 < count; r0 += n_waves * 8u) {      // wave-uniform loop: the shuffles below need every lane
+    const uint32_t r = r0 + (uint32_t)g;
+    const bool live = r < count;
+    LongRay L = longs[live ? r : r0];
+    const int px = (int)(L.pix % (uint32_t)P.w), py = (int)(L.pix / (uint32_t)P.w);
+    const float3 dn = normalize3(pixel_dir_vol(P, (float)px + 0.5f, (float)py + 0.5f));
+    const float3 step = make_float3(dn.x * sd, dn.y * sd, dn.z * sd);
+    float3 pos = make_float3(L.x, L.y, L.z);
+    float prev = L.prev;
+    uint32_t n = L.n;
+    bool done = !live, hit = false;
+    float3 hit_pos = pos;
+    float hit_d = 0.0f;
+    while (__ballot(!done)) {
+      float3 p[kBatch];
+      float d[kBatch];
+      p[0] = pos;
+      for (int t = 0; t < j; ++t) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) p[0] = make_float3(p[0].x + step.x, p[0].y + step.y, p[0].z + step.z);
+      }
+#pragma unroll
+      for (int k = 1; k < kBatch; ++k) p[k] = make_float3(p[k - 1].x + step.x, p[k - 1].y + step.y, p[k - 1].z + step.z);
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) d[k] = tex3d_tsdf(V, p[k].x, p[k].y, p[k].z);     // unconditional: taps are clamped into the allocation
+      // examine this lane's eight samples in order
+      bool lhit = false, lprev_set = false;
+      float lprev = 0.0f, lhd = 0.0f;
+      float3 lhp = pos;
+      uint32_t lk = 0;
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const bool valid = n + (uint32_t)(kBatch * j + k) < L.max_n;
+        if (!lhit && valid) {
+          if (d[k] > 0.0f) { lhit = true; lk = (uint32_t)k; lhp = p[k]; lhd = d[k]; }
+          else { lprev = d[k]; lprev_set = true; }
+        }
+      }
+      // the ray's first hit is in the lowest lane of its group that found one
+      const uint32_t gm = (uint32_t)(__ballot(lhit && !done) >> (8 * g)) & 0xffu;
+      const float d7_before = __shfl(d[kBatch - 1], ln > 0 ? ln - 1 : 0);               // last sample of the lane one batch earlier
+      const int last = 8 * g + 7;
+      const float d7_last = __shfl(d[kBatch - 1], last);
+      const float3 p7_last = make_float3(__shfl(p[kBatch - 1].x, last), __shfl(p[kBatch - 1].y, last), __shfl(p[kBatch - 1].z, last));
+      if (!done) {
+        if (gm) {
+          const int jw = __ffs((int)gm) - 1;
+          // broadcast the winner's result to the group (every lane of the group keeps a copy; lane 0 writes it out)
+          const int src = 8 * g + jw;
+          const float wprev = lprev_set ? lprev : (j > 0 ? d7_before : prev);
+          prev = __shfl(wprev, src);
+          hit_pos = make_float3(__shfl(lhp.x, src), __shfl(lhp.y, src), __shfl(lhp.z, src));
+          hit_d = __shfl(lhd, src);
+          n += (uint32_t)(kBatch * jw) + __shfl(lk, src) + 1u;
+          hit = true; done = true;
+        } else if (L.max_n - n <= (uint32_t)(8 * kBatch)) {
+          n = L.max_n; done = true;
+        } else {
+          prev = d7_last;
+          pos = make_float3(p7_last.x + step.x, p7_last.y + step.y, p7_last.z + step.z);
+          n += (uint32_t)(8 * kBatch);
+        }
+      }
+    }
+    if (live && j == 0) {
+      if (hit) {                                                        // approximate ray-cell intersection, :99-101
+        const float kk = prev / (hit_d - prev);
+        Hit h;
+        h.x = (hit_pos.x - step.x) - step.x * kk; h.y = (hit_pos.y - step.y) - step.y * kk; h.z = (hit_pos.z - step.z) - step.z * kk;
+        h.pix = L.pix;
+        hits[atomicAdd(hit_count, 1u)] = h;
+      } else {
+        const size_t oi = (size_t)py * R.stride + px;
+        R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
+        R.depth[oi] = 1.0f;
+      }
+      R.nsamples[(size_t)py * P.w + px] = (float)n * 0.0027f;           // writeNumSamples(), :395-398
+    }
+  }
+}
+
 // submitFragment(), :116-134, one thread per hit.  Thread 0 also re-arms the OTHER hit counter for the next frame.
 __global__ __launch_bounds__(256) void k_shade(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
                                                const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { next_count[0] = 0u; next_count[2] = 0u; }   // hit + long-ray counters of the next frame
   const uint32_t n_hits = *hit_count;
   const float limit = V.limit, sd = limit * 0.5f;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += gridDim.x * blockDim.x) {
@@ -527,7 +667,7 @@ __global__ __launch_bounds__(256) void k_shade(ViewParams P, StreamTable T, Fram
   }
 }
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
-                     void* hit_list, uint32_t* hit_counters, int parity, int phase) {
+                     void* hit_list, uint32_t* hit_counters, int parity, int phase, void* long_list, uint32_t cap) {
   // phase 2: k_march alone; phase 3: k_shade alone; 0: everything (the split lets the caller time the march kernel alone)
   if (kUseSkip && phase != 3) {
     hipMemsetAsync(V.pyr, 0, (size_t)V.pyr_off[0] * sizeof(uint32_t), st);
@@ -535,9 +675,13 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
   }
   dim3 grid((P.w + 15) / 16, (P.h + 15) / 16);
   const size_t lds = kUseSkip ? (size_t)V.pyr_off[0] * sizeof(uint32_t) : 0;
+  // counters: [hit parity 0, hit parity 1, long parity 0, long parity 1]
+  const bool two_pass = !partial && !kUseSkip && P.skip && long_list && cap != 0xffffffffu;
   if (phase != 3) {
-    if (partial) hipLaunchKernelGGL(k_march<true>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
-    else hipLaunchKernelGGL(k_march<false>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+    if (partial) hipLaunchKernelGGL(k_march<true>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity, (LongRay*)nullptr, hit_counters + 2 + parity, 0xffffffffu);
+    else hipLaunchKernelGGL(k_march<false>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity, (LongRay*)long_list, hit_counters + 2 + parity,
+                            two_pass ? cap : 0xffffffffu);
+    if (two_pass) hipLaunchKernelGGL(k_march_long, dim3(512), dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity, (const LongRay*)long_list, hit_counters + 2 + parity);
   }
   if (phase == 2) return;
   hipLaunchKernelGGL(k_shade, dim3(1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1));

@@ -169,10 +169,16 @@ int integrate_box_cap();
 void launch_mark_all_mixed(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
 void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* linear);
-void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels);
-struct RayTarget { float4* color; float* depth; int stride; float* nsamples; const float4* peels; float clear[4]; };
+void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels, uint8_t* touched_cur = nullptr, const uint8_t* touched_prev = nullptr);
+struct LongRay { uint32_t pix, n, max_n; float prev; float x, y, z, pad; };   // state of a ray handed to k_march_long
+struct RayTarget {
+  float4* color; float* depth; int stride; float* nsamples; const float4* peels; float clear[4];
+  const uint8_t* touched_cur; uint8_t* touched_prev; int rewrite_all;   // 8x8-pixel tile history (k_raymarch.hip); null = none
+};
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
-                     void* hit_list, uint32_t* hit_counters, int parity, int phase = 0);   // hit_list: 16 B per view pixel; two counters used alternately
+                     void* hit_list, uint32_t* hit_counters, int parity, int phase = 0, void* long_list = nullptr, uint32_t cap = 0xffffffffu);
+// hit_list: 16 B per view pixel; long_list: 32 B per view pixel (rays handed to the wave-per-ray pass after `cap` samples);
+// hit_counters: 4 words [hit, hit', long, long'], the primed ones re-armed for the next frame by k_shade
 void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod);
 void launch_inpaint_pyramid(hipStream_t st, const Atlas& A);
 void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth);
