@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-GROUPS = {"k_integrate_tiles_lds": ("k_integrate_tiles_lds",), "k_march+k_shade": ("k_march", "k_shade")}
+GROUPS = {"k_integrate_tiles_lds": ("k_integrate_tiles_lds",), "k_march": ("k_march",), "k_march+k_shade": ("k_march", "k_shade")}   # k_march covers both passes (k_march<>, k_march_long)
 
 
 def per_kernel(path):
