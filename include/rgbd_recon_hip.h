@@ -93,6 +93,14 @@ int32_t tsdf_calib_volume_read(const char* path, uint32_t texel_floats, float* d
 int32_t tsdf_calib_volume_write(const char* path, uint32_t texel_floats, const uint32_t res[3], const float depth_limits[2], const float* data);
 const char* tsdf_calib_last_error(void);
 
+/* ---- the point back-end behind the same interface: kinect::ReconPoints::draw(),
+ * framework/reconstruction/recon_points.cpp:71-111 + glsl/points.{vs,gs,fs}: one depth-tested point sprite per depth pixel
+ * and sensor (size 10 / eye distance, 4 in shade mode 3), flat-shaded with the sensor's colour image and normal.
+ * Reads what the TSDF path reads (frame, cv_xyz, cv_uv) plus the NetKinectArray normal array: tsdf_process_textures
+ * produces it, or upload it with tsdf_upload_normals ([N][H][W][3]).  Result: tsdf_download_framebuffer. */
+int32_t tsdf_upload_normals(tsdf_ctx* ctx, const float* normals_rgb);
+int32_t tsdf_draw_points(tsdf_ctx* ctx, const float modelview[16], const float projection[16]);
+
 /* ---- inverse calibration volumes: the offline tool source/calib_inverter.cpp.
  * tsdf_frustum_from_volume: kinect::Frustum built from the 8 corner texels of a forward volume (getCornerPoints,
  *   calibration_inverter.cpp:117-133; planes + inside(): frustum.cpp) -> planes[6][4] (near far left right top bottom,

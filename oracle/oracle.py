@@ -165,6 +165,14 @@ class OracleRecon:
 
     def fillColors(self): self._L.orc_fill_colors(self._c)
 
+    # --- kinect::ReconPoints (recon_points.cpp): the point back-end behind the same Reconstruction interface
+    def upload_normals(self, normals):
+        self._normals = _f32(normals)
+        self._L.orc_set_normals(self._c, _p(self._normals))
+
+    def drawPoints(self, mv, proj):
+        self._L.orc_draw_points(self._c, _p(_f32(mv)), _p(_f32(proj)))
+
     def drawF(self, mv, proj):
         self.draw(mv, proj)
         if self.flags["fill_holes"]:

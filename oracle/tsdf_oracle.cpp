@@ -193,6 +193,7 @@ struct orc_ctx {
   std::vector<float> peels;                   // m_view_depth RGBA32F
   std::vector<float> nsamples;                // tex_num_samples
   std::vector<float> fb_c, fb_d;              // "default framebuffer" colour / depth
+  const float* normals = nullptr;             // [N][H][W][3] kinect_normals (NetKinectArray "normal" array) for the point back-end
   int shade_mode = 0;
 };
 
@@ -1221,6 +1222,78 @@ void orc_invert_calibration(const float* xyz, const uint32_t res[3], const float
         }
         wi = {wi.x / tw, wi.y / tw, wi.z / tw};
         o[0] = (wi.x + 0.5f) / cd.x; o[1] = (wi.y + 0.5f) / cd.y; o[2] = (wi.z + 0.5f) / cd.z; o[3] = 1.0f;
+      }
+}
+
+
+// ================================================================= point back-end (first half)
+// kinect::ReconPoints::draw(), framework/reconstruction/recon_points.cpp:71-111, with glsl/points.vs / .gs / .fs:
+// one GL point per depth pixel and layer, layers in order, depth test GL_LESS into the cleared default framebuffer.
+// Every varying is `flat`, so a pixel shows the colour of the nearest point that covers it; between equal depths the
+// point drawn first wins (layer, then row-major pixel order: the order of the vertex buffer, recon_points.cpp:46-52).
+// Definitions GL leaves to the implementation (the kernels use the same ones):
+//   * P * MV is formed once in double and rounded to float (gl_Position = gl_ProjectionMatrix * gl_ModelViewMatrix * v);
+//   * gl_NormalMatrix, redeclared as a mat4 uniform by points.fs, is inverseTranspose(MV) (the fixed-function matrix);
+//   * a point is clipped by its centre; gl_PointSize is clamped to [1, 2047] and, with GL_POINT_SPRITE enabled
+//     (kinect_client.cpp:258-259), not rounded: it covers the pixels whose centre lies in [c - s/2, c + s/2) per axis;
+//   * window z = ndc.z * 0.5 + 0.5 in fp32 (no 24-bit quantisation).
+void orc_set_normals(orc_ctx* c, const float* normals) { c->normals = normals; }
+void orc_draw_points(orc_ctx* c, const float* mv16, const float* proj16) {
+  const view_mats V = make_view(c, mv16, proj16);
+  double mvd[16], prd[16], pm[16];
+  to_d(mv16, mvd); to_d(proj16, prd); mul_d(prd, mvd, pm);
+  const mat4 PMV = to_f(pm);
+  const int W = (int)c->cfg.depth_w, H = (int)c->cfg.depth_h, N = (int)c->cfg.num_streams, CW = (int)c->cfg.color_w, CH = (int)c->cfg.color_h;
+  const int vw = (int)c->vw, vh = (int)c->vh;
+  const float* normals = c->normals ? c->normals : (c->pp_normal.empty() ? nullptr : c->pp_normal.data());
+  for (size_t i = 0; i < c->fb_d.size(); ++i) { c->fb_c[4 * i] = c->fb_c[4 * i + 1] = c->fb_c[4 * i + 2] = c->fb_c[4 * i + 3] = 0.0f; c->fb_d[i] = 1.0f; }
+  const float stepX = 1.0f / (float)W, stepY = 1.0f / (float)H;                     // recon_points.cpp:44-45
+  const float max_size = c->shade_mode == 3 ? 4.0f : 10.0f;                          // points.gs:49-53
+  for (int l = 0; l < N; ++l)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const float u = (float)(((double)x + 0.5) * (double)stepX), v = (float)(((double)y + 0.5) * (double)stepY);   // :48
+        const float depth = c->depth[((size_t)l * W * H + (size_t)y * W + x) * 2];   // texel (x, y) at its own centre
+        float pc[3], tc[2];
+        tex3d(c->xyz[l], 3, c->xyz_res[l], u, v, depth, pc);                          // points.vs:27
+        tex3d(c->uv[l], 2, c->uv_res[l], u, v, depth, tc);                            // :29
+        const vec3 pos_cs = {pc[0], pc[1], pc[2]};
+        if (!in_bbox(c, pos_cs) || depth <= 0.0f) continue;                          // points.gs:36-38
+        if (tc[0] > 0.99f || tc[0] < 0.01f || tc[1] > 0.99f || tc[1] < 0.01f) continue;   // points.fs:38-41 (flat: the whole point)
+        const vec4 pe = mul(V.mv, {pos_cs.x, pos_cs.y, pos_cs.z, 1.0f});
+        const vec3 pos_es = {pe.x, pe.y, pe.z};
+        const vec4 clip = mul(PMV, {pos_cs.x, pos_cs.y, pos_cs.z, 1.0f});
+        if (!(clip.w > 0.0f) || fabsf(clip.x) > clip.w || fabsf(clip.y) > clip.w || fabsf(clip.z) > clip.w) continue;
+        const float xw = (clip.x / clip.w * 0.5f + 0.5f) * (float)vw, yw = (clip.y / clip.w * 0.5f + 0.5f) * (float)vh;
+        const float zw = clip.z / clip.w * 0.5f + 0.5f;
+        if (!(zw < 1.0f)) continue;
+        const float size = fminf(fmaxf(max_size / length(pos_es), 1.0f), 2047.0f);   // points.gs:55
+        const float half = size * 0.5f;
+        int x0 = (int)ceilf((xw - half) - 0.5f), x1 = (int)ceilf((xw + half) - 0.5f) - 1;
+        int y0 = (int)ceilf((yw - half) - 0.5f), y1 = (int)ceilf((yw + half) - 0.5f) - 1;
+        x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0; x1 = x1 > vw - 1 ? vw - 1 : x1; y1 = y1 > vh - 1 ? vh - 1 : y1;
+        vec3 out = {0, 0, 0};
+        bool shaded = false;
+        for (int py = y0; py <= y1; ++py)
+          for (int px = x0; px <= x1; ++px) {
+            const size_t o = (size_t)py * vw + px;
+            if (!(zw < c->fb_d[o])) continue;                                        // GL_LESS
+            if (!shaded) {                                                           // points.fs:64-75
+              shaded = true;
+              if (c->shade_mode == 3) out = {camera_colors[l & 7][0], camera_colors[l & 7][1], camera_colors[l & 7][2]};
+              else {
+                float col[3];
+                tex2d_linear_u8(c->color, CW, CH, l, tc[0], tc[1], col);
+                vec3 n = {0, 0, 0};
+                if (normals) { const float* t = normals + ((size_t)l * W * H + (size_t)y * W + x) * 3; n = {t[0], t[1], t[2]}; }
+                const float* mi = V.mv_inv.m;                                        // inverseTranspose(MV) * (n, 0): columns of MV^-1 dotted with n
+                const vec3 vn = {mi[0] * n.x + mi[1] * n.y + mi[2] * n.z, mi[4] * n.x + mi[5] * n.y + mi[6] * n.z, mi[8] * n.x + mi[9] * n.y + mi[10] * n.z};
+                out = shade(c, V, pos_es, vn, {col[0], col[1], col[2]});
+              }
+            }
+            c->fb_c[4 * o] = out.x; c->fb_c[4 * o + 1] = out.y; c->fb_c[4 * o + 2] = out.z; c->fb_c[4 * o + 3] = 1.0f;
+            c->fb_d[o] = zw;
+          }
       }
 }
 

@@ -305,6 +305,13 @@ class ReconIntegrationHip:
 
     def integrate(self): self._ck(self._L.tsdf_integrate(self._c))
     def draw(self, mv, proj): self._ck(self._L.tsdf_raymarch(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
+    # kinect::ReconPoints (recon_points.cpp): the point back-end
+    def upload_normals(self, normals):
+        self._ck(self._L.tsdf_upload_normals(self._c, _fp(_f32(normals))))
+
+    def drawPoints(self, mv, proj):
+        self._ck(self._L.tsdf_draw_points(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
+
     def fillColors(self): self._ck(self._L.tsdf_fill_colors(self._c))
     def drawF(self, mv, proj): self._ck(self._L.tsdf_draw_f(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
     def setTsdfLimit(self, v): self._ck(self._L.tsdf_set_tsdf_limit(self._c, C.c_float(v)))

@@ -826,6 +826,43 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
 }
+// ---- the point back-end behind the same Reconstruction interface (kinect::ReconPoints, recon_points.cpp)
+int32_t tsdf_upload_normals(tsdf_ctx* c, const float* normals_rgb) {
+  CHECK_CTX(c);
+  if (!normals_rgb) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "null normals");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h;
+  if (!c->d_normal) HIP_TRY(c, hipMalloc(&c->d_normal, np * sizeof(float4)));
+  std::vector<float4> padded(np);
+  for (size_t i = 0; i < np; ++i) padded[i] = make_float4(normals_rgb[3 * i], normals_rgb[3 * i + 1], normals_rgb[3 * i + 2], 0.0f);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(c->d_normal, padded.data(), np * sizeof(float4), hipMemcpyHostToDevice));
+  return TSDF_OK;
+}
+int32_t tsdf_draw_points(tsdf_ctx* c, const float* mv, const float* pr) {
+  CHECK_CTX(c);
+  if (!mv || !pr) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "null matrix");
+  int32_t rc = require_inputs(c, true, true);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  ViewParams P;
+  if (!make_view_params(c, mv, pr, &P)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "singular modelview / projection matrix");
+  PointParams Q{};
+  double mvd[16], prd[16], pm[16];
+  for (int i = 0; i < 16; ++i) { mvd[i] = mv[i]; prd[i] = pr[i]; }
+  mat_mul_d(prd, mvd, pm);
+  for (int i = 0; i < 16; ++i) Q.pmv.m[i] = (float)pm[i];
+  for (int a = 0; a < 3; ++a) { Q.bbox_min[a] = c->cfg.bbox_min[a]; Q.bbox_max[a] = c->cfg.bbox_max[a]; }
+  Q.normals = c->d_normal;
+  if (!c->d_comp_key) HIP_TRY(c, hipMalloc(&c->d_comp_key, (size_t)c->vw * c->vh * sizeof(unsigned long long)));
+  FrameImages F = c->frame;
+  F.depth = c->d_depth_plane;
+  timer_begin(c, "points");
+  launch_draw_points(c->stream, P, Q, c->luts, F, c->d_comp_key, c->d_fb_c, c->d_fb_d);
+  timer_end(c, "points");
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
 int32_t tsdf_raymarch(tsdf_ctx* c, const float* mv, const float* pr) {
   CHECK_CTX(c);
   int32_t rc = raymarch_impl(c, mv, pr, true);

@@ -134,6 +134,15 @@ struct PreBuffers {
   float4* dqs;            // packed {depth.r, quality, silhouette, 0}
   float* depth_plane;
 };
+// point back-end (k_points.hip)
+struct PointParams {
+  Mat4 pmv;                     // P * MV, formed in double, rounded once
+  float bbox_min[3], bbox_max[3];
+  const float4* normals;        // [N][H][W] kinect_normals (xyz), may be null
+};
+void launch_draw_points(hipStream_t st, const ViewParams& P, const PointParams& Q, const StreamTable& T, const FrameImages& F, unsigned long long* key,
+                        float4* fb_c, float* fb_d);
+
 // inverse calibration volume builder (k_inverter.hip)
 struct InverterGrid {
   uint32_t rx, ry, rz, n;     // forward volume resolution, sample count

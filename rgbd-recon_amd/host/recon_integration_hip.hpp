@@ -125,6 +125,9 @@ class ReconIntegrationHip {
     tsdf.resize((std::size_t)r[0] * r[1] * r[2]);
     check(tsdf_download_volume(m_ctx, tsdf.data()));
   }
+  // ---- kinect::ReconPoints::draw() (recon_points.cpp:71-111) on the same inputs: the point back-end for A/B comparison
+  void uploadNormals(const float* normals_rgb) { check(tsdf_upload_normals(m_ctx, normals_rgb)); }
+  void drawPoints() { check(tsdf_draw_points(m_ctx, m_mv, m_proj)); }
   tsdf_ctx* handle() const { return m_ctx; }
 
  private:
