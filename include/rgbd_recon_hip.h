@@ -100,6 +100,12 @@ const char* tsdf_calib_last_error(void);
  * produces it, or upload it with tsdf_upload_normals ([N][H][W][3]).  Result: tsdf_download_framebuffer. */
 int32_t tsdf_upload_normals(tsdf_ctx* ctx, const float* normals_rgb);
 int32_t tsdf_draw_points(tsdf_ctx* ctx, const float modelview[16], const float projection[16]);
+/* kinect::ReconTrigrid::draw(), framework/reconstruction/recon_trigrid.cpp:85-148 + glsl/trigrid_accum.{vs,gs,fs},
+ * trigrid_normalize.fs: two triangles per depth-pixel cell and sensor; z pre-pass, quality-weighted blend of all fragments
+ * within 0.075 m of the front surface, normalise.  min_length: Reconstruction::m_min_length = CalibrationFiles::minLength()
+ * (default 0.0125, KinectCalibrationFile.cpp:96).  Result: tsdf_download_framebuffer. */
+int32_t tsdf_set_min_length(tsdf_ctx* ctx, float min_length);
+int32_t tsdf_draw_trigrid(tsdf_ctx* ctx, const float modelview[16], const float projection[16]);
 
 /* ---- inverse calibration volumes: the offline tool source/calib_inverter.cpp.
  * tsdf_frustum_from_volume: kinect::Frustum built from the 8 corner texels of a forward volume (getCornerPoints,

@@ -173,6 +173,12 @@ class OracleRecon:
     def drawPoints(self, mv, proj):
         self._L.orc_draw_points(self._c, _p(_f32(mv)), _p(_f32(proj)))
 
+    # --- kinect::ReconTrigrid (recon_trigrid.cpp): the triangle-grid back-end
+    def setMinLength(self, v): self._L.orc_set_min_length(self._c, C.c_float(v))
+
+    def drawTrigrid(self, mv, proj):
+        self._L.orc_draw_trigrid(self._c, _p(_f32(mv)), _p(_f32(proj)))
+
     def drawF(self, mv, proj):
         self.draw(mv, proj)
         if self.flags["fill_holes"]:

@@ -193,6 +193,7 @@ struct orc_ctx {
   std::vector<float> peels;                   // m_view_depth RGBA32F
   std::vector<float> nsamples;                // tex_num_samples
   std::vector<float> fb_c, fb_d;              // "default framebuffer" colour / depth
+  float min_length = 0.0125f;                 // KinectCalibrationFile::min_length default (KinectCalibrationFile.cpp:96) -> Reconstruction::m_min_length
   const float* normals = nullptr;             // [N][H][W][3] kinect_normals (NetKinectArray "normal" array) for the point back-end
   int shade_mode = 0;
 };
@@ -1295,6 +1296,160 @@ void orc_draw_points(orc_ctx* c, const float* mv16, const float* proj16) {
             c->fb_d[o] = zw;
           }
       }
+}
+
+
+// ================================================================= triangle-grid back-end (second half)
+// kinect::ReconTrigrid::draw(), framework/reconstruction/recon_trigrid.cpp:85-148, with glsl/trigrid_accum.{vs,gs,fs} and
+// trigrid_normalize.fs: two triangles per depth-pixel cell and layer; pass 1 z-buffers the surfaces, pass 2 adds up
+// quality-weighted shaded colour of every fragment within epsilon (0.075) of the front surface, pass 3 divides.
+// Restated literally, including
+//   * the vertex buffer's swapped loop bounds (recon_trigrid.cpp:53-54: y < width, x < height): cells x < H, y < W --
+//     columns >= H of a W x H image are never drawn and the rows past the image collapse to zero-area triangles;
+//   * trigrid_accum.fs:69: gl_FragCoord.xy + 0.5 (one pixel diagonal offset of the reprojected surface position).
+// Definitions GL leaves to the implementation (shared with the kernels): P*MV formed in double; gl_NormalMatrix unused here;
+// a triangle with a vertex at w <= 0 is dropped; pixel-centre sampling, edge functions in fp32 with a top-left style
+// tie-break on exact zeros; window z linear in screen space, fragments outside 0 <= z <= 1 dropped; smooth varyings
+// perspective-correct as sum(l_i a_i / w_i) / sum(l_i / w_i); depth and quality images sampled NEAREST (the positions are
+// texel centres or clamp to them); additive blending in draw order (fp32).
+}  // extern "C" (helpers with templates follow)
+namespace {
+struct TriVert { vec3 pos_cs, pos_es; float tcx, tcy, depth, quality, xw, yw, zw, iw; bool front; };
+struct TriSetup { TriVert v[3]; vec3 normal; float area; bool ok; };
+
+TriVert tri_vertex(const orc_ctx* c, const view_mats& V, const mat4& PMV, int l, int gx, int gy) {
+  const int W = (int)c->cfg.depth_w, H = (int)c->cfg.depth_h;
+  const float stepX = 1.0f / (float)W, stepY = 1.0f / (float)H;                       // recon_trigrid.cpp:51-52
+  const float u = (float)(((double)gx + 0.5) * (double)stepX), v = (float)(((double)gy + 0.5) * (double)stepY);
+  TriVert t;
+  t.depth = tex2d_nearest(c->depth, 2, W, H, l, u, v, 0);
+  t.quality = tex2d_nearest(c->quality, 1, W, H, l, u, v, 0);
+  float pc[3], tc[2];
+  tex3d(c->xyz[l], 3, c->xyz_res[l], u, v, t.depth, pc);
+  tex3d(c->uv[l], 2, c->uv_res[l], u, v, t.depth, tc);
+  t.pos_cs = {pc[0], pc[1], pc[2]}; t.tcx = tc[0]; t.tcy = tc[1];
+  const vec4 pe = mul(V.mv, {pc[0], pc[1], pc[2], 1.0f});
+  t.pos_es = {pe.x, pe.y, pe.z};
+  const vec4 clip = mul(PMV, {pc[0], pc[1], pc[2], 1.0f});
+  t.front = clip.w > 0.0f;
+  t.iw = 1.0f / clip.w;
+  t.xw = (clip.x / clip.w * 0.5f + 0.5f) * (float)c->vw;
+  t.yw = (clip.y / clip.w * 0.5f + 0.5f) * (float)c->vh;
+  t.zw = clip.z / clip.w * 0.5f + 0.5f;
+  return t;
+}
+TriSetup tri_setup(const orc_ctx* c, TriVert a, TriVert b, TriVert d) {                 // trigrid_accum.gs
+  TriSetup T; T.v[0] = a; T.v[1] = b; T.v[2] = d; T.ok = false;
+  if (a.depth < 0.0f || b.depth < 0.0f || d.depth < 0.0f) return T;                    // validSurface, :31-42
+  const float avg = (a.depth + b.depth + d.depth) / 3.0f;
+  const float l = c->min_length * avg * 4.0f;
+  if (!(length(b.pos_cs - a.pos_cs) < l && length(d.pos_cs - a.pos_cs) < l && length(d.pos_cs - b.pos_cs) < l)) return T;
+  if (!(a.front && b.front && d.front)) return T;
+  const vec3 ea = b.pos_es - a.pos_es, eb = d.pos_es - a.pos_es;
+  T.normal = normalize(vec3{ea.y * eb.z - eb.y * ea.z, ea.z * eb.x - eb.z * ea.x, ea.x * eb.y - eb.x * ea.y});   // normalize(cross(a, b)), :59
+  T.area = (b.xw - a.xw) * (d.yw - a.yw) - (d.xw - a.xw) * (b.yw - a.yw);
+  if (!(T.area != 0.0f)) return T;
+  T.ok = true;
+  return T;
+}
+struct Fragment { float z, tcx, tcy, quality; vec3 pos_es, pos_cs; };
+// coverage + interpolation at pixel centre (px + .5, py + .5); false: not covered
+inline bool tri_fragment(const TriSetup& T, int px, int py, Fragment& f) {
+  const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+  const TriVert &a = T.v[0], &b = T.v[1], &d = T.v[2];
+  float e0 = (d.xw - b.xw) * (y - b.yw) - (d.yw - b.yw) * (x - b.xw);                    // edge b->d, opposite a
+  float e1 = (a.xw - d.xw) * (y - d.yw) - (a.yw - d.yw) * (x - d.xw);                    // edge d->a, opposite b
+  float e2 = (b.xw - a.xw) * (y - a.yw) - (b.yw - a.yw) * (x - a.xw);                    // edge a->b, opposite d
+  const float sgn = T.area > 0.0f ? 1.0f : -1.0f;
+  const float ex[3] = {(d.xw - b.xw) * sgn, (a.xw - d.xw) * sgn, (b.xw - a.xw) * sgn}, ey[3] = {(d.yw - b.yw) * sgn, (a.yw - d.yw) * sgn, (b.yw - a.yw) * sgn};
+  const float ee[3] = {e0 * sgn, e1 * sgn, e2 * sgn};
+  for (int i = 0; i < 3; ++i) {
+    if (ee[i] < 0.0f) return false;
+    if (ee[i] == 0.0f && !(ey[i] > 0.0f || (ey[i] == 0.0f && ex[i] < 0.0f))) return false;   // a pixel centre exactly on an edge belongs to one side only
+    if (!(ee[i] >= 0.0f)) return false;                                                      // NaN
+  }
+  const float l0 = e0 / T.area, l1 = e1 / T.area, l2 = e2 / T.area;
+  f.z = l0 * a.zw + l1 * b.zw + l2 * d.zw;
+  if (!(f.z >= 0.0f && f.z <= 1.0f)) return false;
+  const float w0 = l0 * a.iw, w1 = l1 * b.iw, w2 = l2 * d.iw, iw = w0 + w1 + w2;
+  auto ip = [&](float p, float q, float r) { return (w0 * p + w1 * q + w2 * r) / iw; };
+  f.tcx = ip(a.tcx, b.tcx, d.tcx); f.tcy = ip(a.tcy, b.tcy, d.tcy); f.quality = ip(a.quality, b.quality, d.quality);
+  f.pos_es = {ip(a.pos_es.x, b.pos_es.x, d.pos_es.x), ip(a.pos_es.y, b.pos_es.y, d.pos_es.y), ip(a.pos_es.z, b.pos_es.z, d.pos_es.z)};
+  f.pos_cs = {ip(a.pos_cs.x, b.pos_cs.x, d.pos_cs.x), ip(a.pos_cs.y, b.pos_cs.y, d.pos_cs.y), ip(a.pos_cs.z, b.pos_cs.z, d.pos_cs.z)};
+  return true;
+}
+// the tests every stage applies (trigrid_accum.fs:44-62); n = -normalize(pass_normal_es)
+inline bool tri_fragment_kept(const orc_ctx* c, const TriSetup& T, const Fragment& f, vec3& n) {
+  if (!in_bbox(c, f.pos_cs)) return false;
+  if (f.tcx > 0.99f || f.tcx < 0.01f || f.tcy > 0.99f || f.tcy < 0.01f) return false;
+  const vec3 nn = normalize(T.normal);
+  n = {-nn.x, -nn.y, -nn.z};
+  if (dot(n, normalize(f.pos_es)) > 0.0f) return false;                                  // backface culling
+  return true;
+}
+template <typename F>
+void for_each_triangle(orc_ctx* c, const view_mats& V, const mat4& PMV, F&& body) {
+  const int W = (int)c->cfg.depth_w, H = (int)c->cfg.depth_h, N = (int)c->cfg.num_streams, vw = (int)c->vw, vh = (int)c->vh;
+  for (int l = 0; l < N; ++l)
+    for (int y = 0; y < W; ++y)                                                           // sic: recon_trigrid.cpp:53
+      for (int x = 0; x < H; ++x) {                                                       // sic: :54
+        const TriVert v00 = tri_vertex(c, V, PMV, l, x, y), v10 = tri_vertex(c, V, PMV, l, x + 1, y), v01 = tri_vertex(c, V, PMV, l, x, y + 1),
+                      v11 = tri_vertex(c, V, PMV, l, x + 1, y + 1);
+        const TriSetup tris[2] = {tri_setup(c, v00, v10, v01), tri_setup(c, v10, v11, v01)};   // :55-61
+        for (const TriSetup& T : tris) {
+          if (!T.ok) continue;
+          const float minx = fminf(fminf(T.v[0].xw, T.v[1].xw), T.v[2].xw), maxx = fmaxf(fmaxf(T.v[0].xw, T.v[1].xw), T.v[2].xw);
+          const float miny = fminf(fminf(T.v[0].yw, T.v[1].yw), T.v[2].yw), maxy = fmaxf(fmaxf(T.v[0].yw, T.v[1].yw), T.v[2].yw);
+          if (!(maxx >= 0.0f && maxy >= 0.0f && minx <= (float)vw && miny <= (float)vh)) continue;
+          const int x0 = (int)fmaxf(floorf(minx - 0.5f), 0.0f), x1 = (int)fminf(ceilf(maxx - 0.5f), (float)(vw - 1));
+          const int y0 = (int)fmaxf(floorf(miny - 0.5f), 0.0f), y1 = (int)fminf(ceilf(maxy - 0.5f), (float)(vh - 1));
+          for (int py = y0; py <= y1; ++py)
+            for (int px = x0; px <= x1; ++px) {
+              Fragment f;
+              if (!tri_fragment(T, px, py, f)) continue;
+              vec3 n;
+              if (!tri_fragment_kept(c, T, f, n)) continue;
+              body(l, px, py, f, n);
+            }
+        }
+      }
+}
+}  // namespace
+extern "C" {
+
+void orc_set_min_length(orc_ctx* c, float v) { c->min_length = v; }
+void orc_draw_trigrid(orc_ctx* c, const float* mv16, const float* proj16) {
+  const view_mats V = make_view(c, mv16, proj16);
+  double mvd[16], prd[16], pm[16];
+  to_d(mv16, mvd); to_d(proj16, prd); mul_d(prd, mvd, pm);
+  const mat4 PMV = to_f(pm);
+  const int vw = (int)c->vw, vh = (int)c->vh, CW = (int)c->cfg.color_w, CH = (int)c->cfg.color_h;
+  std::vector<float> zbuf((size_t)vw * vh, 1.0f), acc((size_t)vw * vh * 4, 0.0f);
+  for_each_triangle(c, V, PMV, [&](int, int px, int py, const Fragment& f, vec3) {         // stage 0: depth only, GL_LESS
+    float& z = zbuf[(size_t)py * vw + px];
+    if (f.z < z) z = f.z;
+  });
+  const float epsilon = 0.075f;                                                            // recon_trigrid.cpp:35
+  for_each_triangle(c, V, PMV, [&](int l, int px, int py, const Fragment& f, vec3 n) {     // stage 1: blend ONE, ONE
+    const float depth_curr = zbuf[(size_t)py * vw + px];
+    const vec4 pc = mul(V.img_to_eye, {((float)px + 0.5f) + 0.5f, ((float)py + 0.5f) + 0.5f, depth_curr, 1.0f});   // sic, :69
+    const vec3 es = {pc.x / pc.w, pc.y / pc.w, pc.z / pc.w};
+    if (epsilon < length(es - f.pos_es)) return;
+    vec3 col;
+    if (c->shade_mode == 3) col = {camera_colors[l & 7][0], camera_colors[l & 7][1], camera_colors[l & 7][2]};
+    else {
+      float t[3];
+      tex2d_linear_u8(c->color, CW, CH, l, f.tcx, f.tcy, t);
+      col = shade(c, V, f.pos_es, n, {t[0], t[1], t[2]});
+    }
+    float* a = &acc[4 * ((size_t)py * vw + px)];
+    a[0] += col.x * f.quality; a[1] += col.y * f.quality; a[2] += col.z * f.quality; a[3] += f.quality;
+  });
+  for (size_t i = 0; i < (size_t)vw * vh; ++i) {                                           // trigrid_normalize.fs
+    const float* a = &acc[4 * i];
+    if (a[3] > 0.0f) { c->fb_c[4 * i] = a[0] / a[3]; c->fb_c[4 * i + 1] = a[1] / a[3]; c->fb_c[4 * i + 2] = a[2] / a[3]; c->fb_c[4 * i + 3] = a[3] / a[3]; c->fb_d[i] = zbuf[i]; }
+    else { c->fb_c[4 * i] = c->fb_c[4 * i + 1] = c->fb_c[4 * i + 2] = c->fb_c[4 * i + 3] = 0.0f; c->fb_d[i] = 1.0f; }
+  }
 }
 
 }  // extern "C"

@@ -312,6 +312,12 @@ class ReconIntegrationHip:
     def drawPoints(self, mv, proj):
         self._ck(self._L.tsdf_draw_points(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
 
+    # kinect::ReconTrigrid (recon_trigrid.cpp): the triangle-grid back-end
+    def setMinLength(self, v): self._ck(self._L.tsdf_set_min_length(self._c, C.c_float(v)))
+
+    def drawTrigrid(self, mv, proj):
+        self._ck(self._L.tsdf_draw_trigrid(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
+
     def fillColors(self): self._ck(self._L.tsdf_fill_colors(self._c))
     def drawF(self, mv, proj): self._ck(self._L.tsdf_draw_f(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
     def setTsdfLimit(self, v): self._ck(self._L.tsdf_set_tsdf_limit(self._c, C.c_float(v)))

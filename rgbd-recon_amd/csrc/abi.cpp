@@ -75,6 +75,7 @@ struct tsdf_ctx {
   void* d_hits = nullptr; uint32_t* d_hit_counters = nullptr; int hit_parity = 0;
   uint8_t* d_touched[2]{}; int touched_parity = 0; bool tile_history = false;   // image-space dirty tiles (k_raymarch.hip); history is dropped
                                                                                 // whenever something else writes the march target
+  uint32_t* d_tri_z = nullptr; float4* d_tri_acc = nullptr; float min_length = 0.0125f;   // triangle-grid back-end; KinectCalibrationFile.cpp:96 default
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
   void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
   unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
@@ -130,6 +131,7 @@ Mat4 to_mat4(const double* d) { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (f
 void release_view(tsdf_ctx* c) {
   hipFree(c->atlas.color); hipFree(c->atlas.depth); hipFree(c->d_peels); hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
   hipFree(c->d_long); c->d_long = nullptr;
+  hipFree(c->d_tri_z); hipFree(c->d_tri_acc); c->d_tri_z = nullptr; c->d_tri_acc = nullptr;
   hipFree(c->d_touched[0]); hipFree(c->d_touched[1]); c->d_touched[0] = c->d_touched[1] = nullptr; c->tile_history = false;
   hipFree(c->d_hits); hipFree(c->d_hit_counters); hipFree(c->d_comp_key); c->d_hits = nullptr; c->d_hit_counters = nullptr; c->d_comp_key = nullptr;
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
@@ -860,6 +862,30 @@ int32_t tsdf_draw_points(tsdf_ctx* c, const float* mv, const float* pr) {
   timer_begin(c, "points");
   launch_draw_points(c->stream, P, Q, c->luts, F, c->d_comp_key, c->d_fb_c, c->d_fb_d);
   timer_end(c, "points");
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+// kinect::ReconTrigrid (recon_trigrid.cpp)
+int32_t tsdf_set_min_length(tsdf_ctx* c, float v) { CHECK_CTX(c); if (!(v > 0.0f)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "min_length must be positive"); c->min_length = v; return TSDF_OK; }
+int32_t tsdf_draw_trigrid(tsdf_ctx* c, const float* mv, const float* pr) {
+  CHECK_CTX(c);
+  if (!mv || !pr) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "null matrix");
+  int32_t rc = require_inputs(c, true, true);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->device));
+  ViewParams P;
+  if (!make_view_params(c, mv, pr, &P)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "singular modelview / projection matrix");
+  PointParams Q{};
+  double mvd[16], prd[16], pm[16];
+  for (int i = 0; i < 16; ++i) { mvd[i] = mv[i]; prd[i] = pr[i]; }
+  mat_mul_d(prd, mvd, pm);
+  for (int i = 0; i < 16; ++i) Q.pmv.m[i] = (float)pm[i];
+  for (int a = 0; a < 3; ++a) { Q.bbox_min[a] = c->cfg.bbox_min[a]; Q.bbox_max[a] = c->cfg.bbox_max[a]; }
+  const size_t nv = (size_t)c->vw * c->vh;
+  if (!c->d_tri_z) { HIP_TRY(c, hipMalloc(&c->d_tri_z, nv * sizeof(uint32_t))); HIP_TRY(c, hipMalloc(&c->d_tri_acc, nv * sizeof(float4))); }
+  timer_begin(c, "trigrid");
+  launch_draw_trigrid(c->stream, P, Q, c->luts, c->frame, c->min_length, c->d_tri_z, c->d_tri_acc, c->d_fb_c, c->d_fb_d);
+  timer_end(c, "trigrid");
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
 }

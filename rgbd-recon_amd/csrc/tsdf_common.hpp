@@ -143,6 +143,9 @@ struct PointParams {
 void launch_draw_points(hipStream_t st, const ViewParams& P, const PointParams& Q, const StreamTable& T, const FrameImages& F, unsigned long long* key,
                         float4* fb_c, float* fb_d);
 
+void launch_draw_trigrid(hipStream_t st, const ViewParams& P, const PointParams& Q, const StreamTable& T, const FrameImages& F, float min_length, uint32_t* zbuf,
+                         float4* acc, float4* fb_c, float* fb_d);
+
 // inverse calibration volume builder (k_inverter.hip)
 struct InverterGrid {
   uint32_t rx, ry, rz, n;     // forward volume resolution, sample count

@@ -128,6 +128,9 @@ class ReconIntegrationHip {
   // ---- kinect::ReconPoints::draw() (recon_points.cpp:71-111) on the same inputs: the point back-end for A/B comparison
   void uploadNormals(const float* normals_rgb) { check(tsdf_upload_normals(m_ctx, normals_rgb)); }
   void drawPoints() { check(tsdf_draw_points(m_ctx, m_mv, m_proj)); }
+  // ---- kinect::ReconTrigrid::draw() (recon_trigrid.cpp:85-148)
+  void setMinLength(float v) { check(tsdf_set_min_length(m_ctx, v)); }
+  void drawTrigrid() { check(tsdf_draw_trigrid(m_ctx, m_mv, m_proj)); }
   tsdf_ctx* handle() const { return m_ctx; }
 
  private:

@@ -12,3 +12,7 @@ for _ in range(10): hip.drawPoints(mv, pr)
 hip.sync(); t0 = time.perf_counter()
 for _ in range(200): hip.drawPoints(mv, pr)
 hip.sync(); print("drawPoints ms", (time.perf_counter() - t0) / 200 * 1e3, "covered pixels", (hip.framebuffer()[1] < 1).sum())
+for _ in range(5): hip.drawTrigrid(mv, pr)
+hip.sync(); t0 = time.perf_counter()
+for _ in range(100): hip.drawTrigrid(mv, pr)
+hip.sync(); print("drawTrigrid ms", (time.perf_counter() - t0) / 100 * 1e3, "covered pixels", (hip.framebuffer()[1] < 1).sum())
