@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"], help="N > 1: integrate the halo layers locally, or RCCL all-gather them")
     ap.add_argument("--composite", default="compact", choices=["compact", "dense"], help="N > 1: gather hit records, or whole partial images")
+    ap.add_argument("--parallel", default="slabs", choices=["slabs", "frames"],
+                    help="N > 1: 'slabs' = ONE volume split into Z-slabs with the RCCL exchange (the north-star partition, strong scaling); "
+                         "'frames' = every GPU fuses its own frames of the stream (each frame rebuilds the volume from scratch, so frames are "
+                         "independent: no exchange at all, weak scaling)")
     ap.add_argument("--preprocess", action="store_true", help="also run the image pre-processing passes (f1) every frame, from the raw depth/colour")
     ap.add_argument("--ingest", default=None, choices=["f32-rgb8", "f32-dxt1", "u8-rgb8", "u8-dxt1", "u8-dxt5"],
                     help="also measure the wire path (f2): every frame arrives as one host message, is copied through the pinned double "
@@ -128,7 +132,8 @@ def main():
     scene = rr.scene.make_scene(n_streams=cfg["streams"], width=640, height=480, lut_res=LUT, inv_res=LUT)
     ext = scene["bbox_max"] - scene["bbox_min"]
     brick = [float(ext[a]) / cfg["res"][a] * 8 for a in range(3)]          # 8^3 voxels per brick
-    slab = mg.slab_range(cfg["res"][2], rank, world) if world > 1 else (0, 0)
+    frames_mode = world > 1 and args.parallel == "frames"
+    slab = mg.slab_range(cfg["res"][2], rank, world) if (world > 1 and not frames_mode) else (0, 0)
     hip = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, slab=slab,
                                  recompute_halo=(args.halo == "recompute"))
     hip.setUseBricks(cfg["use_bricks"]); hip.setSpaceSkip(cfg["skip_space"]); hip.setColorFilling(cfg["fill_holes"])
@@ -136,7 +141,8 @@ def main():
     hip.set_stream(stream.cuda_stream)         # kernels, HIP event timers and the collectives share one stream
     if args.preprocess:
         hip.upload_raw_frame(scene)
-    drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite, preprocess=args.preprocess)
+    drv = mg.SlabDriver(hip, 0 if frames_mode else rank, 1 if frames_mode else world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite,
+                        preprocess=args.preprocess)
     mv, pr = rr.scene.default_view(*VIEW)
 
     def barrier():
@@ -194,15 +200,16 @@ def main():
         n, ms = hip.timer_stats(dom)
         dom_ms = ms / n if n else None
     ratio = hip.occupiedRatio()
-    ab = algorithmic_bytes(cfg, cfg["streams"], world)
+    ab = algorithmic_bytes(cfg, cfg["streams"], 1 if frames_mode else world)
     out = {
         "metric": "frames/sec (integrate+raymarch) at %d^3 x %d streams" % (cfg["res"][0], cfg["streams"]),
-        "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "value": (world if frames_mode else 1) * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if frames_mode else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "config": args.config, "streams": cfg["streams"], "res": list(cfg["res"]),
                    "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
-                   "parallelism": "single GPU" if world == 1 else f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0"},
+                   "parallelism": "single GPU" if world == 1 else (f"{world} GPUs, each fusing its own frames (no exchange)" if frames_mode else
+                                                                    f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0")},
         "stage_ms": stages,
         "stage_ms_note": "per-stage device time from a separate all-timers pass before the timed region (not part of `value`)",
         "upload_ms_per_frame": upload_ms,

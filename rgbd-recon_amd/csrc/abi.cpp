@@ -822,7 +822,7 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   timer_begin(c, "k_march");
   launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu);
   timer_end(c, "k_march");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3);
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu);
   c->hit_parity ^= 1;
   timer_end(c, "draw");
   HIP_TRY(c, hipGetLastError());

@@ -500,10 +500,12 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
 // chain of `pos += step` additions, so positions, densities, the first positive sample and the sample count are exactly
 // those of the one-at-a-time loop (:89-110).  A single lane walking a 92-sample ray issues ~14 k dependent instructions;
 // here the same ray is two rounds of ~1.4 k.
-__global__ __launch_bounds__(256) void k_march_long(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count,
-                                                    const LongRay* __restrict__ longs, const uint32_t* __restrict__ long_count) {
+struct StreamTable; struct FrameImages;
+__device__ __forceinline__ void shade_hit(const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, const Hit& h);
+__device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V, const RayTarget& R, const LongRay* __restrict__ longs,
+                                           const uint32_t* __restrict__ long_count, uint32_t n_blocks, const StreamTable* T, const FrameImages* F) {
   const int ln = threadIdx.x & 63, g = ln >> 3, j = ln & 7;
-  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = n_blocks * 4u;
   const uint32_t count = *long_count;
   const float sd = V.limit * 0.5f;
   for (uint32_t r0 = wave * 8u; r0 < count; r0 += n_waves * 8u) {      // wave-uniform loop: the shuffles below need every lane
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256) void k_march_long(ViewParams P, Volume V, RayT
         Hit h;
         h.x = (hit_pos.x - step.x) - step.x * kk; h.y = (hit_pos.y - step.y) - step.y * kk; h.z = (hit_pos.z - step.z) - step.z * kk;
         h.pix = L.pix;
-        hits[atomicAdd(hit_count, 1u)] = h;
+        shade_hit(P, *T, *F, V, R, h);                                  // no list: the hit is shaded where it was found
       } else {
         const size_t oi = (size_t)py * R.stride + px;
         R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
@@ -588,39 +590,56 @@ __global__ __launch_bounds__(256) void k_march_long(ViewParams P, Volume V, RayT
 }
 
 // submitFragment(), :116-134, one thread per hit.  Thread 0 also re-arms the OTHER hit counter for the next frame.
+__device__ __forceinline__ void shade_hit(const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, const Hit& h) {
+  const float limit = V.limit, sd = limit * 0.5f;
+  const float3 pos = make_float3(h.x, h.y, h.z);
+  const int px = (int)(h.pix % (uint32_t)P.w), py = (int)(h.pix / (uint32_t)P.w);
+  const float gx = tex3d_tsdf(V, pos.x + sd, pos.y, pos.z) - tex3d_tsdf(V, pos.x - sd, pos.y, pos.z);
+  const float gy = tex3d_tsdf(V, pos.x, pos.y + sd, pos.z) - tex3d_tsdf(V, pos.x, pos.y - sd, pos.z);
+  const float gz = tex3d_tsdf(V, pos.x, pos.y, pos.z + sd) - tex3d_tsdf(V, pos.x, pos.y, pos.z - sd);
+  const float3 gn = normalize3(make_float3(gx, gy, gz));              // get_gradient(), :140-149
+  const float4 vn4 = mat_mul(P.normal, -gn.x, -gn.y, -gn.z, 0.0f);
+  const float3 vn = normalize3(make_float3(vn4.x, vn4.y, vn4.z));
+  const float4 vp4 = mat_mul(P.mv_v2w, pos.x, pos.y, pos.z, 1.0f);
+  const float3 vp = make_float3(vp4.x, vp4.y, vp4.z);
+  float4 col;
+  if (P.shade_mode == 3) {
+    const float3 bc = blend_cameras(T, F, limit, pos);
+    col = make_float4(bc.x, bc.y, bc.z, 1.0f);
+  } else {
+    const float4 dc = blend_colors(T, F, limit, pos);
+    const float3 s = shade(P, vp, vn, make_float3(dc.x, dc.y, dc.z));
+    col = make_float4(s.x, s.y, s.z, dc.w);
+  }
+  float fd = (P.proj.m[10] * vp.z + P.proj.m[14]) / -vp.z * 0.5f + 0.5f;   // gl_FragDepth, :133
+  fd = fminf(fmaxf(fd, 0.0f), 1.0f);
+  const size_t oi = (size_t)py * R.stride + px;
+  const bool pass = fd < 1.0f;                                        // GL_LESS against the cleared 1.0
+  R.color[oi] = pass ? col : make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
+  R.depth[oi] = pass ? fd : 1.0f;
+}
+
+// the hit list of the first march pass, one thread per hit, blocks [first_block, gridDim.x)
+__device__ __forceinline__ void shade_list(const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R,
+                                           const Hit* __restrict__ hits, const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count, uint32_t first_block) {
+  const uint32_t b = blockIdx.x - first_block, nb = gridDim.x - first_block;
+  if (b == 0 && threadIdx.x == 0) { next_count[0] = 0u; next_count[2] = 0u; }   // hit + long-ray counters of the next frame
+  const uint32_t n_hits = *hit_count;
+  for (uint32_t i = b * blockDim.x + threadIdx.x; i < n_hits; i += nb * blockDim.x) shade_hit(P, T, F, V, R, hits[i]);
+}
 __global__ __launch_bounds__(256) void k_shade(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
                                                const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { next_count[0] = 0u; next_count[2] = 0u; }   // hit + long-ray counters of the next frame
-  const uint32_t n_hits = *hit_count;
-  const float limit = V.limit, sd = limit * 0.5f;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += gridDim.x * blockDim.x) {
-    const Hit h = hits[i];
-    const float3 pos = make_float3(h.x, h.y, h.z);
-    const int px = (int)(h.pix % (uint32_t)P.w), py = (int)(h.pix / (uint32_t)P.w);
-    const float gx = tex3d_tsdf(V, pos.x + sd, pos.y, pos.z) - tex3d_tsdf(V, pos.x - sd, pos.y, pos.z);
-    const float gy = tex3d_tsdf(V, pos.x, pos.y + sd, pos.z) - tex3d_tsdf(V, pos.x, pos.y - sd, pos.z);
-    const float gz = tex3d_tsdf(V, pos.x, pos.y, pos.z + sd) - tex3d_tsdf(V, pos.x, pos.y, pos.z - sd);
-    const float3 gn = normalize3(make_float3(gx, gy, gz));              // get_gradient(), :140-149
-    const float4 vn4 = mat_mul(P.normal, -gn.x, -gn.y, -gn.z, 0.0f);
-    const float3 vn = normalize3(make_float3(vn4.x, vn4.y, vn4.z));
-    const float4 vp4 = mat_mul(P.mv_v2w, pos.x, pos.y, pos.z, 1.0f);
-    const float3 vp = make_float3(vp4.x, vp4.y, vp4.z);
-    float4 col;
-    if (P.shade_mode == 3) {
-      const float3 bc = blend_cameras(T, F, limit, pos);
-      col = make_float4(bc.x, bc.y, bc.z, 1.0f);
-    } else {
-      const float4 dc = blend_colors(T, F, limit, pos);
-      const float3 s = shade(P, vp, vn, make_float3(dc.x, dc.y, dc.z));
-      col = make_float4(s.x, s.y, s.z, dc.w);
-    }
-    float fd = (P.proj.m[10] * vp.z + P.proj.m[14]) / -vp.z * 0.5f + 0.5f;   // gl_FragDepth, :133
-    fd = fminf(fmaxf(fd, 0.0f), 1.0f);
-    const size_t oi = (size_t)py * R.stride + px;
-    const bool pass = fd < 1.0f;                                        // GL_LESS against the cleared 1.0
-    R.color[oi] = pass ? col : make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
-    R.depth[oi] = pass ? fd : 1.0f;
-  }
+  shade_list(P, T, F, V, R, hits, hit_count, next_count, 0u);
+}
+// ONE launch for the two independent jobs that follow the first march pass: blocks [0, kLongBlocks) finish the long rays
+// (and shade their own hits on the spot), the rest shade the first pass's hit list.  Saves a dependent launch (~5 us of
+// ramp) and overlaps two latency-bound kernels: 15 + 19 us -> ~21 us.
+constexpr uint32_t kLongBlocks = 512;
+__global__ __launch_bounds__(256) void k_shade_and_long(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
+                                                        const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count,
+                                                        const LongRay* __restrict__ longs, const uint32_t* __restrict__ long_count) {
+  if (blockIdx.x < kLongBlocks) march_long(P, V, R, longs, long_count, kLongBlocks, &T, &F);
+  else shade_list(P, T, F, V, R, hits, hit_count, next_count, kLongBlocks);
 }
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
                      void* hit_list, uint32_t* hit_counters, int parity, int phase, void* long_list, uint32_t cap) {
@@ -637,9 +656,13 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
     if (partial) hipLaunchKernelGGL(k_march<true>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity, (LongRay*)nullptr, hit_counters + 2 + parity, 0xffffffffu);
     else hipLaunchKernelGGL(k_march<false>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity, (LongRay*)long_list, hit_counters + 2 + parity,
                             two_pass ? cap : 0xffffffffu);
-    if (two_pass) hipLaunchKernelGGL(k_march_long, dim3(512), dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity, (const LongRay*)long_list, hit_counters + 2 + parity);
   }
   if (phase == 2) return;
+  if (two_pass) {
+    hipLaunchKernelGGL(k_shade_and_long, dim3(kLongBlocks + 1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1),
+                       (const LongRay*)long_list, hit_counters + 2 + parity);
+    return;
+  }
   hipLaunchKernelGGL(k_shade, dim3(1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1));
 }
 
