@@ -9,6 +9,12 @@
 //  and its arithmetic is GLSL that cannot be executed here (no GL context),
 // so this restatement is pinned only by line-by-line review against the cited sources and by
 // hand-computed known-answer tests (tests/test_oracle_*.py).
+// Exceptions, pinned by the reference's OWN code compiled from its sources into oracle/_ref (oracle/ref/Makefile):
+//   * orc_decode_dxt                      == external/squish DecompressImage   (tests/test_oracle_ingest.py)
+//   * the .stream record layout           == framework/io/FileBuffer           (tests/test_oracle_ingest.py)
+//   * (product side) .cv_* volume files   == calibration_volume.hpp read/write (tests/test_calib_io.py)
+// Everything else below -- TSDF path, pre-processing, inverse-LUT builder (CGAL absent), point / triangle-grid back-ends --
+// is restated, not run.
 //
 // Texture sampling follows OpenGL 4.4 §8.14 with the sampler state the reference sets
 // (SURVEY.md Appendix A): fp32, lerp(a,b,t) = a + (b-a)*t applied x, then y, then z.
