@@ -357,6 +357,8 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   for (int a = 0; a < 3; ++a)
     if (!(cfg->bbox_max[a] > cfg->bbox_min[a])) { g_create_error = "empty bounding box"; return TSDF_ERR_INVALID_ARGUMENT; }
   if (cfg->depth_w < 1 || cfg->depth_h < 1 || cfg->color_w < 1 || cfg->color_h < 1) { g_create_error = "image size must be >= 1"; return TSDF_ERR_INVALID_ARGUMENT; }
+  if ((uint64_t)cfg->depth_w * cfg->depth_h * cfg->num_streams >= (1ull << 24) * 16 || (uint64_t)cfg->depth_w * cfg->depth_h >= (1ull << 24) ||
+      (uint64_t)cfg->color_w * cfg->color_h >= (1ull << 24)) { g_create_error = "images of 2^24 pixels or more are not supported (24-bit index arithmetic)"; return TSDF_ERR_INVALID_ARGUMENT; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible (the HIP path has no CPU fallback)"; return TSDF_ERR_NO_DEVICE; }
   if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return TSDF_ERR_INVALID_ARGUMENT; }
@@ -400,6 +402,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   V.int_tz1 = recompute ? V.tz1 : V.own_tz1;
   if (!whole && V.own_tz1 - V.own_tz0 < c->halo_layers) { c->err = "slab thinner than its halo"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
   const size_t nvox = (size_t)(V.tz1 - V.tz0) * V.nty * V.ntx * TILE_VOX;
+  if (nvox >= (1ull << 32)) { c->err = "a context stores at most 2^32 voxels (32-bit tap offsets); split the volume into Z-slabs"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
   int32_t rc;
   auto tryhip = [&](hipError_t e, const char* what) -> int32_t {
     if (e == hipSuccess) return TSDF_OK;
@@ -490,6 +493,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
   StreamLut& L = c->luts.s[i];
   auto vol_n = [](const uint32_t r[3]) { return (size_t)r[0] * r[1] * r[2]; };
   for (int a = 0; a < 3; ++a) if (ri[a] < 1 || ri[a] > 2048) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "LUT resolution out of range");
+  if ((uint64_t)ri[0] * ri[1] * ri[2] > (1ull << 31)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "inverse LUT larger than 2^31 texels (the kernels index it with 32 bits)");
   float4* d_inv = nullptr;
   HIP_TRY(c, hipMalloc(&d_inv, vol_n(ri) * sizeof(float4)));
   c->lut_allocs.push_back(d_inv);

@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         const int n = min(dx * dy * dz, kBoxCap);
         for (int e = tid; e < n; e += 256) {
           const int bx = e % dx, by = (e / dx) % dy, bz = e / (dx * dy);
-          s_box[c][e] = L.inv[((size_t)(mz + bz) * L.inv_res[1] + (my + by)) * L.inv_res[0] + (mx + bx)];
+          // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate and this launch is VALU-issue bound): operands are LUT
+          // coordinates / resolutions <= 2048, the texel index fits 32 bits (tsdf_set_calibration rejects larger LUTs)
+          s_box[c][e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
         }
       }
       __syncthreads();
@@ -251,7 +253,8 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         const int n1 = min(dy * dz * 8, kRowCap);
         for (int e = tid; e < n1; e += 256) {
           const int k = e & 7, row = e >> 3;
-          const float4 a = s_box[c][row * dx + (s_i0[c][0][k] - mx)], b = s_box[c][row * dx + (s_i1[c][0][k] - mx)];
+          const int rb = __mul24(row, dx);
+          const float4 a = s_box[c][rb + (s_i0[c][0][k] - mx)], b = s_box[c][rb + (s_i1[c][0][k] - mx)];
           const float3 r = lerp3(a, b, s_w[c][0][k]);
           s_row[c][e] = make_float4(r.x, r.y, r.z, 0.0f);
         }
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         const int n2 = min(dz * 64, kBoxCap);
         for (int e = tid; e < n2; e += 256) {
           const int k = e & 7, j = (e >> 3) & 7, bz = e >> 6;
-          const float4 a = s_row[c][((bz * dy + (s_i0[c][1][j] - my)) << 3) + k], b = s_row[c][((bz * dy + (s_i1[c][1][j] - my)) << 3) + k];
+          const int zb = __mul24(bz, dy);
+          const float4 a = s_row[c][((zb + (s_i0[c][1][j] - my)) << 3) + k], b = s_row[c][((zb + (s_i1[c][1][j] - my)) << 3) + k];
           const float3 r = lerp3(a, b, s_w[c][1][j]);
           s_box[c][e] = make_float4(r.x, r.y, r.z, 0.0f);
         }

@@ -70,7 +70,8 @@ struct Dqs { float4 t00, t10, t01, t11; float ax, ay; };
 __device__ __forceinline__ Dqs dqs_fetch(const FrameImages& F, int layer, float u, float v) {
   const Axis X = axis_linear(u, F.w), Y = axis_linear(v, F.h);
   const float4* __restrict__ b = F.dqs;
-  const uint32_t base = (uint32_t)layer * (uint32_t)(F.w * F.h), r0 = base + (uint32_t)Y.i0 * (uint32_t)F.w, r1 = base + (uint32_t)Y.i1 * (uint32_t)F.w;
+  // 24-bit multiplies: full rate, and every operand (layer < 16, image rows/widths, w*h of a depth image) is far below 2^24
+  const uint32_t base = (uint32_t)__mul24(layer, F.w * F.h), r0 = base + (uint32_t)__mul24(Y.i0, F.w), r1 = base + (uint32_t)__mul24(Y.i1, F.w);
   Dqs r;
   r.t00 = b[r0 + X.i0]; r.t10 = b[r0 + X.i1];
   r.t01 = b[r1 + X.i0]; r.t11 = b[r1 + X.i1];
@@ -96,8 +97,10 @@ __device__ __forceinline__ float dqs_depth(const Dqs& d) {
 // < 2^32 voxels); the address of tap (x,y,z) is the sum of three per-axis partial offsets, so the eight taps of a
 // footprint cost six partials and eight adds instead of eight full index computations.
 __device__ __forceinline__ uint32_t vol_off_x(int x) { return ((uint32_t)(x >> 3) << 9) + (uint32_t)(x & 7); }
-__device__ __forceinline__ uint32_t vol_off_y(const Volume& V, int y) { return (((uint32_t)(y >> 3) * (uint32_t)V.ntx) << 9) + ((uint32_t)(y & 7) << 3); }
-__device__ __forceinline__ uint32_t vol_off_z(const Volume& V, int z) { return (((uint32_t)((z >> 3) - V.tz0) * (uint32_t)(V.nty * V.ntx)) << 9) + ((uint32_t)(z & 7) << 6); }
+// (24-bit multiplies are full rate, v_mul_lo_u32 quarter rate: tile coordinates and tiles-per-plane are far below 2^24 and the
+// products -- tile indices of a context -- below 2^23)
+__device__ __forceinline__ uint32_t vol_off_y(const Volume& V, int y) { return ((uint32_t)__mul24(y >> 3, V.ntx) << 9) + ((uint32_t)(y & 7) << 3); }
+__device__ __forceinline__ uint32_t vol_off_z(const Volume& V, int z) { return ((uint32_t)__mul24((z >> 3) - V.tz0, V.nty * V.ntx) << 9) + ((uint32_t)(z & 7) << 6); }
 __device__ __forceinline__ size_t vol_index(const Volume& V, int x, int y, int z) { return (size_t)(vol_off_x(x) + vol_off_y(V, y) + vol_off_z(V, z)); }
 
 struct TsdfTaps { Axis X, Y, Z; };
