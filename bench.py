@@ -199,6 +199,20 @@ def main():
     if dom:
         n, ms = hip.timer_stats(dom)
         dom_ms = ms / n if n else None
+    # per-frame device time distribution (SURVEY.md section 8d asks for median and p95): one event pair per frame, own short pass
+    frame_ms = None
+    if not args.no_timers:
+        hip.set_timer_filter(["frame"])
+        hip.enable_timers(True)
+        for _ in range(100):
+            hip.timer_begin("frame"); drv.frame(mv, pr); hip.timer_end("frame")
+        barrier()
+        hip.enable_timers(False)
+        hip.set_timer_filter(None)
+        smp = np.sort(hip.timer_samples("frame"))
+        if smp.size:
+            frame_ms = {"frames": int(smp.size), "median": float(np.median(smp)), "p95": float(smp[min(smp.size - 1, int(0.95 * smp.size))]),
+                        "min": float(smp[0]), "max": float(smp[-1]), "note": "HIP events around whole frames on rank 0, separate pass after the timed region"}
     ratio = hip.occupiedRatio()
     ab = algorithmic_bytes(cfg, cfg["streams"], 1 if frames_mode else world)
     out = {
@@ -211,6 +225,7 @@ def main():
                    "parallelism": "single GPU" if world == 1 else (f"{world} GPUs, each fusing its own frames (no exchange)" if frames_mode else
                                                                     f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0")},
         "stage_ms": stages,
+        "frame_device_ms": frame_ms,
         "stage_ms_note": "per-stage device time from a separate all-timers pass before the timed region (not part of `value`)",
         "upload_ms_per_frame": upload_ms,
         "pcie_inclusive_frames_per_s": 1e3 / (upload_ms + dt / args.steps * 1e3),

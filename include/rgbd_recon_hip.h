@@ -228,6 +228,11 @@ int32_t tsdf_enable_timers(tsdf_ctx* ctx, int32_t active);
 /* every recorded event costs a few microseconds of stream time: restrict recording to a comma-separated list of timer names
  * (e.g. "2integrate") while measuring throughput; NULL or "" = all */
 int32_t tsdf_set_timer_filter(tsdf_ctx* ctx, const char* names);
+/* caller-defined intervals on the context's stream (recorded only while timers are enabled and `name` passes the filter),
+ * and the individual samples of any timer since it was last read (resets it) */
+int32_t tsdf_timer_begin(tsdf_ctx* ctx, const char* name);
+int32_t tsdf_timer_end(tsdf_ctx* ctx, const char* name);
+int32_t tsdf_timer_samples(tsdf_ctx* ctx, const char* name, float* out_ms, uint32_t capacity, uint32_t* count);
 int32_t tsdf_timer_ms(tsdf_ctx* ctx, const char* name, float* last_ms);   /* synchronises on that timer */
 /* every invocation since the previous call: count and summed device time; resets the timer */
 int32_t tsdf_timer_stats(tsdf_ctx* ctx, const char* name, uint32_t* count, float* total_ms);

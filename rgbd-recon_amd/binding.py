@@ -408,6 +408,14 @@ class ReconIntegrationHip:
     def set_timer_filter(self, names=None):
         self._ck(self._L.tsdf_set_timer_filter(self._c, (",".join(names)).encode() if names else None))
 
+    def timer_begin(self, name): self._ck(self._L.tsdf_timer_begin(self._c, name.encode()))
+    def timer_end(self, name): self._ck(self._L.tsdf_timer_end(self._c, name.encode()))
+
+    def timer_samples(self, name, capacity=8192):
+        out, n = np.zeros(capacity, np.float32), C.c_uint32()
+        self._ck(self._L.tsdf_timer_samples(self._c, name.encode(), _fp(out), capacity, C.byref(n)))
+        return out[:n.value].copy()
+
     def timer_stats(self, name):
         n, ms = C.c_uint32(), C.c_float()
         self._ck(self._L.tsdf_timer_stats(self._c, name.encode(), C.byref(n), C.byref(ms)))

@@ -1139,6 +1139,26 @@ int32_t tsdf_timer_ms(tsdf_ctx* c, const char* name, float* ms) {
   HIP_TRY(c, hipEventElapsedTime(ms, e.first, e.second));
   return TSDF_OK;
 }
+// caller-defined intervals on the context's stream (bench.py brackets whole frames with them)
+int32_t tsdf_timer_begin(tsdf_ctx* c, const char* name) { CHECK_CTX(c); if (!name) return TSDF_ERR_INVALID_ARGUMENT; HIP_TRY(c, hipSetDevice(c->device)); timer_begin(c, name); return TSDF_OK; }
+int32_t tsdf_timer_end(tsdf_ctx* c, const char* name) { CHECK_CTX(c); if (!name) return TSDF_ERR_INVALID_ARGUMENT; timer_end(c, name); return TSDF_OK; }
+// the individual samples recorded since the last tsdf_timer_stats / tsdf_timer_samples of this timer (and resets it)
+int32_t tsdf_timer_samples(tsdf_ctx* c, const char* name, float* out_ms, uint32_t capacity, uint32_t* count) {
+  CHECK_CTX(c);
+  if (!name || !count || (!out_ms && capacity)) return TSDF_ERR_INVALID_ARGUMENT;
+  *count = 0;
+  auto it = c->timers.find(name);
+  if (it == c->timers.end()) return TSDF_OK;
+  Timer& t = it->second;
+  const size_t n = std::min<size_t>(t.used, capacity);
+  for (size_t i = 0; i < n; ++i) {
+    HIP_TRY(c, hipEventSynchronize(t.ev[i].second));
+    HIP_TRY(c, hipEventElapsedTime(&out_ms[i], t.ev[i].first, t.ev[i].second));
+  }
+  *count = (uint32_t)n;
+  t.used = 0;
+  return TSDF_OK;
+}
 int32_t tsdf_timer_stats(tsdf_ctx* c, const char* name, uint32_t* count, float* total_ms) {
   CHECK_CTX(c);
   if (!name || !count || !total_ms) return TSDF_ERR_INVALID_ARGUMENT;
