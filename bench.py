@@ -99,6 +99,9 @@ def main():
                     help="N > 1: 'slabs' = ONE volume split into Z-slabs with the RCCL exchange (the north-star partition, strong scaling); "
                          "'frames' = every GPU fuses its own frames of the stream (each frame rebuilds the volume from scratch, so frames are "
                          "independent: no exchange at all, weak scaling)")
+    ap.add_argument("--sparse-pool", type=int, default=0, metavar="TILES",
+                    help="store the TSDF in a sparse pool of this many 8^3-voxel tiles (2 KiB each) instead of a dense array "
+                         "(BASELINE.json configs[4] 'sparse-brick allocation'); needs a culled configuration")
     ap.add_argument("--preprocess", action="store_true", help="also run the image pre-processing passes (f1) every frame, from the raw depth/colour")
     ap.add_argument("--ingest", default=None, choices=["f32-rgb8", "f32-dxt1", "u8-rgb8", "u8-dxt1", "u8-dxt5"],
                     help="also measure the wire path (f2): every frame arrives as one host message, is copied through the pinned double "
@@ -135,7 +138,7 @@ def main():
     frames_mode = world > 1 and args.parallel == "frames"
     slab = mg.slab_range(cfg["res"][2], rank, world) if (world > 1 and not frames_mode) else (0, 0)
     hip = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, slab=slab,
-                                 recompute_halo=(args.halo == "recompute"))
+                                 recompute_halo=(args.halo == "recompute"), sparse_pool_tiles=args.sparse_pool)
     hip.setUseBricks(cfg["use_bricks"]); hip.setSpaceSkip(cfg["skip_space"]); hip.setColorFilling(cfg["fill_holes"])
     stream = torch.cuda.current_stream()
     hip.set_stream(stream.cuda_stream)         # kernels, HIP event timers and the collectives share one stream
@@ -222,6 +225,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "config": args.config, "streams": cfg["streams"], "res": list(cfg["res"]),
                    "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
+                   "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
                    "parallelism": "single GPU" if world == 1 else (f"{world} GPUs, each fusing its own frames (no exchange)" if frames_mode else
                                                                     f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0")},
         "stage_ms": stages,

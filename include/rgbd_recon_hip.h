@@ -60,12 +60,20 @@ typedef struct tsdf_config {
   /* 1: this context also integrates the halo tile layers next to its slab itself (voxels are independent in K1), so no
    * halo exchange is needed before the raymarch; 0: the halo is filled by tsdf_halo_unpack_dev from the neighbours. */
   uint32_t slab_recompute_halo;
+  /* > 0: sparse tile pool (BASELINE.json configs[4] "sparse-brick allocation"): the TSDF is stored as a pool of this many
+   * 8^3-voxel tiles (2 KiB each) plus a tile -> slot table instead of a dense res_x*res_y*res_z array; only tiles that an
+   * occupied brick reaches hold storage, every other voxel reads as -limit.  Volumes far beyond dense memory become
+   * possible (4096^3 = 256 GiB dense).  Needs brick culling (setUseBricks(true)); with a slab, slab_recompute_halo = 1.
+   * A frame that needs more tiles than the pool holds drops the excess (they read -limit): tsdf_sparse_pool_stats. 0: dense. */
+  uint32_t sparse_pool_tiles;
 } tsdf_config;
 
 /* ---- lifetime / errors ------------------------------------------------------------------------- */
 int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out);
 int32_t tsdf_destroy(tsdf_ctx* ctx);
 const char* tsdf_last_error(const tsdf_ctx* ctx);   /* ctx may be NULL: error of the last failed tsdf_create */
+/* sparse contexts: tiles the last integrate() needed / pool capacity (synchronises the stream) */
+int32_t tsdf_sparse_pool_stats(tsdf_ctx* ctx, uint32_t* tiles_needed, uint32_t* pool_tiles);
 int32_t tsdf_set_stream(tsdf_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL: back to own) */
 int32_t tsdf_sync(tsdf_ctx* ctx);
 

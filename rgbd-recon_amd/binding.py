@@ -33,7 +33,8 @@ class TsdfConfig(C.Structure):
                 ("voxel_size", C.c_float), ("res", C.c_uint32 * 3), ("brick_size", C.c_float * 3),
                 ("limit", C.c_float), ("num_streams", C.c_uint32), ("depth_w", C.c_uint32), ("depth_h", C.c_uint32),
                 ("color_w", C.c_uint32), ("color_h", C.c_uint32), ("view_w", C.c_uint32), ("view_h", C.c_uint32),
-                ("device", C.c_int32), ("slab_z0", C.c_uint32), ("slab_z1", C.c_uint32), ("slab_recompute_halo", C.c_uint32)]
+                ("device", C.c_int32), ("slab_z0", C.c_uint32), ("slab_z1", C.c_uint32), ("slab_recompute_halo", C.c_uint32),
+                ("sparse_pool_tiles", C.c_uint32)]
 
 
 def build_library():
@@ -166,7 +167,7 @@ class ReconIntegrationHip:
     NetKinectArray hold in the reference (rgbd-recon_amd/scene.py layout)."""
 
     def __init__(self, scene, res=None, voxel_size=0.01, brick_size=0.1, limit=0.01, view=(1280, 720),
-                 device=0, slab=(0, 0), upload=True, recompute_halo=False):
+                 device=0, slab=(0, 0), upload=True, recompute_halo=False, sparse_pool_tiles=0):
         self._L = load_library()
         self._c = None
         cfg = TsdfConfig()
@@ -184,6 +185,7 @@ class ReconIntegrationHip:
         cfg.device = device
         cfg.slab_z0, cfg.slab_z1 = slab
         cfg.slab_recompute_halo = int(bool(recompute_halo))
+        cfg.sparse_pool_tiles = int(sparse_pool_tiles)
         ctx = C.c_void_p()
         rc = self._L.tsdf_create(C.byref(cfg), C.byref(ctx))
         if rc != 0:
@@ -407,6 +409,11 @@ class ReconIntegrationHip:
 
     def set_timer_filter(self, names=None):
         self._ck(self._L.tsdf_set_timer_filter(self._c, (",".join(names)).encode() if names else None))
+
+    def sparse_pool_stats(self):
+        need, cap = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.tsdf_sparse_pool_stats(self._c, C.byref(need), C.byref(cap)))
+        return need.value, cap.value
 
     def timer_begin(self, name): self._ck(self._L.tsdf_timer_begin(self._c, name.encode()))
     def timer_end(self, name): self._ck(self._L.tsdf_timer_end(self._c, name.encode()))

@@ -5,6 +5,7 @@
 // source/kinect_client.cpp:569-599,614.  All device work goes to one HIP stream.
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -351,6 +352,9 @@ const char* tsdf_last_error(const tsdf_ctx* ctx) { return ctx ? ctx->err.c_str()
 int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if (!cfg || !out) { g_create_error = "null argument"; return TSDF_ERR_INVALID_ARGUMENT; }
   *out = nullptr;
+  // struct_size lets the struct grow: a caller built against the layout that ended at slab_recompute_halo is still accepted
+  tsdf_config grown{};
+  if (cfg->struct_size == offsetof(tsdf_config, sparse_pool_tiles)) { memcpy(&grown, cfg, cfg->struct_size); grown.struct_size = sizeof(tsdf_config); cfg = &grown; }
   if (cfg->struct_size != sizeof(tsdf_config)) { g_create_error = "tsdf_config.struct_size mismatch"; return TSDF_ERR_INVALID_ARGUMENT; }
   if (cfg->num_streams < 1 || cfg->num_streams > TSDF_MAX_STREAMS) { g_create_error = "num_streams out of range"; return TSDF_ERR_INVALID_ARGUMENT; }
   if (!(cfg->limit > 0.0f)) { g_create_error = "limit must be > 0"; return TSDF_ERR_INVALID_ARGUMENT; }
@@ -401,8 +405,13 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   V.int_tz0 = recompute ? V.tz0 : V.own_tz0;
   V.int_tz1 = recompute ? V.tz1 : V.own_tz1;
   if (!whole && V.own_tz1 - V.own_tz0 < c->halo_layers) { c->err = "slab thinner than its halo"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
-  const size_t nvox = (size_t)(V.tz1 - V.tz0) * V.nty * V.ntx * TILE_VOX;
-  if (nvox >= (1ull << 32)) { c->err = "a context stores at most 2^32 voxels (32-bit tap offsets); split the volume into Z-slabs"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+  const bool sparse = cfg->sparse_pool_tiles > 0;
+  V.n_stored_tiles = (V.tz1 - V.tz0) * V.nty * V.ntx;
+  if ((uint64_t)(V.tz1 - V.tz0) * V.nty * V.ntx >= (1ull << 31)) { c->err = "more than 2^31 storage tiles"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+  if (sparse && !whole && !recompute) { c->err = "a sparse slab context needs slab_recompute_halo (exchanged halo layers have no pool slots)"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+  if (sparse && cfg->sparse_pool_tiles >= (1u << 23)) { c->err = "sparse_pool_tiles must be below 2^23 (16 GiB of tiles)"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+  const size_t nvox = sparse ? (size_t)cfg->sparse_pool_tiles * TILE_VOX : (size_t)(V.tz1 - V.tz0) * V.nty * V.ntx * TILE_VOX;
+  if (nvox >= (1ull << 32)) { c->err = "a context stores at most 2^32 voxels (32-bit tap offsets); split the volume into Z-slabs or use a sparse pool"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
   int32_t rc;
   auto tryhip = [&](hipError_t e, const char* what) -> int32_t {
     if (e == hipSuccess) return TSDF_OK;
@@ -411,10 +420,15 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   };
   if ((rc = tryhip(hipMalloc(&V.data, nvox * sizeof(float)), "hipMalloc(volume)"))) return fail(rc);
   launch_fill_u32(c->stream, (uint32_t*)V.data, 0u, nvox);
+  V.slot = nullptr; V.pool_tiles = 0;
+  if (sparse) {
+    if ((rc = tryhip(hipMalloc(&V.slot, (size_t)V.n_stored_tiles * sizeof(uint32_t)), "hipMalloc(slot table)"))) return fail(rc);
+    if ((rc = tryhip(hipMemsetAsync(V.slot, 0xff, (size_t)V.n_stored_tiles * sizeof(uint32_t), c->stream), "hipMemset(slot table)"))) return fail(rc);
+    V.pool_tiles = cfg->sparse_pool_tiles;
+  }
   TileState& S = c->tiles;
   S.n = (V.int_tz1 - V.int_tz0) * V.nty * V.ntx;
   if ((rc = tryhip(hipMalloc(&S.active, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
-  V.n_stored_tiles = (V.tz1 - V.tz0) * V.nty * V.ntx;
   if ((rc = tryhip(hipMalloc(&c->d_cls_all, (size_t)V.n_stored_tiles), "hipMalloc(tiles)"))) return fail(rc);
   hipMemsetAsync(c->d_cls_all, kTileMixed, (size_t)V.n_stored_tiles, c->stream);   // halo layers keep this value for good
   V.cls = c->d_cls_all;
@@ -427,9 +441,12 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
       words += (cells + 31) / 32;
     }
     V.pyr_off[0] = words;
-    if (words * 4 > 60 * 1024) { c->err = "volume too large for the raymarch's LDS empty-space pyramid"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
-    if ((rc = tryhip(hipMalloc(&c->d_pyr, (size_t)words * sizeof(uint32_t)), "hipMalloc(pyramid)"))) return fail(rc);
-    V.pyr = c->d_pyr;
+    V.pyr = nullptr;
+    if (kUseSkip) {                               // the experiment switch of tsdf_common.hpp; off in the shipped build
+      if (words * 4 > 60 * 1024) { c->err = "volume too large for the raymarch's LDS empty-space pyramid"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
+      if ((rc = tryhip(hipMalloc(&c->d_pyr, (size_t)words * sizeof(uint32_t)), "hipMalloc(pyramid)"))) return fail(rc);
+      V.pyr = c->d_pyr;
+    }
   }
   S.cls = c->d_cls_all + (size_t)(V.int_tz0 - V.tz0) * V.nty * V.ntx;
   if ((rc = tryhip(hipMalloc(&S.list, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
@@ -464,7 +481,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   release_view(c); release_bricks(c);
   hipFree(c->tiles.active); hipFree(c->d_cls_all); hipFree(c->d_pyr); hipFree(c->tiles.list);
-  hipFree(c->vol.data); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
+  hipFree(c->vol.data); hipFree(c->vol.slot); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
   hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal);
   hipFree(c->d_depth_plane); hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
   for (void* p : c->lut_allocs) hipFree(p);
@@ -477,6 +494,17 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   return TSDF_OK;
 }
 
+int32_t tsdf_sparse_pool_stats(tsdf_ctx* c, uint32_t* need, uint32_t* cap) {
+  CHECK_CTX(c);
+  if (!c->vol.slot) FAIL(c, TSDF_ERR_STATE, "not a sparse context");
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t n = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n, c->tiles.count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (need) *need = n;
+  if (cap) *cap = c->vol.pool_tiles;
+  return TSDF_OK;
+}
 int32_t tsdf_set_stream(tsdf_ctx* c, void* s) {
   CHECK_CTX(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -780,6 +808,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   CHECK_CTX(c);
   int32_t rc = require_inputs(c, false, false);
   if (rc) return rc;
+  if (c->vol.slot && !c->use_bricks) FAIL(c, TSDF_ERR_STATE, "a sparse tile pool needs brick culling (setUseBricks(true)): without it every tile is active");
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "2integrate");
   bool lds = true;
@@ -984,6 +1013,7 @@ int32_t tsdf_download_volume(tsdf_ctx* c, float* out) {
 int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
   CHECK_CTX(c);
   if (!in) return TSDF_ERR_INVALID_ARGUMENT;
+  if (c->vol.slot) FAIL(c, TSDF_ERR_STATE, "tsdf_upload_volume is not available with a sparse tile pool (tiles get storage from integrate())");
   HIP_TRY(c, hipSetDevice(c->device));
   int32_t rc = need_linear(c);
   if (rc) return rc;
@@ -1064,6 +1094,7 @@ int32_t tsdf_halo_info(const tsdf_ctx* c, uint32_t* layers, uint64_t* bytes) {
 }
 int32_t tsdf_halo_pack_dev(tsdf_ctx* c, void* lo, void* hi) {
   CHECK_CTX(c);
+  if (c->vol.slot) FAIL(c, TSDF_ERR_STATE, "halo exchange is not available with a sparse tile pool (use slab_recompute_halo)");
   HIP_TRY(c, hipSetDevice(c->device));
   const Volume& V = c->vol;
   const size_t layer = (size_t)V.nty * V.ntx * TILE_VOX, n = (size_t)c->halo_layers * layer * sizeof(float);
@@ -1073,6 +1104,7 @@ int32_t tsdf_halo_pack_dev(tsdf_ctx* c, void* lo, void* hi) {
 }
 int32_t tsdf_halo_unpack_dev(tsdf_ctx* c, const void* below, const void* above) {
   CHECK_CTX(c);
+  if (c->vol.slot) FAIL(c, TSDF_ERR_STATE, "halo exchange is not available with a sparse tile pool (use slab_recompute_halo)");
   HIP_TRY(c, hipSetDevice(c->device));
   const Volume& V = c->vol;
   const size_t layer = (size_t)V.nty * V.ntx * TILE_VOX;

@@ -54,6 +54,8 @@ __device__ __forceinline__ bool voxel_drawn(const Bricks& B, int x, int y, int z
   return any;
 }
 
+// index of integrated tile `tile` (int_tz0-relative) in the per-stored-tile tables (tz0-relative)
+__device__ __forceinline__ uint32_t stored_tile_index(const Volume& V, int tile) { return (uint32_t)tile + (uint32_t)((V.int_tz0 - V.tz0) * V.nty * V.ntx); }
 __device__ __forceinline__ void tile_coords(const Volume& V, int tile, int& tx, int& ty, int& tz) {
   tx = tile % V.ntx; ty = (tile / V.ntx) % V.nty; tz = V.int_tz0 + tile / (V.ntx * V.nty);
 }
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(256) void k_classify_clear_tiles(Volume V, Bricks B
         for (int i = b0[0]; i <= b1[0]; ++i)
           active |= B.flags[((size_t)k * B.res[1] + j) * B.res[0] + i] != 0;
     S.active[tile] = active ? 1 : 0;
-    need_clear = !active && S.cls[tile] != kTileMinus;
-    if (need_clear) S.cls[tile] = kTileMinus;
+    need_clear = !active && S.cls[tile] != kTileMinus && !V.slot;     // sparse pool: a tile without a slot IS the clear value
+    if (need_clear || (V.slot && !active)) S.cls[tile] = kTileMinus;
   }
   const unsigned long long am = __ballot(active);
   if (am) {
@@ -85,8 +87,11 @@ __global__ __launch_bounds__(256) void k_classify_clear_tiles(Volume V, Bricks B
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(S.count, (uint32_t)__popcll(am));
     base = __shfl(base, leader);
-    if (active) S.list[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = (uint32_t)tile;
+    const uint32_t pos = base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+    if (active) S.list[pos] = (uint32_t)tile;
+    if (active && V.slot) V.slot[stored_tile_index(V, tile)] = pos < V.pool_tiles ? pos : kNoSlot;   // slot = position in this frame's list
   }
+  if (V.slot && tile < S.n && !active) V.slot[stored_tile_index(V, tile)] = kNoSlot;
   unsigned long long m = __ballot(need_clear);
   const float4 cv = make_float4(-V.limit, -V.limit, -V.limit, -V.limit);
   const int wave_base = tile - lane;
@@ -133,7 +138,8 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
     const int tile = work_tile<kList>(S, w);
     int tx, ty, tz;
     tile_coords(V, tile, tx, ty, tz);
-    float* __restrict__ out = V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9);
+    if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
+    float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9);
     __syncthreads();
     if (threadIdx.x == 0) s_flag = 3;
     __syncthreads();
@@ -209,7 +215,8 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
     const int tile = work_tile<kList>(S, w);
     int t3[3];
     tile_coords(V, tile, t3[0], t3[1], t3[2]);
-    float* __restrict__ out = V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
+    if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
+    float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
     // both voxels of this thread: l and l + 256 share x and y, z differs by 4
     const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256) void k_volume_to_linear(Volume V, float* __res
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int x = (int)(i % V.res[0]), y = (int)((i / V.res[0]) % V.res[1]), z = (int)(i / ((size_t)V.res[0] * V.res[1]));
     const int tz = z >> 3;
-    lin[i] = (tz >= V.tz0 && tz < V.tz1) ? V.data[vol_index(V, x, y, z)] : 0.0f;
+    lin[i] = (tz >= V.tz0 && tz < V.tz1) ? (V.slot ? tsdf_tap_sparse(V, x, y, z) : V.data[vol_index(V, x, y, z)]) : 0.0f;
   }
 }
 __global__ __launch_bounds__(256) void k_volume_from_linear(Volume V, const float* __restrict__ lin) {

@@ -305,7 +305,7 @@ __device__ __forceinline__ uint32_t empty_run(const Volume& V, const uint32_t* p
 #endif
 constexpr int kBatch = RR_MARCH_BATCH;   // samples in flight per ray
 
-template <bool kPartial>
+template <bool kPartial, bool kSparse>
 __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count,
                                                                  LongRay* __restrict__ longs, uint32_t* __restrict__ long_count, uint32_t cap) {
   constexpr bool partial = kPartial;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       own[k] = (n + k < max_n) && (!partial || sample_owned(V, p[k].z));
-      d[k] = tex3d_tsdf(V, p[k].x, p[k].y, p[k].z);   // unconditional: taps are clamped into the allocation, and a predicated
+      d[k] = tex3d_tsdf<kSparse>(V, p[k].x, p[k].y, p[k].z);   // unconditional: taps are clamped into the allocation, and a predicated
                                                       // fetch would make the compiler wait for each sample's loads separately
     }
     bool all_minus = true;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
     }
   }
   if (hit) {                                                            // approximate ray-cell intersection, :99-101
-    if (partial && !prev_valid) prev = tex3d_tsdf(V, pos_prev.x, pos_prev.y, pos_prev.z);   // sample n-1 is a neighbour's: read it from the halo
+    if (partial && !prev_valid) prev = tex3d_tsdf<kSparse>(V, pos_prev.x, pos_prev.y, pos_prev.z);   // sample n-1 is a neighbour's: read it from the halo
     const float kk = prev / (hit_d - prev);
     pos = make_float3((hit_pos.x - step.x) - step.x * kk, (hit_pos.y - step.y) - step.y * kk, (hit_pos.z - step.z) - step.z * kk);
   }
@@ -501,7 +501,9 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
 // those of the one-at-a-time loop (:89-110).  A single lane walking a 92-sample ray issues ~14 k dependent instructions;
 // here the same ray is two rounds of ~1.4 k.
 struct StreamTable; struct FrameImages;
+template <bool kSparse>
 __device__ __forceinline__ void shade_hit(const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, const Hit& h);
+template <bool kSparse>
 __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V, const RayTarget& R, const LongRay* __restrict__ longs,
                                            const uint32_t* __restrict__ long_count, uint32_t n_blocks, const StreamTable* T, const FrameImages* F) {
   const int ln = threadIdx.x & 63, g = ln >> 3, j = ln & 7;
@@ -532,7 +534,7 @@ __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V,
 #pragma unroll
       for (int k = 1; k < kBatch; ++k) p[k] = make_float3(p[k - 1].x + step.x, p[k - 1].y + step.y, p[k - 1].z + step.z);
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) d[k] = tex3d_tsdf(V, p[k].x, p[k].y, p[k].z);     // unconditional: taps are clamped into the allocation
+      for (int k = 0; k < kBatch; ++k) d[k] = tex3d_tsdf<kSparse>(V, p[k].x, p[k].y, p[k].z);     // unconditional: taps are clamped into the allocation
       // examine this lane's eight samples in order
       bool lhit = false, lprev_set = false;
       float lprev = 0.0f, lhd = 0.0f;
@@ -578,7 +580,7 @@ __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V,
         Hit h;
         h.x = (hit_pos.x - step.x) - step.x * kk; h.y = (hit_pos.y - step.y) - step.y * kk; h.z = (hit_pos.z - step.z) - step.z * kk;
         h.pix = L.pix;
-        shade_hit(P, *T, *F, V, R, h);                                  // no list: the hit is shaded where it was found
+        shade_hit<kSparse>(P, *T, *F, V, R, h);                         // no list: the hit is shaded where it was found
       } else {
         const size_t oi = (size_t)py * R.stride + px;
         R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
@@ -590,13 +592,14 @@ __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V,
 }
 
 // submitFragment(), :116-134, one thread per hit.  Thread 0 also re-arms the OTHER hit counter for the next frame.
+template <bool kSparse>
 __device__ __forceinline__ void shade_hit(const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, const Hit& h) {
   const float limit = V.limit, sd = limit * 0.5f;
   const float3 pos = make_float3(h.x, h.y, h.z);
   const int px = (int)(h.pix % (uint32_t)P.w), py = (int)(h.pix / (uint32_t)P.w);
-  const float gx = tex3d_tsdf(V, pos.x + sd, pos.y, pos.z) - tex3d_tsdf(V, pos.x - sd, pos.y, pos.z);
-  const float gy = tex3d_tsdf(V, pos.x, pos.y + sd, pos.z) - tex3d_tsdf(V, pos.x, pos.y - sd, pos.z);
-  const float gz = tex3d_tsdf(V, pos.x, pos.y, pos.z + sd) - tex3d_tsdf(V, pos.x, pos.y, pos.z - sd);
+  const float gx = tex3d_tsdf<kSparse>(V, pos.x + sd, pos.y, pos.z) - tex3d_tsdf<kSparse>(V, pos.x - sd, pos.y, pos.z);
+  const float gy = tex3d_tsdf<kSparse>(V, pos.x, pos.y + sd, pos.z) - tex3d_tsdf<kSparse>(V, pos.x, pos.y - sd, pos.z);
+  const float gz = tex3d_tsdf<kSparse>(V, pos.x, pos.y, pos.z + sd) - tex3d_tsdf<kSparse>(V, pos.x, pos.y, pos.z - sd);
   const float3 gn = normalize3(make_float3(gx, gy, gz));              // get_gradient(), :140-149
   const float4 vn4 = mat_mul(P.normal, -gn.x, -gn.y, -gn.z, 0.0f);
   const float3 vn = normalize3(make_float3(vn4.x, vn4.y, vn4.z));
@@ -620,26 +623,29 @@ __device__ __forceinline__ void shade_hit(const ViewParams& P, const StreamTable
 }
 
 // the hit list of the first march pass, one thread per hit, blocks [first_block, gridDim.x)
+template <bool kSparse>
 __device__ __forceinline__ void shade_list(const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R,
                                            const Hit* __restrict__ hits, const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count, uint32_t first_block) {
   const uint32_t b = blockIdx.x - first_block, nb = gridDim.x - first_block;
   if (b == 0 && threadIdx.x == 0) { next_count[0] = 0u; next_count[2] = 0u; }   // hit + long-ray counters of the next frame
   const uint32_t n_hits = *hit_count;
-  for (uint32_t i = b * blockDim.x + threadIdx.x; i < n_hits; i += nb * blockDim.x) shade_hit(P, T, F, V, R, hits[i]);
+  for (uint32_t i = b * blockDim.x + threadIdx.x; i < n_hits; i += nb * blockDim.x) shade_hit<kSparse>(P, T, F, V, R, hits[i]);
 }
+template <bool kSparse>
 __global__ __launch_bounds__(256) void k_shade(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
                                                const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count) {
-  shade_list(P, T, F, V, R, hits, hit_count, next_count, 0u);
+  shade_list<kSparse>(P, T, F, V, R, hits, hit_count, next_count, 0u);
 }
 // ONE launch for the two independent jobs that follow the first march pass: blocks [0, kLongBlocks) finish the long rays
 // (and shade their own hits on the spot), the rest shade the first pass's hit list.  Saves a dependent launch (~5 us of
 // ramp) and overlaps two latency-bound kernels: 15 + 19 us -> ~21 us.
 constexpr uint32_t kLongBlocks = 512;
+template <bool kSparse>
 __global__ __launch_bounds__(256) void k_shade_and_long(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
                                                         const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count,
                                                         const LongRay* __restrict__ longs, const uint32_t* __restrict__ long_count) {
-  if (blockIdx.x < kLongBlocks) march_long(P, V, R, longs, long_count, kLongBlocks, &T, &F);
-  else shade_list(P, T, F, V, R, hits, hit_count, next_count, kLongBlocks);
+  if (blockIdx.x < kLongBlocks) march_long<kSparse>(P, V, R, longs, long_count, kLongBlocks, &T, &F);
+  else shade_list<kSparse>(P, T, F, V, R, hits, hit_count, next_count, kLongBlocks);
 }
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
                      void* hit_list, uint32_t* hit_counters, int parity, int phase, void* long_list, uint32_t cap) {
@@ -652,18 +658,25 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
   const size_t lds = kUseSkip ? (size_t)V.pyr_off[0] * sizeof(uint32_t) : 0;
   // counters: [hit parity 0, hit parity 1, long parity 0, long parity 1]
   const bool two_pass = !partial && !kUseSkip && P.skip && long_list && cap != 0xffffffffu;
+  const bool sparse = V.slot != nullptr;
   if (phase != 3) {
-    if (partial) hipLaunchKernelGGL(k_march<true>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity, (LongRay*)nullptr, hit_counters + 2 + parity, 0xffffffffu);
-    else hipLaunchKernelGGL(k_march<false>, grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity, (LongRay*)long_list, hit_counters + 2 + parity,
-                            two_pass ? cap : 0xffffffffu);
+    const uint32_t cap1 = two_pass ? cap : 0xffffffffu;
+    LongRay* const ll = partial ? nullptr : (LongRay*)long_list;
+#define RR_LAUNCH_MARCH(PART, SP) hipLaunchKernelGGL((k_march<PART, SP>), grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity, ll, hit_counters + 2 + parity, cap1)
+    if (partial) { if (sparse) RR_LAUNCH_MARCH(true, true); else RR_LAUNCH_MARCH(true, false); }
+    else { if (sparse) RR_LAUNCH_MARCH(false, true); else RR_LAUNCH_MARCH(false, false); }
+#undef RR_LAUNCH_MARCH
   }
   if (phase == 2) return;
   if (two_pass) {
-    hipLaunchKernelGGL(k_shade_and_long, dim3(kLongBlocks + 1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1),
-                       (const LongRay*)long_list, hit_counters + 2 + parity);
+    if (sparse) hipLaunchKernelGGL(k_shade_and_long<true>, dim3(kLongBlocks + 1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1),
+                                   (const LongRay*)long_list, hit_counters + 2 + parity);
+    else hipLaunchKernelGGL(k_shade_and_long<false>, dim3(kLongBlocks + 1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1),
+                            (const LongRay*)long_list, hit_counters + 2 + parity);
     return;
   }
-  hipLaunchKernelGGL(k_shade, dim3(1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1));
+  if (sparse) hipLaunchKernelGGL(k_shade<true>, dim3(1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1));
+  else hipLaunchKernelGGL(k_shade<false>, dim3(1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1));
 }
 
 // ------------------------------------------------------------------------------------------- multi-GPU image exchange

@@ -113,7 +113,24 @@ __device__ __forceinline__ TsdfTaps tsdf_taps(const Volume& V, float u, float v,
   t.Z.i1 = clampi(t.Z.i1, V.zlo, V.zhi);
   return t;
 }
+// sparse pool: the tap's tile goes through the slot table (one dependent load more per tap; unallocated tiles read -limit)
+__device__ __forceinline__ float tsdf_tap_sparse(const Volume& V, int x, int y, int z) {
+  const uint32_t tile = (uint32_t)__mul24((z >> 3) - V.tz0, V.nty * V.ntx) + (uint32_t)__mul24(y >> 3, V.ntx) + (uint32_t)(x >> 3);
+  const uint32_t s = V.slot[tile];
+  if (s == kNoSlot) return -V.limit;
+  return V.data[((size_t)s << 9) + (uint32_t)(((z & 7) << 6) | ((y & 7) << 3) | (x & 7))];
+}
+// kSparse is a compile-time property of the kernel instantiation: the dense path must not carry the sparse one's code and
+// registers (a run-time branch here cost the dense march 15 %)
+template <bool kSparse>
 __device__ __forceinline__ float tsdf_fetch(const Volume& V, const TsdfTaps& t) {
+  if (kSparse) {
+    const float c00 = lerpf(tsdf_tap_sparse(V, t.X.i0, t.Y.i0, t.Z.i0), tsdf_tap_sparse(V, t.X.i1, t.Y.i0, t.Z.i0), t.X.a);
+    const float c10 = lerpf(tsdf_tap_sparse(V, t.X.i0, t.Y.i1, t.Z.i0), tsdf_tap_sparse(V, t.X.i1, t.Y.i1, t.Z.i0), t.X.a);
+    const float c01 = lerpf(tsdf_tap_sparse(V, t.X.i0, t.Y.i0, t.Z.i1), tsdf_tap_sparse(V, t.X.i1, t.Y.i0, t.Z.i1), t.X.a);
+    const float c11 = lerpf(tsdf_tap_sparse(V, t.X.i0, t.Y.i1, t.Z.i1), tsdf_tap_sparse(V, t.X.i1, t.Y.i1, t.Z.i1), t.X.a);
+    return lerpf(lerpf(c00, c10, t.Y.a), lerpf(c01, c11, t.Y.a), t.Z.a);
+  }
   const float* __restrict__ d = V.data;
   const uint32_t x0 = vol_off_x(t.X.i0), x1 = vol_off_x(t.X.i1);
   const uint32_t y0 = vol_off_y(V, t.Y.i0), y1 = vol_off_y(V, t.Y.i1);
@@ -125,7 +142,8 @@ __device__ __forceinline__ float tsdf_fetch(const Volume& V, const TsdfTaps& t) 
   const float c11 = lerpf(d[b11 + x0], d[b11 + x1], t.X.a);
   return lerpf(lerpf(c00, c10, t.Y.a), lerpf(c01, c11, t.Y.a), t.Z.a);
 }
-__device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) { return tsdf_fetch(V, tsdf_taps(V, u, v, w)); }
+template <bool kSparse>
+__device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) { return tsdf_fetch<kSparse>(V, tsdf_taps(V, u, v, w)); }
 
 __device__ __forceinline__ float4 mat_mul(const Mat4& a, float x, float y, float z, float w) {
   return make_float4(a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w,

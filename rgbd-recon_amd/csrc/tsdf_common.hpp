@@ -40,6 +40,11 @@ struct Volume {
   int own_tz0, own_tz1;  // owned tile layers: the samples of the raymarch this context is responsible for
   int int_tz0, int_tz1;  // tile layers integrate() computes: the owned ones, plus the halo when it is recomputed locally
   int zlo, zhi;        // stored voxel planes [zlo, zhi]: every Z tap is clamped into them (slab contexts)
+  // Sparse tile pool (tsdf_config::sparse_pool_tiles): `data` is a pool of pool_tiles tiles and slot[stored tile index] is the
+  // tile's position in it, or kNoSlot (every voxel of the tile reads -limit).  The TSDF is rebuilt from scratch every frame,
+  // so a tile's slot is simply its position in this frame's compacted active list: no free list, no fragmentation.
+  uint32_t* slot;      // nullptr: dense storage
+  uint32_t pool_tiles;
   const uint8_t* cls;  // tile class of every STORED tile, index ((tz - tz0) * nty + ty) * ntx + tx; halo layers stay kTileMixed
   int n_stored_tiles;
   // Empty-space pyramid over the WHOLE volume, rebuilt before every raymarch: level l (1..4) has one bit per cell of
@@ -58,6 +63,7 @@ struct Volume {
 // follows the occupied bricks instead of the whole volume (the reference clears everything, :249-250).  The raymarch
 // uses cls to skip the fetch of samples whose whole footprint lies in uniform tiles (the value is known exactly).
 constexpr uint8_t kTileMinus = 0, kTilePlus = 1, kTileMixed = 2;
+constexpr uint32_t kNoSlot = 0xffffffffu;
 // Empty-space run skipping in the raymarch (bit pyramid of all-(-limit) cells, k_raymarch.hip) and the per-tile class
 // vote in integrate that feeds it.  Measured on MI355X it LOSES (c2 march 68 -> 98 us, c1 280 -> 340 us, plus a 17 us
 // pyramid build): a skip decision costs about as many VALU instructions as the few samples it saves at 2.56 voxels per
