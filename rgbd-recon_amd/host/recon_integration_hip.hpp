@@ -44,6 +44,7 @@ struct ReconInputs {
   std::array<unsigned, 3> explicit_res{{0, 0, 0}};    // 0: res = ceil(bbox / voxel_size) like setVoxelSize()
   unsigned slab_z0 = 0, slab_z1 = 0;                  // multi-GPU Z-slab (0,0 = whole volume)
   bool slab_recompute_halo = false;                   // integrate the halo layers locally instead of exchanging them
+  unsigned sparse_pool_tiles = 0;                     // > 0: TSDF in a sparse pool of this many 8^3-voxel tiles (needs brick culling)
 };
 
 class ReconIntegrationHip {
@@ -64,6 +65,7 @@ class ReconIntegrationHip {
     cfg.device = in.device;
     cfg.slab_z0 = in.slab_z0; cfg.slab_z1 = in.slab_z1;
     cfg.slab_recompute_halo = in.slab_recompute_halo ? 1u : 0u;
+    cfg.sparse_pool_tiles = in.sparse_pool_tiles;
     if (tsdf_create(&cfg, &m_ctx) != TSDF_OK) throw std::runtime_error(std::string("ReconIntegrationHip: ") + tsdf_last_error(nullptr));
     const float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::memcpy(m_mv, id, sizeof(id));
