@@ -146,6 +146,37 @@ class ReconIntegrationHip {
   bool m_draw_bricks = false;
 };
 
+// The input side: kinect::NetKinectArray's public surface (framework/NetKinectArray.h:40-55) over the SAME context, for callers
+// that also replace the GL upload / pre-process.  The ZMQ socket stays with the caller: where readLoop() memcpy's the received
+// message into the PBOs (NetKinectArray.cpp:513-523), hand it to submit().
+class NetKinectArrayHip {
+ public:
+  // colour_format: CalibrationFiles::isCompressedRGB() (0 RGB8 / 1 DXT1 / 5 DXT5); compressed_depth: isCompressedDepth()
+  NetKinectArrayHip(ReconIntegrationHip& recon, unsigned colour_format, bool compressed_depth) : m_ctx(recon.handle()) {
+    check(tsdf_set_wire_format(m_ctx, colour_format, compressed_depth ? TSDF_DEPTH_U8 : TSDF_DEPTH_F32));
+  }
+  // per sensor: KinectCalibrationFile::isCompressedDepth()/getNear()/getFar(), CalibVolumes::getDepthLimits(i)
+  void setSensor(unsigned i, bool compressed_depth, float near_m, float far_m, float cv_min_d, float cv_max_d) {
+    check(tsdf_set_depth_compression(m_ctx, i, compressed_depth, near_m, far_m));
+    check(tsdf_set_depth_limits(m_ctx, i, cv_min_d, cv_max_d));
+  }
+  std::size_t messageBytes() const { uint64_t n = 0; tsdf_wire_sizes(m_ctx, nullptr, nullptr, &n); return (std::size_t)n; }
+  void submit(const void* zmq_message, std::size_t bytes) { check(tsdf_upload_wire_frame(m_ctx, zmq_message, bytes, &m_frametime)); m_dirty = true; }   // readLoop(), :482-529
+  bool update() { const bool fresh = m_dirty; m_dirty = false; return fresh; }      // NetKinectArray.cpp:225-236: "a new frame was uploaded"
+  void processTextures() { check(tsdf_process_textures(m_ctx)); }                    // :309-426 (marks the bricks itself)
+  void filterTextures(bool f) { m_filter = f; apply(); }                             // :463-476: each setter re-runs the passes
+  void useProcessedDepths(bool f) { m_processed = f; apply(); }
+  void refineBoundary(bool f) { m_refine = f; apply(); }
+  double frameTime() const { return m_frametime; }
+
+ private:
+  void apply() { check(tsdf_set_preprocess(m_ctx, m_filter, m_processed, m_refine)); }
+  void check(int32_t rc) const { if (rc != TSDF_OK) throw std::runtime_error(std::string("NetKinectArrayHip: ") + tsdf_last_error(m_ctx)); }
+  tsdf_ctx* m_ctx;
+  bool m_dirty = false, m_filter = true, m_processed = true, m_refine = true;
+  double m_frametime = 0.0;
+};
+
 }  // namespace kinect
 
 #endif  // RECON_INTEGRATION_HIP_HPP

@@ -30,6 +30,14 @@ def test_adapter_has_the_reference_method_names():
         assert re.search(r"\b%s\s*\(" % name, text), name
 
 
+def test_input_side_adapter_has_netkinectarray_method_names():
+    # framework/NetKinectArray.h:40-55: the calls source/kinect_client.cpp makes on the input object
+    text = open(os.path.join(HOST, "recon_integration_hip.hpp")).read()
+    body = text[text.index("class NetKinectArrayHip"):]
+    for name in ["update", "processTextures", "filterTextures", "useProcessedDepths", "refineBoundary"]:
+        assert re.search(r"\b%s\s*\(" % name, body), name
+
+
 def test_python_mirror_has_the_reference_method_names(rr):
     for name in ["draw", "drawF", "integrate", "setColorFilling", "setUseBricks", "setSpaceSkip", "setTsdfLimit", "setBrickSize",
                  "numBricks", "occupiedRatio", "getBrickSize", "clearOccupiedBricks", "updateOccupiedBricks", "setMinVoxelsPerBrick", "resize"]:
