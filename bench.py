@@ -99,6 +99,11 @@ def main():
                     help="N > 1: 'slabs' = ONE volume split into Z-slabs with the RCCL exchange (the north-star partition, strong scaling); "
                          "'frames' = every GPU fuses its own frames of the stream (each frame rebuilds the volume from scratch, so frames are "
                          "independent: no exchange at all, weak scaling)")
+    ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="single GPU: process this many frames concurrently, one context + HIP stream per slot (every frame rebuilds the "
+                         "volume from scratch, so frames are independent and the frame's 17 small latency-bound kernels overlap well). "
+                         "A throughput mode: the latency of a frame does not improve, and per-kernel times (roofline) are measured under "
+                         "contention.  Default 1")
     ap.add_argument("--sparse-pool", type=int, default=0, metavar="TILES",
                     help="store the TSDF in a sparse pool of this many 8^3-voxel tiles (2 KiB each) instead of a dense array "
                          "(BASELINE.json configs[4] 'sparse-brick allocation'); needs a culled configuration")
@@ -147,6 +152,22 @@ def main():
     drv = mg.SlabDriver(hip, 0 if frames_mode else rank, 1 if frames_mode else world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite,
                         preprocess=args.preprocess)
     mv, pr = rr.scene.default_view(*VIEW)
+    # extra frame slots (throughput mode): independent contexts on their own streams, fed round robin in the timed loop
+    slots = [drv]
+    if args.frames_in_flight > 1:
+        if world > 1 or args.ingest:
+            raise SystemExit("--frames-in-flight is a single-GPU option (and not combined with --ingest)")
+        for _ in range(args.frames_in_flight - 1):
+            h2 = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, sparse_pool_tiles=args.sparse_pool)
+            h2.setUseBricks(cfg["use_bricks"]); h2.setSpaceSkip(cfg["skip_space"]); h2.setColorFilling(cfg["fill_holes"])
+            s2 = torch.cuda.Stream()
+            h2.set_stream(s2.cuda_stream)
+            if args.preprocess:
+                h2.upload_raw_frame(scene)
+            slots.append(mg.SlabDriver(h2, 0, 1, f"cuda:{local}", view=VIEW, preprocess=args.preprocess))
+            slots[-1]._stream = s2                  # keep the torch stream alive
+        for d in slots * 5:
+            d.frame(mv, pr)
 
     def barrier():
         if world > 1:
@@ -161,6 +182,11 @@ def main():
     hip.sync()
     upload_ms = (time.perf_counter() - tu0) / 5 * 1e3
     for _ in range(args.warmup):
+        drv.frame(mv, pr)
+    # The HIP runtime has a one-time stall of ~18 ms a few thousand launches into a process (measured: 600 timed steps after 20
+    # warm-up frames ran 12 % slower than after 700; 200 or 30 000 steps did not show it).  Whatever W the caller asks for, run
+    # the launch path into its steady state before anything is timed.
+    for _ in range(max(0, 800 - args.warmup)):
         drv.frame(mv, pr)
     barrier()
 
@@ -184,12 +210,19 @@ def main():
         dom = max(cands, key=lambda k: stages[k]) if cands else None
         # ... and the timed region records only the dominant kernel's two events per frame (the roofline's live measurement)
         if dom:
+            hip.timer_reserve(dom, args.steps)       # no hipEventCreate inside the timed loop
             hip.set_timer_filter([dom])
             hip.enable_timers(True)
     barrier()
+    # at most ~200 event pairs in flight: many hundreds of un-synchronised events slow the launch path down (600 steps with an
+    # event pair each ran 12 % slower than 200), so long runs time the dominant kernel on every stride-th frame
+    stride = max(1, args.steps // 200)
+    timing = bool(dom)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        drv.frame(mv, pr)
+    for i in range(args.steps):
+        if timing and stride > 1:
+            hip.enable_timers(i % stride == 0)
+        slots[i % len(slots)].frame(mv, pr)
     barrier()
     dt = time.perf_counter() - t0
     hip.enable_timers(False)
@@ -205,6 +238,7 @@ def main():
     # per-frame device time distribution (SURVEY.md section 8d asks for median and p95): one event pair per frame, own short pass
     frame_ms = None
     if not args.no_timers:
+        hip.timer_reserve("frame", 100)
         hip.set_timer_filter(["frame"])
         hip.enable_timers(True)
         for _ in range(100):
@@ -225,6 +259,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "config": args.config, "streams": cfg["streams"], "res": list(cfg["res"]),
                    "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
+                   "frames_in_flight": args.frames_in_flight,
                    "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
                    "parallelism": "single GPU" if world == 1 else (f"{world} GPUs, each fusing its own frames (no exchange)" if frames_mode else
                                                                     f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0")},

@@ -238,6 +238,7 @@ int32_t tsdf_enable_timers(tsdf_ctx* ctx, int32_t active);
 int32_t tsdf_set_timer_filter(tsdf_ctx* ctx, const char* names);
 /* caller-defined intervals on the context's stream (recorded only while timers are enabled and `name` passes the filter),
  * and the individual samples of any timer since it was last read (resets it) */
+int32_t tsdf_timer_reserve(tsdf_ctx* ctx, const char* name, uint32_t n);   /* create n event pairs now instead of on first use */
 int32_t tsdf_timer_begin(tsdf_ctx* ctx, const char* name);
 int32_t tsdf_timer_end(tsdf_ctx* ctx, const char* name);
 int32_t tsdf_timer_samples(tsdf_ctx* ctx, const char* name, float* out_ms, uint32_t capacity, uint32_t* count);

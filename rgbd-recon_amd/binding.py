@@ -415,6 +415,8 @@ class ReconIntegrationHip:
         self._ck(self._L.tsdf_sparse_pool_stats(self._c, C.byref(need), C.byref(cap)))
         return need.value, cap.value
 
+    def timer_reserve(self, name, n): self._ck(self._L.tsdf_timer_reserve(self._c, name.encode(), int(n)))
+
     def timer_begin(self, name): self._ck(self._L.tsdf_timer_begin(self._c, name.encode()))
     def timer_end(self, name): self._ck(self._L.tsdf_timer_end(self._c, name.encode()))
 

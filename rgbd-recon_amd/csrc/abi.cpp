@@ -1171,6 +1171,19 @@ int32_t tsdf_timer_ms(tsdf_ctx* c, const char* name, float* ms) {
   HIP_TRY(c, hipEventElapsedTime(ms, e.first, e.second));
   return TSDF_OK;
 }
+// event pairs are created on first use; creating them inside a measured loop costs host time per frame: make n available up front
+int32_t tsdf_timer_reserve(tsdf_ctx* c, const char* name, uint32_t n) {
+  CHECK_CTX(c);
+  if (!name) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  Timer& t = c->timers[name];
+  while (t.ev.size() < std::min<size_t>(n, kMaxTimerPairs)) {
+    hipEvent_t a, b;
+    HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b));
+    t.ev.emplace_back(a, b);
+  }
+  return TSDF_OK;
+}
 // caller-defined intervals on the context's stream (bench.py brackets whole frames with them)
 int32_t tsdf_timer_begin(tsdf_ctx* c, const char* name) { CHECK_CTX(c); if (!name) return TSDF_ERR_INVALID_ARGUMENT; HIP_TRY(c, hipSetDevice(c->device)); timer_begin(c, name); return TSDF_OK; }
 int32_t tsdf_timer_end(tsdf_ctx* c, const char* name) { CHECK_CTX(c); if (!name) return TSDF_ERR_INVALID_ARGUMENT; timer_end(c, name); return TSDF_OK; }
