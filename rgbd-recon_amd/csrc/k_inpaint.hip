@@ -20,16 +20,32 @@ struct Texel { float4 c; float d; };
 //   cls 1: the freshly cleared copy's value (ViewLod::enable, view_lod.cpp:75-81): columns >= w of S are never written,
 //          and pyramid levels > lod are still cleared in the reference when this level is built
 //   cls 2: atlas texel at `off`: squeezed column s holds atlas column int(pass_TexCoord.x * resolution_tex.x)
+// The 4 x 4 window is a product of 4 columns and 4 rows: the two IEEE divisions of the mapping are done once per column / row
+// (8 per pixel instead of 32) and a tap's class and offset are combined from its column's and its row's part.
 struct TapAddr { uint32_t off; int cls; };
-__device__ __forceinline__ TapAddr squeezed_addr(const Atlas& A, int w, int lod, int s, int y) {
-  const bool oob = s < 0 || y < 0 || s >= A.aw || y >= A.h;
-  const float tu = ((float)s + 0.5f) / (float)w, tv = ((float)y + 0.5f) / (float)A.h;
-  const int c = (int)(tu * (float)A.aw), sy = (int)(tv * (float)A.h);
-  const bool cleared = s >= w || (c >= w && !(lod >= 1 && sy >= A.off[lod][1]));
-  const bool zero2 = c >= A.aw || sy >= A.h;
+struct TapCol { int c; bool oob, past_w, in_pyramid, past_aw; };      // squeezed column s -> atlas column c
+struct TapRow { int sy; bool oob, below_level, past_h; };            // row y -> atlas row sy
+__device__ __forceinline__ TapCol squeezed_col(const Atlas& A, int w, int s) {
+  TapCol t;
+  const float tu = ((float)s + 0.5f) / (float)w;                       // pass_TexCoord.x
+  t.c = (int)(tu * (float)A.aw);                                       // ivec2(pass_TexCoord * resolution_tex).x
+  t.oob = s < 0 || s >= A.aw; t.past_w = s >= w; t.in_pyramid = t.c >= w; t.past_aw = t.c >= A.aw;
+  return t;
+}
+__device__ __forceinline__ TapRow squeezed_row(const Atlas& A, int lod, int y) {
+  TapRow t;
+  const float tv = ((float)y + 0.5f) / (float)A.h;
+  t.sy = (int)(tv * (float)A.h);
+  t.oob = y < 0 || y >= A.h; t.below_level = lod >= 1 && t.sy >= A.off[lod][1]; t.past_h = t.sy >= A.h;
+  return t;
+}
+__device__ __forceinline__ TapAddr squeezed_addr(const Atlas& A, const TapCol& C, const TapRow& R) {
+  const bool oob = C.oob || R.oob;
+  const bool cleared = C.past_w || (C.in_pyramid && !R.below_level);
+  const bool zero2 = C.past_aw || R.past_h;
   TapAddr t;
   t.cls = oob ? 0 : (cleared ? 1 : (zero2 ? 0 : 2));
-  t.off = t.cls == 2 ? (uint32_t)sy * (uint32_t)A.aw + (uint32_t)c : 0u;
+  t.off = t.cls == 2 ? (uint32_t)R.sy * (uint32_t)A.aw + (uint32_t)C.c : 0u;
   return t;
 }
 
@@ -41,11 +57,15 @@ __device__ __forceinline__ void inpaint_pixel(const Atlas& A, int w, int lod, in
   const int lx = (int)((float)A.off[lod][0] + (float)A.res[lod][0] * tcx);                           // to_lod_pos, :30-32
   const int ly = (int)((float)A.off[lod][1] + (float)A.res[lod][1] * tcy);
   const int pxi = (int)((float)lx * (float)(2.0 / 3.0)), pyi = (int)((float)ly * 1.0f);               // :38
+  TapCol tcol[4];
+  TapRow trow[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { tcol[k] = squeezed_col(A, w, pxi + k - 1); trow[k] = squeezed_row(A, lod, pyi + k - 1); }
   TapAddr ta[16];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) ta[x + y * 4] = squeezed_addr(A, w, lod, pxi + x - 1, pyi + y - 1);   // :45-47
+    for (int y = 0; y < 4; ++y) ta[x + y * 4] = squeezed_addr(A, tcol[x], trow[y]);                    // :45-47
   float4 tc[16];
   float td_[16];
 #pragma unroll
