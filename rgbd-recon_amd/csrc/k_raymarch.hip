@@ -77,55 +77,65 @@ __global__ __launch_bounds__(64) void k_depth_limits(ViewParams P, Bricks B, uin
       lo[a] = (float)idx[a] * B.size[a] + B.bbox_min[a] + 0.0f * B.size[a];
       hi[a] = (float)idx[a] * B.size[a] + B.bbox_min[a] + 1.0f * B.size[a];
     }
+    // One sweep over the pixel bounding box of the whole brick instead of one per face: the ray direction of a pixel is
+    // computed once and tested against the (up to six) drawn faces, and the per-face MIN/MAX blends collapse into at most three
+    // atomics per pixel.  Every (pixel, face) pair passes exactly the tests it passed in a per-face sweep -- a pixel outside a
+    // face's own bounding box fails that face's rectangle test -- so the peels are unchanged.
+    bool drawn[6], front[6];
+    float coord[6];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+    for (int f = 0; f < 6; ++f) {
+      const int a = f >> 1, dir = (f & 1) ? 1 : -1;
+      drawn[f] = !neighbour_gt10(B, idx[0], idx[1], idx[2], a, dir);        // shared face culled in the GS, bricks.gs:26-43
+      coord[f] = dir < 0 ? lo[a] : hi[a];
+      front[f] = dir > 0 ? (o[a] > coord[f]) : (o[a] < coord[f]);           // gl_FrontFacing of an outward-wound cube
+    }
+    if (!(drawn[0] | drawn[1] | drawn[2] | drawn[3] | drawn[4] | drawn[5])) continue;
+    // pixel bounding box of the brick (conservative: +-1 px; whole screen if a corner is behind the eye)
+    float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f;
+    bool behind = false;
 #pragma unroll
-      for (int dir = -1; dir <= 1; dir += 2) {
-        if (neighbour_gt10(B, idx[0], idx[1], idx[2], a, dir)) continue;  // shared face culled in the GS, bricks.gs:26-43
-        const float coord = dir < 0 ? lo[a] : hi[a];
-        // pixel bounding box of the face (conservative: +-1 px; whole screen if a corner is behind the eye)
-        float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f;
-        bool behind = false;
+    for (int c = 0; c < 8; ++c) {
+      const float4 e = mat_mul(P.mv, (c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2], 1.0f);
+      const float4 cl = mat_mul(P.proj, e.x, e.y, e.z, e.w);
+      behind |= !(cl.w > 1.0e-6f);
+      const float wx = (cl.x / cl.w * 0.5f + 0.5f) * (float)P.w, wy = (cl.y / cl.w * 0.5f + 0.5f) * (float)P.h;
+      bx0 = fminf(bx0, wx); bx1 = fmaxf(bx1, wx); by0 = fminf(by0, wy); by1 = fmaxf(by1, wy);
+    }
+    int x0 = 0, x1 = P.w - 1, y0 = 0, y1 = P.h - 1;
+    if (!behind) {
+      x0 = max((int)floorf(fmaxf(bx0, -1.0e6f)) - 1, 0); x1 = min((int)floorf(fminf(bx1, 1.0e6f)) + 1, P.w - 1);
+      y0 = max((int)floorf(fmaxf(by0, -1.0e6f)) - 1, 0); y1 = min((int)floorf(fminf(by1, 1.0e6f)) + 1, P.h - 1);
+    }
+    const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+    if (bw <= 0 || bh <= 0) continue;
+    for (int k = lane; k < bw * bh; k += 64) {
+      const int px = x0 + k % bw, py = y0 + k / bw;
+      const float3 dw = pixel_dir_world(P, (float)px + 0.5f, (float)py + 0.5f);
+      const float d[3] = {dw.x, dw.y, dw.z};
+      float zmin = 2.0f, zmax = -1.0f, zback = 2.0f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float hp[3];
-          hp[a] = coord; hp[a1] = (c & 1) ? hi[a1] : lo[a1]; hp[a2] = (c & 2) ? hi[a2] : lo[a2];
-          const float4 e = mat_mul(P.mv, hp[0], hp[1], hp[2], 1.0f);
-          const float4 cl = mat_mul(P.proj, e.x, e.y, e.z, e.w);
-          behind |= !(cl.w > 1.0e-6f);
-          const float wx = (cl.x / cl.w * 0.5f + 0.5f) * (float)P.w, wy = (cl.y / cl.w * 0.5f + 0.5f) * (float)P.h;
-          bx0 = fminf(bx0, wx); bx1 = fmaxf(bx1, wx); by0 = fminf(by0, wy); by1 = fmaxf(by1, wy);
-        }
-        int x0 = 0, x1 = P.w - 1, y0 = 0, y1 = P.h - 1;
-        if (!behind) {
-          x0 = max((int)floorf(fmaxf(bx0, -1.0e6f)) - 1, 0); x1 = min((int)floorf(fminf(bx1, 1.0e6f)) + 1, P.w - 1);
-          y0 = max((int)floorf(fmaxf(by0, -1.0e6f)) - 1, 0); y1 = min((int)floorf(fminf(by1, 1.0e6f)) + 1, P.h - 1);
-        }
-        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-        if (bw <= 0 || bh <= 0) continue;
-        const bool front = dir > 0 ? (o[a] > coord) : (o[a] < coord);     // gl_FrontFacing of an outward-wound cube
-        for (int k = lane; k < bw * bh; k += 64) {
-          const int px = x0 + k % bw, py = y0 + k / bw;
-          const float3 dw = pixel_dir_world(P, (float)px + 0.5f, (float)py + 0.5f);
-          const float d[3] = {dw.x, dw.y, dw.z};
-          const float t = (coord - o[a]) / d[a];
-          if (!(t > 0.0f)) continue;
-          const float q1 = o[a1] + t * d[a1], q2 = o[a2] + t * d[a2];
-          if (q1 < lo[a1] || q1 > hi[a1] || q2 < lo[a2] || q2 > hi[a2]) continue;
-          float hp[3];
-          hp[a] = coord; hp[a1] = q1; hp[a2] = q2;
-          const float ez = P.mv.m[2] * hp[0] + P.mv.m[6] * hp[1] + P.mv.m[10] * hp[2] + P.mv.m[14] * 1.0f;
-          const float zw = (P.proj.m[10] * ez + P.proj.m[14]) / (-ez) * 0.5f + 0.5f;
-          if (!(zw >= 0.0f && zw <= 1.0f)) continue;                      // near / far clip
-          uint32_t* pp = (uint32_t*)&peels[(size_t)py * P.w + px];
-          const uint32_t zb = __float_as_uint(zw);
-          atomicMin(pp + 0, zb);                                          // bricks.fs:6 with GL_MIN blending
-          atomicMax(pp + 1, zb);
-          if (!front) atomicMin(pp + 2, zb);
-          if (touched) touched[(py >> 3) * ntx + (px >> 3)] = 1;
-        }
+      for (int f = 0; f < 6; ++f) {
+        if (!drawn[f]) continue;
+        const int a = f >> 1, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+        const float t = (coord[f] - o[a]) / d[a];
+        if (!(t > 0.0f)) continue;
+        const float q1 = o[a1] + t * d[a1], q2 = o[a2] + t * d[a2];
+        if (q1 < lo[a1] || q1 > hi[a1] || q2 < lo[a2] || q2 > hi[a2]) continue;
+        float hp[3];
+        hp[a] = coord[f]; hp[a1] = q1; hp[a2] = q2;
+        const float ez = P.mv.m[2] * hp[0] + P.mv.m[6] * hp[1] + P.mv.m[10] * hp[2] + P.mv.m[14] * 1.0f;
+        const float zw = (P.proj.m[10] * ez + P.proj.m[14]) / (-ez) * 0.5f + 0.5f;
+        if (!(zw >= 0.0f && zw <= 1.0f)) continue;                        // near / far clip
+        zmin = fminf(zmin, zw); zmax = fmaxf(zmax, zw);                   // bricks.fs:6 with GL_MIN blending on (z, -z, back z)
+        if (!front[f]) zback = fminf(zback, zw);
       }
+      if (zmax < 0.0f) continue;                                          // no face of this brick under the pixel
+      uint32_t* pp = (uint32_t*)&peels[(size_t)py * P.w + px];
+      atomicMin(pp + 0, __float_as_uint(zmin));
+      atomicMax(pp + 1, __float_as_uint(zmax));
+      if (zback <= 1.0f) atomicMin(pp + 2, __float_as_uint(zback));
+      if (touched) touched[(py >> 3) * ntx + (px >> 3)] = 1;
     }
   }
 }
