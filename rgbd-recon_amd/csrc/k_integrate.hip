@@ -9,6 +9,8 @@
 //   k_integrate_tiles* active tiles only (persistent workgroups pulling from the list); a tile is written
 //                      as two fully coalesced 1 KiB stores per wave; the _lds variant stages the LUT box in LDS
 // Without bricks (setUseBricks(false)) every tile is active and the dense kernel runs on a plain grid.
+#include <cstdlib>
+
 #include "sampling.hpp"
 
 namespace rr {
@@ -200,8 +202,11 @@ constexpr int kRowCap = RR_K1_BOXCAP;   // x-pass results: dz*dy rows of 8
 #endif
 constexpr int kChunk = RR_K1_CHUNK;
 
-template <bool kList>
-__global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
+// kThreads = 256 (shipped): two voxels per thread (z and z + 4); 128 (RR_K1_THREADS=128, experiment): four voxels per thread --
+// half the workgroup, twice as many tiles in flight per CU, meant to fill the last, mostly empty round of resident workgroups.
+// Measured slower (see launch_integrate): the per-tile chain gets longer by more than the extra tiles in flight return.
+template <bool kList, int kThreads>
+__global__ __launch_bounds__(kThreads, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
   __shared__ float4 s_box[kChunk][kBoxCap];     // the texel box; after the x-pass it is reused for the y-pass results
   __shared__ float4 s_row[kChunk][kRowCap];     // x-pass results
   __shared__ int s_i0[kChunk][3][8], s_i1[kChunk][3][8];
@@ -217,15 +222,17 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
     tile_coords(V, tile, t3[0], t3[1], t3[2]);
     if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
     float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
-    // both voxels of this thread: l and l + 256 share x and y, z differs by 4
+    constexpr int kVox = 512 / kThreads, kZStep = kThreads / 64;        // voxels per thread; their z spacing
+    static_assert(!kUseSkip || kThreads == 256, "the tile class vote of the skip experiment assumes two voxels per thread");
+    // the voxels of this thread share x and y
     const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
-    bool drawn[2], inres[2];
-    float tsd[2], wsum[2];
+    bool drawn[kVox], inres[kVox];
+    float tsd[kVox], wsum[kVox];
     if (tid == 0) s_flag = 3;                                           // ordered before the vote by the chunk barriers
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int z = t3[2] * 8 + lz + 4 * h;
+    for (int h = 0; h < kVox; ++h) {
+      const int z = t3[2] * 8 + lz + kZStep * h;
       drawn[h] = inres[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
       if (drawn[h] && per_voxel_check) drawn[h] = voxel_drawn(B, x, y, z);
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         const int mx = s_i0[c][0][0], my = s_i0[c][1][0], mz = s_i0[c][2][0];
         const int dx = s_i1[c][0][7] - mx + 1, dy = s_i1[c][1][7] - my + 1, dz = s_i1[c][2][7] - mz + 1;
         const int n = min(dx * dy * dz, kBoxCap);
-        for (int e = tid; e < n; e += 256) {
+        for (int e = tid; e < n; e += kThreads) {
           const int bx = e % dx, by = (e / dx) % dy, bz = e / (dx * dy);
           // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate and this launch is VALU-issue bound): operands are LUT
           // coordinates / resolutions <= 2048, the texel index fits 32 bits (tsdf_set_calibration rejects larger LUTs)
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         const int mx = s_i0[c][0][0];
         const int dx = s_i1[c][0][7] - mx + 1, dy = s_i1[c][1][7] - s_i0[c][1][0] + 1, dz = s_i1[c][2][7] - s_i0[c][2][0] + 1;
         const int n1 = min(dy * dz * 8, kRowCap);
-        for (int e = tid; e < n1; e += 256) {
+        for (int e = tid; e < n1; e += kThreads) {
           const int k = e & 7, row = e >> 3;
           const int rb = __mul24(row, dx);
           const float4 a = s_box[c][rb + (s_i0[c][0][k] - mx)], b = s_box[c][rb + (s_i1[c][0][k] - mx)];
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         const int my = s_i0[c][1][0];
         const int dy = s_i1[c][1][7] - my + 1, dz = s_i1[c][2][7] - s_i0[c][2][0] + 1;
         const int n2 = min(dz * 64, kBoxCap);
-        for (int e = tid; e < n2; e += 256) {
+        for (int e = tid; e < n2; e += kThreads) {
           const int k = e & 7, j = (e >> 3) & 7, bz = e >> 6;
           const int zb = __mul24(bz, dy);
           const float4 a = s_row[c][((zb + (s_i0[c][1][j] - my)) << 3) + k], b = s_row[c][((zb + (s_i1[c][1][j] - my)) << 3) + k];
@@ -280,10 +287,13 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         }
       }
       __syncthreads();
-      if (__ballot(drawn[0] | drawn[1]) != 0ull) {                      // pass Z + fusion
+      bool any_drawn = false;
+#pragma unroll
+      for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
+      if (__ballot(any_drawn) != 0ull) {                                // pass Z + fusion
 #pragma unroll RR_K1_UNROLL_H
-        for (int h = 0; h < 2; ++h) {
-          const int kz = lz + 4 * h;
+        for (int h = 0; h < kVox; ++h) {
+          const int kz = lz + kZStep * h;
           float3 pc[kChunk];
           Dqs q[kChunk];
 #pragma unroll
@@ -324,11 +334,14 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         }
       }
     }
-    const float v0 = drawn[0] ? tsd[0] : -limit, v1 = drawn[1] ? tsd[1] : -limit;   // clearImage(-limit), :249-250
-    out[tid] = v0;
-    out[tid + 256] = v1;
+    float vv[kVox];
+#pragma unroll
+    for (int h = 0; h < kVox; ++h) {
+      vv[h] = drawn[h] ? tsd[h] : -limit;                               // clearImage(-limit), :249-250
+      out[tid + kThreads * h] = vv[h];
+    }
     if (kUseSkip) {
-      tile_class_vote(&s_flag, inres[0], v0, inres[1], v1, limit);
+      tile_class_vote(&s_flag, inres[0], vv[0], inres[kVox - 1], vv[kVox - 1], limit);
       __syncthreads();
       if (tid == 0) S.cls[tile] = tile_class_from(s_flag);
     } else if (tid == 0) {
@@ -346,11 +359,14 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     }
     if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
-    if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    // A/B (c2 / c3 / c4 integrate, us): 256 threads 69 / 119 / 383, 128 threads 74 / 128 / 415 -- the smaller workgroup loses
+    static const int wg = (getenv("RR_K1_THREADS") && atoi(getenv("RR_K1_THREADS")) == 128) ? 128 : 256;
+    if (lds_ok && wg == 128) hipLaunchKernelGGL((k_integrate_tiles_lds<true, 128>), grid, dim3(128), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, 256>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
   } else {
     if (phase == 1) return;
-    if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+    if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, 256>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
   }
 }
