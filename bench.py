@@ -131,9 +131,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # rehearsal hooks for a box with ONE GPU (never set by the driver): all ranks on device RR_BENCH_DEVICE, gloo instead of RCCL
+    backend = os.environ.get("RR_BENCH_BACKEND", "nccl")
+    if "RR_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["RR_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     cfg = CONFIGS[args.config]
     limit = 0.01
@@ -228,7 +235,7 @@ def main():
     hip.enable_timers(False)
     hip.set_timer_filter(None)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     dom_ms = None
