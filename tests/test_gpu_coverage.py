@@ -108,3 +108,46 @@ def test_frame_sequence_resets_tiles_that_empty_out(rr):
         occupied.append(set(np.flatnonzero(hip.bricks()[1])))
     assert occupied[0] - occupied[1] and occupied[1] - occupied[2]      # bricks really do empty out between the frames
     assert occupied[0] == occupied[3]
+
+
+def test_older_config_struct_is_still_accepted(rr, small_scene):
+    """tsdf_config grew by sparse_pool_tiles: a caller built against the previous layout (struct_size 4 bytes shorter) still works."""
+    import ctypes as C
+    L = rr.load_library()
+    hip = rr.ReconIntegrationHip(small_scene, **KW)                  # reference context for the geometry
+    cfg = rr.TsdfConfig()
+    cfg.struct_size = C.sizeof(rr.TsdfConfig) - 4
+    cfg.bbox_min[:] = [float(x) for x in small_scene["bbox_min"]]
+    cfg.bbox_max[:] = [float(x) for x in small_scene["bbox_max"]]
+    cfg.voxel_size = 0.05
+    cfg.res[:] = [64, 64, 64]
+    cfg.brick_size[:] = [0.25, 0.275, 0.25]
+    cfg.limit = 0.04
+    cfg.num_streams = small_scene["n"]
+    cfg.depth_w, cfg.depth_h = small_scene["width"], small_scene["height"]
+    cfg.color_w, cfg.color_h = small_scene["color_width"], small_scene["color_height"]
+    cfg.view_w, cfg.view_h = 160, 90
+    cfg.sparse_pool_tiles = 12345                                    # lies beyond struct_size: must be ignored
+    ctx = C.c_void_p()
+    assert L.tsdf_create(C.byref(cfg), C.byref(ctx)) == 0
+    need, cap = C.c_uint32(), C.c_uint32()
+    assert L.tsdf_sparse_pool_stats(ctx, C.byref(need), C.byref(cap)) != 0       # a dense context
+    assert L.tsdf_destroy(ctx) == 0
+    cfg.struct_size = 8
+    assert L.tsdf_create(C.byref(cfg), C.byref(ctx)) != 0
+
+
+def test_caller_timers_and_samples(rr, small_scene):
+    hip = rr.ReconIntegrationHip(small_scene, **KW)
+    mv, pr = rr.scene.default_view(*KW["view"])
+    hip.timer_reserve("frame", 8)
+    hip.set_timer_filter(["frame"])
+    hip.enable_timers(True)
+    for _ in range(5):
+        hip.timer_begin("frame"); frame(hip, mv, pr); hip.timer_end("frame")
+    hip.enable_timers(False)
+    smp = hip.timer_samples("frame")
+    assert smp.shape == (5,) and (smp > 0).all() and smp.max() < 50.0
+    assert hip.timer_samples("frame").size == 0                      # reading resets
+    assert hip.timer_stats("k_integrate_tiles")[0] == 0              # filtered out while the filter was set
+    hip.set_timer_filter(None)
