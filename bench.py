@@ -40,12 +40,13 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")   # per-kernel HBM bytes from separate rocprofv3 --pmc passes
 
 
-def measured_traffic(config, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json, made by
-    profiles/summarize_pmc.py from FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections); None if absent."""
+def measured_traffic(config, kernel, key="hbm_bytes"):
+    """HBM bytes (or, key="valu_insts", VALU wave-instructions) per launch of `kernel` from the committed PMC summary
+    (profiles/traffic.json, made by profiles/summarize_pmc.py from separate FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes with the
+    gfx950 corrections); None if absent."""
     try:
         with open(TRAFFIC_JSON) as f:
-            return json.load(f).get(config, {}).get(kernel, {}).get("hbm_bytes")
+            return json.load(f).get(config, {}).get(kernel, {}).get(key)
     except (OSError, ValueError):
         return None
 
@@ -281,10 +282,14 @@ def main():
         ach = ab[key] / (dom_ms * 1e-3) / 1e9
         kname = "k_integrate_tiles_lds" if key == "integrate" else "k_march"
         traffic = measured_traffic(args.config, kname)
+        valu = measured_traffic(args.config, kname, "valu_insts")
         out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": traffic, "algorithmic_bytes": ab[key], "avg_launch_ms": dom_ms,
                            "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                           # what actually binds this kernel: VALU wave-instructions (PMC) x 4 issue cycles over the
+                           # 1024 SIMDs' cycles at 2.4 GHz during the launch
+                           "valu_issue_frac": (valu * 4.0 / (1024 * 2.4e9 * dom_ms * 1e-3)) if valu else None,
                            "timing": "HIP events around this kernel alone, recorded on the launch stream in every frame of the timed region",
                            "note": "algorithmic bytes are the DENSE figures of BASELINE.md section 3; with brick culling the launch touches "
                                    "only occupied tiles (occupied_brick_ratio), so achieved may exceed what HBM really moved (traffic)"}

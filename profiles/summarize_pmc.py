@@ -1,7 +1,11 @@
 """profiles/traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (run on the GPU box, separate passes as
 MI355X_MICROARCH.md prescribes; both counters are in KiB).
 
-    python profiles/summarize_pmc.py <config> <fetch_counter_collection.csv> <write_counter_collection.csv>
+    python profiles/summarize_pmc.py <config> <fetch_counter_collection.csv> <write_counter_collection.csv> [<sq_insts_valu_counter_collection.csv>]
+
+The optional fourth pass (SQ_INSTS_VALU) adds `valu_insts` = VALU wave-instructions per launch; bench.py turns it into
+`roofline.valu_issue_frac` = valu_insts x 4 issue cycles / (1024 SIMDs x 2.4 GHz x launch time): the share of the launch the
+SIMDs spend issuing vector instructions (the binding resource of the integrate kernel).
 
 Corrections: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950 -> x2 (an upper bound for gathers);
 WRITE_SIZE is taken as is (calibration on this path: the dense c1 integrate writes 256^3 x 4 B = 67.1 MB and the counter
@@ -15,9 +19,11 @@ import sys
 GROUPS = {"k_integrate_tiles_lds": ("k_integrate_tiles_lds",), "k_march": ("k_march",), "k_march+k_shade": ("k_march", "k_shade")}   # k_march covers both passes (k_march<>, k_march_long)
 
 
-def per_kernel(path):
+def per_kernel(path, counter=None):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
+        if counter and r["Counter_Name"] != counter:
+            continue
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in agg.items()}     # steady-state launches
 
@@ -25,11 +31,14 @@ def per_kernel(path):
 def main():
     cfg, fetch, write = sys.argv[1:4]
     f, w = per_kernel(fetch), per_kernel(write)
+    v = per_kernel(sys.argv[4], "SQ_INSTS_VALU") if len(sys.argv) > 4 else {}
     out = {}
     for name, parts in GROUPS.items():
         fb = sum(v for k, v in f.items() if any(p in k for p in parts)) * 1024 * 2
         wb = sum(v for k, v in w.items() if any(p in k for p in parts)) * 1024
         out[name] = {"fetch_bytes_corrected": fb, "write_bytes_corrected": wb, "hbm_bytes": fb + wb}
+        if v:
+            out[name]["valu_insts"] = sum(x for k, x in v.items() if any(p in k for p in parts))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[cfg] = out
