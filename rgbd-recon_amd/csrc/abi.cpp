@@ -47,7 +47,12 @@ struct tsdf_ctx {
   uint8_t* d_vox_count[3]{};
   uint16_t* d_tile_b0[3]{};
   uint16_t* d_tile_b1[3]{};
-  bool occ_count_zeroed = false, tile_count_zeroed = false;   // the two device scalars were reset by tsdf_clear_bricks' memset
+  uint16_t* d_brick_t0[3]{};
+  uint16_t* d_brick_t1[3]{};
+  // active-tile lists of this and the previous integrate() (k_classify_lists), their two device counts, and what decides
+  // whether the next integrate() may trust the previous list
+  uint32_t* d_tile_list[2]{}; uint32_t* d_tile_counts = nullptr; int tile_parity = 0; bool full_classify = true; uint32_t frame_stamp = 0;
+  uint32_t* d_occ_counts = nullptr; int occ_parity = 0;   // two occupied-brick counts used alternately (see Bricks::num_occupied)
   uint32_t min_voxels = 10;      // recon_integration.cpp:59
   size_t counter_words = 0;
   uint32_t* h_num_occupied = nullptr;   // pinned
@@ -139,10 +144,12 @@ void release_view(tsdf_ctx* c) {
 }
 void release_bricks(tsdf_ctx* c) {
   hipFree(c->br.counters); hipFree(c->br.flags); hipFree(c->br.occupied);   // num_occupied and tiles.count live behind the counters
-  c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr; c->tiles.count = nullptr;
+  c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr;
   for (int a = 0; a < 3; ++a) {
     hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); hipFree(c->d_tile_b0[a]); hipFree(c->d_tile_b1[a]);
+    hipFree(c->d_brick_t0[a]); hipFree(c->d_brick_t1[a]);
     c->d_vox_first[a] = nullptr; c->d_vox_count[a] = nullptr; c->d_tile_b0[a] = nullptr; c->d_tile_b1[a] = nullptr;
+    c->d_brick_t0[a] = nullptr; c->d_brick_t1[a] = nullptr;
   }
 }
 
@@ -252,23 +259,36 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
     HIP_TRY(c, hipMemcpy(c->d_tile_b1[a], t1.data(), nt * sizeof(uint16_t), hipMemcpyHostToDevice));
     B.tile_b0[a] = c->d_tile_b0[a];
     B.tile_b1[a] = c->d_tile_b1[a];
+    // and the inverse: the storage tiles a brick's voxel list reaches into
+    const int nb = (int)starts[a].size();
+    std::vector<uint16_t> bt0(nb, 1), bt1(nb, 0);
+    std::vector<int> blo(nb, 0x7fffffff), bhi(nb, -1);
+    for (int v = 0; v < c->res[a]; ++v)
+      for (int k = 0; k < count[a][v]; ++k) { const int b = first[a][v] + k; blo[b] = std::min(blo[b], v >> 3); bhi[b] = std::max(bhi[b], v >> 3); }
+    for (int b = 0; b < nb; ++b) if (bhi[b] >= 0) { bt0[b] = (uint16_t)blo[b]; bt1[b] = (uint16_t)bhi[b]; }
+    HIP_TRY(c, hipMalloc(&c->d_brick_t0[a], nb * sizeof(uint16_t)));
+    HIP_TRY(c, hipMalloc(&c->d_brick_t1[a], nb * sizeof(uint16_t)));
+    HIP_TRY(c, hipMemcpy(c->d_brick_t0[a], bt0.data(), nb * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_brick_t1[a], bt1.data(), nb * sizeof(uint16_t), hipMemcpyHostToDevice));
+    B.brick_t0[a] = c->d_brick_t0[a];
+    B.brick_t1[a] = c->d_brick_t1[a];
   }
+  c->full_classify = true;                                               // a new brick grid: walk every tile once
   // tiles == bricks structurally?  (every voxel in exactly one brick per axis, and a tile never straddles two)
   bool uniform = true;
   for (int a = 0; a < 3 && uniform; ++a)
     for (int v = 0; v < c->res[a] && uniform; ++v)
       uniform = count[a][v] == 1 && first[a][v] == first[a][v & ~7];
   c->tiles.uniform = uniform ? 1 : 0;
-  // [counters (n) | num_occupied | active tile count]: one memset per frame resets all three (tsdf_clear_bricks)
-  c->counter_words = (((size_t)B.n + 2 + 63) / 64) * 64;      // one aligned fill kernel instead of body + tail
+  c->counter_words = (((size_t)B.n + 3 + 63) / 64) * 64;      // padded: one aligned fill kernel; k_update_occupied reads whole quads
   HIP_TRY(c, hipMalloc(&B.counters, c->counter_words * sizeof(uint32_t)));
-  B.num_occupied = B.counters + B.n;
-  c->tiles.count = B.counters + B.n + 1;
+  if (!c->d_occ_counts) HIP_TRY(c, hipMalloc(&c->d_occ_counts, 2 * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(c->d_occ_counts, 0, 2 * sizeof(uint32_t)));      // a new grid: no occupied list yet
+  B.num_occupied = c->d_occ_counts + c->occ_parity;
   HIP_TRY(c, hipMalloc(&B.flags, (size_t)B.n));
   HIP_TRY(c, hipMalloc(&B.occupied, (size_t)B.n * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(B.counters, 0, c->counter_words * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(B.flags, 0, (size_t)B.n));
-  c->occ_count_zeroed = c->tile_count_zeroed = false;
   return TSDF_OK;
 }
 
@@ -428,7 +448,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   }
   TileState& S = c->tiles;
   S.n = (V.int_tz1 - V.int_tz0) * V.nty * V.ntx;
-  if ((rc = tryhip(hipMalloc(&S.active, (size_t)S.n), "hipMalloc(tiles)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&S.stamp, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc(&c->d_cls_all, (size_t)V.n_stored_tiles), "hipMalloc(tiles)"))) return fail(rc);
   hipMemsetAsync(c->d_cls_all, kTileMixed, (size_t)V.n_stored_tiles, c->stream);   // halo layers keep this value for good
   V.cls = c->d_cls_all;
@@ -449,8 +469,12 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
     }
   }
   S.cls = c->d_cls_all + (size_t)(V.int_tz0 - V.tz0) * V.nty * V.ntx;
-  if ((rc = tryhip(hipMalloc(&S.list, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
-  hipMemsetAsync(S.active, 0, (size_t)S.n, c->stream);
+  for (int k = 0; k < 2; ++k)
+    if ((rc = tryhip(hipMalloc(&c->d_tile_list[k], (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
+  if ((rc = tryhip(hipMalloc(&c->d_tile_counts, 2 * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
+  hipMemsetAsync(c->d_tile_counts, 0, 2 * sizeof(uint32_t), c->stream);
+  hipMemsetAsync(S.stamp, 0, (size_t)S.n * sizeof(uint32_t), c->stream);
+  S.list = c->d_tile_list[0]; S.count = c->d_tile_counts;
   if ((rc = tryhip(hipHostMalloc((void**)&c->h_num_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc"))) return fail(rc);
   *c->h_num_occupied = 0;
   if ((rc = setup_bricks(c, cfg->brick_size))) return fail(rc);
@@ -480,12 +504,13 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   release_view(c); release_bricks(c);
-  hipFree(c->tiles.active); hipFree(c->d_cls_all); hipFree(c->d_pyr); hipFree(c->tiles.list);
+  hipFree(c->tiles.stamp); hipFree(c->d_cls_all); hipFree(c->d_pyr); hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts);
   hipFree(c->vol.data); hipFree(c->vol.slot); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
   hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal);
   hipFree(c->d_depth_plane); hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
   for (void* p : c->lut_allocs) hipFree(p);
   if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
+  hipFree(c->d_occ_counts);
   for (int k = 0; k < 2; ++k) { if (c->h_wire[k]) hipHostFree(c->h_wire[k]); if (c->wire_done[k]) hipEventDestroy(c->wire_done[k]); }
   hipFree(c->d_wire);
   for (auto& kv : c->timers) for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -772,7 +797,6 @@ int32_t tsdf_clear_bricks(tsdf_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "bricks");
   HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), c->stream));
-  c->occ_count_zeroed = c->tile_count_zeroed = true;
   return TSDF_OK;
 }
 int32_t tsdf_mark_bricks(tsdf_ctx* c) {
@@ -787,8 +811,9 @@ int32_t tsdf_mark_bricks(tsdf_ctx* c) {
 int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  launch_update_occupied(c->stream, c->br, c->min_voxels, c->occ_count_zeroed ? 0 : 1);
-  c->occ_count_zeroed = false;
+  c->occ_parity ^= 1;
+  c->br.num_occupied = c->d_occ_counts + c->occ_parity;              // zero since the previous update (or creation) re-armed it
+  launch_update_occupied(c->stream, c->br, c->min_voxels, c->d_occ_counts + (c->occ_parity ^ 1));
   HIP_TRY(c, hipGetLastError());
   timer_end(c, "bricks");
   if (ratio) return tsdf_occupied_ratio(c, ratio);                     // the reference reads the count back every frame (:432-440); here only on request
@@ -813,11 +838,20 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   timer_begin(c, "2integrate");
   bool lds = true;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = lds && c->lds_ok[i];
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->tile_count_zeroed ? 0 : 1, 1);
+  if (c->use_bricks) {
+    // this frame's list / count, the previous integrate()'s (trusted unless something else may have written the volume)
+    TileState& S = c->tiles;
+    const int p = c->tile_parity;
+    S.list = c->d_tile_list[p]; S.count = c->d_tile_counts + p;
+    S.prev_list = c->d_tile_list[p ^ 1]; S.prev_count = c->d_tile_counts + (p ^ 1); S.next_count = c->d_tile_counts + (p ^ 1);
+    if (++c->frame_stamp == 0) { c->frame_stamp = 1; c->full_classify = true; HIP_TRY(c, hipMemsetAsync(S.stamp, 0, (size_t)S.n * sizeof(uint32_t), c->stream)); }
+  }
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->full_classify ? 1 : 0, c->frame_stamp, 1);
   timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, 0, 2);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, 0, c->frame_stamp, 2);
   timer_end(c, "k_integrate_tiles");
-  if (c->use_bricks) c->tile_count_zeroed = false;
+  if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
+  else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them
   timer_end(c, "2integrate");
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -956,6 +990,7 @@ int32_t tsdf_set_tsdf_limit(tsdf_ctx* c, float limit) {
   if (!whole && (int)ceilf((limit * 0.5f * (float)c->res[2] + 2.0f) / 8.0f) > c->halo_layers) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit needs a wider slab halo than this context allocated");
   c->vol.limit = limit;
   launch_mark_all_mixed(c->stream, c->tiles);    // the clear value changed: no tile is known to hold it
+  c->full_classify = true;
   return TSDF_OK;
 }
 int32_t tsdf_set_use_bricks(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->use_bricks = a != 0; return TSDF_OK; }
@@ -1020,6 +1055,7 @@ int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
   HIP_TRY(c, hipMemcpyAsync(c->d_linear, in, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float), hipMemcpyHostToDevice, c->stream));
   launch_volume_from_linear(c->stream, c->vol, c->d_linear);
   launch_mark_all_mixed(c->stream, c->tiles);
+  c->full_classify = true;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSDF_OK;
 }

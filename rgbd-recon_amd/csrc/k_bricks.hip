@@ -63,21 +63,38 @@ void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages&
 }
 
 // flags[b] = counter[b] >= min_voxels, the compacted occupied list and its length (one atomic per wave)
-__global__ __launch_bounds__(256) void k_update_occupied(Bricks B, uint32_t min_voxels) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// Four bricks per lane (one 16-byte load, one packed 4-byte flag store): a brick per lane made this a 1 040-workgroup launch of
+// one-element threads, 10 us for 1.3 MB.  The occupied list is unordered (as the atomics of the reference's readback leave no
+// order either): within a wave it is written bit plane by bit plane.
+__global__ __launch_bounds__(256) void k_update_occupied(Bricks B, uint32_t min_voxels, uint32_t* __restrict__ next_count) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;                    // bricks 4q .. 4q + 3
+  if (q == 0) *next_count = 0u;                                           // the count word the NEXT update accumulates into
   const int lane = threadIdx.x & 63;
-  const bool occ = (b < B.n) && (B.counters[b] >= min_voxels);
-  if (b < B.n) B.flags[b] = occ ? 1 : 0;
-  const unsigned long long m = __ballot(occ);
-  if (m == 0ull) return;
+  const int b0 = 4 * q;
+  uint32_t bits = 0;
+  if (b0 < B.n) {
+    const uint4 cnt = ((const uint4*)B.counters)[q];                      // the allocation is padded to 64 words
+    bits = (cnt.x >= min_voxels ? 1u : 0u) | ((b0 + 1 < B.n && cnt.y >= min_voxels) ? 2u : 0u) | ((b0 + 2 < B.n && cnt.z >= min_voxels) ? 4u : 0u) |
+           ((b0 + 3 < B.n && cnt.w >= min_voxels) ? 8u : 0u);
+    const uint32_t packed = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);   // one flag byte per brick
+    if (b0 + 3 < B.n) ((uint32_t*)B.flags)[q] = packed;
+    else for (int j = 0; j < 4 && b0 + j < B.n; ++j) B.flags[b0 + j] = (uint8_t)((bits >> j) & 1u);
+  }
+  const unsigned long long m0 = __ballot(bits & 1u), m1 = __ballot(bits & 2u), m2 = __ballot(bits & 4u), m3 = __ballot(bits & 8u);
+  const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2), n3 = (uint32_t)__popcll(m3);
+  if ((m0 | m1 | m2 | m3) == 0ull) return;
   uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(B.num_occupied, (uint32_t)__popcll(m));
+  if (lane == 0) base = atomicAdd(B.num_occupied, n0 + n1 + n2 + n3);
   base = __shfl(base, 0);
-  if (occ) B.occupied[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (bits & 1u) B.occupied[base + (uint32_t)__popcll(m0 & below)] = (uint32_t)b0;
+  if (bits & 2u) B.occupied[base + n0 + (uint32_t)__popcll(m1 & below)] = (uint32_t)(b0 + 1);
+  if (bits & 4u) B.occupied[base + n0 + n1 + (uint32_t)__popcll(m2 & below)] = (uint32_t)(b0 + 2);
+  if (bits & 8u) B.occupied[base + n0 + n1 + n2 + (uint32_t)__popcll(m3 & below)] = (uint32_t)(b0 + 3);
 }
-void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, int zero_count) {
-  if (zero_count) hipMemsetAsync(B.num_occupied, 0, sizeof(uint32_t), st);
-  hipLaunchKernelGGL(k_update_occupied, dim3((B.n + 255) / 256), dim3(256), 0, st, B, min_voxels);
+void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, uint32_t* next_count) {
+  const int quads = (B.n + 3) / 4;
+  hipLaunchKernelGGL(k_update_occupied, dim3((quads + 255) / 256), dim3(256), 0, st, B, min_voxels, next_count);
 }
 
 }  // namespace rr

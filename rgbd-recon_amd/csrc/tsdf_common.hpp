@@ -73,10 +73,13 @@ constexpr uint32_t kNoSlot = 0xffffffffu;
 #endif
 constexpr bool kUseSkip = RR_USE_SKIP != 0;
 struct TileState {
-  uint8_t* active;
+  uint32_t* stamp;     // per integrated tile: the frame number that last put it on the active list (dedupes the scatter of k_classify_lists)
   uint8_t* cls;        // owned tiles only (points into Volume::cls at the first owned layer)
-  uint32_t* list;      // compacted active tile ids (unordered)
+  uint32_t* list;      // compacted active tile ids of THIS frame (unordered)
   uint32_t* count;     // device scalar
+  const uint32_t* prev_list;   // the active list of the previous integrate(): the only tiles that can hold anything but the clear value
+  const uint32_t* prev_count;
+  uint32_t* next_count;        // = prev_count's word: re-armed (zeroed) by the integrate kernel for the next frame
   int n;               // owned tiles
   int uniform;         // every tile lies inside exactly one brick's voxel list: tile active => all its voxels drawn
 };
@@ -87,12 +90,15 @@ struct TileState {
 struct Bricks {
   uint32_t* counters;       // per brick
   uint8_t* flags;           // counter >= min_voxels (recon_integration.cpp:436)
-  uint32_t* num_occupied;   // device scalar
+  uint32_t* num_occupied;   // device scalar: the count of the latest updateOccupiedBricks() (one of two words used alternately, so that
+                            // clearOccupiedBricks() leaves the list of the last update intact, as the reference's host vector is)
   uint32_t* occupied;       // compacted ids of the occupied bricks (Occupied SSBO, inc_bricks.glsl:18-20), unordered
   const uint16_t* vox_first[3];
   const uint8_t* vox_count[3];
   const uint16_t* tile_b0[3];   // per storage tile index along an axis: first / last brick whose voxel list reaches into it
   const uint16_t* tile_b1[3];   // (b0 > b1: none)
+  const uint16_t* brick_t0[3];  // the inverse: per brick index along an axis, first / last storage tile its voxel list reaches into
+  const uint16_t* brick_t1[3];  // (t0 > t1: the brick holds no voxel)
   int res[3];               // brick grid
   int n;
   float size[3];            // world brick size
@@ -181,8 +187,11 @@ void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quali
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);
 void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
 void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B);
-void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, int zero_count);
-void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok, int zero_count, int phase = 0);
+void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, uint32_t* next_count);
+// full_classify: 1 = walk every tile (first frame, after anything that may have left non-clear data outside the previous active
+// list); 0 = scatter from the occupied bricks + check the previous list only (work follows the scene, not the volume)
+void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
+                      int full_classify, uint32_t frame_stamp, int phase = 0);
 int integrate_box_cap();
 void launch_mark_all_mixed(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);

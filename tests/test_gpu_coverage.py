@@ -147,7 +147,7 @@ def test_caller_timers_and_samples(rr, small_scene):
         hip.timer_begin("frame"); frame(hip, mv, pr); hip.timer_end("frame")
     hip.enable_timers(False)
     smp = hip.timer_samples("frame")
-    assert smp.shape == (5,) and (smp > 0).all() and smp.max() < 50.0
+    assert smp.shape == (5,) and (smp > 0).all() and np.median(smp) < 5.0      # (a single sample can catch a one-off runtime stall of tens of ms)
     assert hip.timer_samples("frame").size == 0                      # reading resets
     assert hip.timer_stats("k_integrate_tiles")[0] == 0              # filtered out while the filter was set
     hip.set_timer_filter(None)
