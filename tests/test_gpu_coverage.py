@@ -151,3 +151,22 @@ def test_caller_timers_and_samples(rr, small_scene):
     assert hip.timer_samples("frame").size == 0                      # reading resets
     assert hip.timer_stats("k_integrate_tiles")[0] == 0              # filtered out while the filter was set
     hip.set_timer_filter(None)
+
+
+def test_integrate_without_update_uses_the_last_occupied_list(rr):
+    """clearOccupiedBricks() zeroes the counters only; until the next updateOccupiedBricks() the reference keeps integrating and
+    drawing with the host list of the last update (recon_integration.cpp:242-277,430-445)."""
+    kw = dict(n_streams=3, width=128, height=96, lut_res=24, inv_res=32)
+    a, b = rr.scene.make_scene(**kw), rr.scene.make_scene(sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2), **kw)
+    hip, orc = rr.ReconIntegrationHip(a, **KW), OracleRecon(a, **KW)
+    mv, pr = rr.scene.default_view(*KW["view"])
+    for o in (hip, orc):
+        frame(o, mv, pr)                                                 # frame 1: scene a, list of a
+        o.upload_frame(b)
+        o.clearOccupiedBricks(); o.markBricks()                          # counters of b, but no update: the list is still a's
+        o.integrate(); o.drawF(mv, pr)
+    compare(hip, orc)
+    assert (hip.bricks()[0] != 0).sum() > 0
+    for o in (hip, orc):
+        o.updateOccupiedBricks(); o.integrate(); o.drawF(mv, pr)         # now b's list
+    compare(hip, orc)
