@@ -83,6 +83,7 @@ struct tsdf_ctx {
                                                                                 // whenever something else writes the march target
   uint32_t* d_tri_z = nullptr; float4* d_tri_acc = nullptr; float min_length = 0.0125f;   // triangle-grid back-end; KinectCalibrationFile.cpp:96 default
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
+  bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)
   void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
   unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
   float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
@@ -846,7 +847,17 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     S.prev_list = c->d_tile_list[p ^ 1]; S.prev_count = c->d_tile_counts + (p ^ 1); S.next_count = c->d_tile_counts + (p ^ 1);
     if (++c->frame_stamp == 0) { c->frame_stamp = 1; c->full_classify = true; HIP_TRY(c, hipMemsetAsync(S.stamp, 0, (size_t)S.n * sizeof(uint32_t), c->stream)); }
   }
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->full_classify ? 1 : 0, c->frame_stamp, 1);
+  // the draw that follows would first reset the peel tiles its predecessor touched: let the classify launch do it
+  PeelClear pc{};
+  {
+    const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
+    if (c->use_bricks && !c->full_classify && c->skip_space && whole && c->use_tile_history && c->tile_history && c->d_peels) {
+      pc.peels = (uint4*)c->d_peels; pc.touched_prev = c->d_touched[c->touched_parity ^ 1];
+      pc.w = c->vw; pc.h = c->vh; pc.ntx = (c->vw + 7) / 8; pc.n_tiles = pc.ntx * ((c->vh + 7) / 8);
+      c->peels_cleared = true;
+    }
+  }
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
   timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
   launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, 0, c->frame_stamp, 2);
   timer_end(c, "k_integrate_tiles");
@@ -875,9 +886,10 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
       HIP_TRY(c, hipMemsetAsync(c->d_touched[1], 0, n_img_tiles, c->stream));
     }
     launch_depth_limits(c->stream, P, c->br, c->d_peels, use_tiles ? c->d_touched[c->touched_parity] : nullptr,
-                        use_tiles && c->tile_history ? c->d_touched[c->touched_parity ^ 1] : nullptr);
+                        use_tiles && c->tile_history ? c->d_touched[c->touched_parity ^ 1] : nullptr, use_tiles && c->tile_history && c->peels_cleared ? 1 : 0);
     timer_end(c, "brickdraw");
   }
+  c->peels_cleared = false;                                              // consumed (or void: this draw did its own reset)
   RayTarget RT = ray_target(c);
   if (use_tiles) {
     RT.touched_cur = c->d_touched[c->touched_parity]; RT.touched_prev = c->d_touched[c->touched_parity ^ 1];

@@ -115,8 +115,18 @@ __global__ __launch_bounds__(256) void k_classify_clear_tiles(Volume V, Bricks B
 //   B  the other blocks: one lane per tile of the PREVIOUS frame's active list -- the only tiles that can hold anything but the
 //      clear value -- repeats the per-tile test; tiles that dropped out are reset by the whole wave (or lose their slot).
 constexpr int kScatterBlocks = 64;
-__global__ __launch_bounds__(256) void k_classify_lists(Volume V, Bricks B, TileState S, uint32_t frame) {
+//   C  (optional) blocks past kScatterBlocks + kStaleBlocks: the peel tiles of the coming draw that the previous draw touched are
+//      reset here instead of in a launch of their own (k_clear_peel_tiles, k_raymarch.hip) -- independent work, same stream
+constexpr int kStaleBlocks = 192;
+__global__ __launch_bounds__(256) void k_classify_lists(Volume V, Bricks B, TileState S, uint32_t frame, PeelClear PC) {
   const int lane = threadIdx.x & 63;
+  if (blockIdx.x >= kScatterBlocks + kStaleBlocks) {                                // ---- part C
+    const int t = (blockIdx.x - (kScatterBlocks + kStaleBlocks)) * 4 + (threadIdx.x >> 6);
+    if (t >= PC.n_tiles || !PC.touched_prev[t]) return;
+    const int px = (t % PC.ntx) * 8 + (lane & 7), py = (t / PC.ntx) * 8 + (lane >> 3);
+    if (px < PC.w && py < PC.h) PC.peels[(size_t)py * PC.w + px] = make_uint4(__float_as_uint(1.0f), 0u, __float_as_uint(1.0f), 0u);   // clear (1,0,1,0)
+    return;
+  }
   if (blockIdx.x < kScatterBlocks) {                                               // ---- part A
     const uint32_t n_occ = *B.num_occupied;
     for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_occ; w += kScatterBlocks * blockDim.x) {
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256) void k_classify_lists(Volume V, Bricks B, Tile
     return;
   }
   const uint32_t n_prev = *S.prev_count;                                           // ---- part B
-  const uint32_t nthreads = (gridDim.x - kScatterBlocks) * blockDim.x;
+  const uint32_t nthreads = kStaleBlocks * blockDim.x;
   for (uint32_t base = (blockIdx.x - kScatterBlocks) * blockDim.x; base < n_prev; base += nthreads) {   // block-uniform: the ballots below need whole waves
     const uint32_t i = base + threadIdx.x;
     bool stale = false;
@@ -418,12 +428,17 @@ __global__ __launch_bounds__(kThreads, RR_K1_BOUNDS) void k_integrate_tiles_lds(
 }
 
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase) {
+                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc) {
   // phase 1: tile classification + stale-tile clear; phase 2: the integrate kernel; 0: both (the split lets the caller time the kernel alone)
   if (use_bricks) {
     if (phase != 2) {
       if (full_classify) hipLaunchKernelGGL(k_classify_clear_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
-      else hipLaunchKernelGGL(k_classify_lists, dim3(kScatterBlocks + 192), dim3(256), 0, st, V, B, S, frame_stamp);
+      else {
+        PeelClear none{};
+        const PeelClear& P = (pc && pc->peels) ? *pc : none;
+        const int extra = P.peels ? (P.n_tiles + 3) / 4 : 0;
+        hipLaunchKernelGGL(k_classify_lists, dim3(kScatterBlocks + kStaleBlocks + extra), dim3(256), 0, st, V, B, S, frame_stamp, P);
+      }
     }
     if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);

@@ -139,10 +139,11 @@ __global__ __launch_bounds__(64) void k_depth_limits(ViewParams P, Bricks B, uin
     }
   }
 }
-void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels, uint8_t* touched_cur, const uint8_t* touched_prev) {
+void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels, uint8_t* touched_cur, const uint8_t* touched_prev, int already_cleared) {
   const int n = P.w * P.h, ntx = (P.w + 7) / 8, n_tiles = ntx * ((P.h + 7) / 8);
   // touched_prev == nullptr: no tile history (first frame, resized view, ...): reset every peel
-  if (touched_prev) hipLaunchKernelGGL(k_clear_peel_tiles, dim3((n_tiles + 3) / 4), dim3(256), 0, st, (uint4*)peels, P.w, P.h, ntx, n_tiles, touched_prev);
+  if (touched_prev && already_cleared) { /* integrate()'s classify launch reset the touched tiles (k_classify_lists part C) */ }
+  else if (touched_prev) hipLaunchKernelGGL(k_clear_peel_tiles, dim3((n_tiles + 3) / 4), dim3(256), 0, st, (uint4*)peels, P.w, P.h, ntx, n_tiles, touched_prev);
   else hipLaunchKernelGGL(k_clear_peels, dim3((n + 255) / 256), dim3(256), 0, st, (uint4*)peels, n);
   const int grid = B.n < 8192 ? B.n : 8192;
   hipLaunchKernelGGL(k_depth_limits, dim3(grid), dim3(64), 0, st, P, B, (uint4*)peels, touched_cur, ntx);

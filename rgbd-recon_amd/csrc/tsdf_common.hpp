@@ -190,13 +190,16 @@ void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages&
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, uint32_t* next_count);
 // full_classify: 1 = walk every tile (first frame, after anything that may have left non-clear data outside the previous active
 // list); 0 = scatter from the occupied bricks + check the previous list only (work follows the scene, not the volume)
+// PeelClear: the peel-tile reset of the coming draw (k_raymarch.hip's k_clear_peel_tiles) rides along in the k_classify_lists launch
+struct PeelClear { uint4* peels; const uint8_t* touched_prev; int w, h, ntx, n_tiles; };   // peels == nullptr: nothing to do
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase = 0);
+                      int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr);
 int integrate_box_cap();
 void launch_mark_all_mixed(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
 void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* linear);
-void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels, uint8_t* touched_cur = nullptr, const uint8_t* touched_prev = nullptr);
+void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels, uint8_t* touched_cur = nullptr, const uint8_t* touched_prev = nullptr,
+                         int already_cleared = 0);
 struct LongRay { uint32_t pix, n, max_n; float prev; float x, y, z, pad; };   // state of a ray handed to k_march_long
 struct RayTarget {
   float4* color; float* depth; int stride; float* nsamples; const float4* peels; float clear[4];
