@@ -55,6 +55,9 @@ struct tsdf_ctx {
   uint32_t* d_occ_counts = nullptr; int occ_parity = 0;   // two occupied-brick counts used alternately (see Bricks::num_occupied)
   uint32_t min_voxels = 10;      // recon_integration.cpp:59
   size_t counter_words = 0;
+  // two counter buffers: while frame f uses one, integrate(f)'s classify launch zeroes the other (part D of k_classify_lists), and
+  // clearOccupiedBricks() of frame f + 1 is a pointer swap instead of a fill launch; spare_clean says whether that happened
+  uint32_t* d_counters[2]{}; int counters_cur = 0; bool spare_clean = false;
   uint32_t* h_num_occupied = nullptr;   // pinned
   // calibration + frame
   StreamTable luts{};
@@ -144,7 +147,8 @@ void release_view(tsdf_ctx* c) {
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
 void release_bricks(tsdf_ctx* c) {
-  hipFree(c->br.counters); hipFree(c->br.flags); hipFree(c->br.occupied);   // num_occupied and tiles.count live behind the counters
+  hipFree(c->d_counters[0]); hipFree(c->d_counters[1]); hipFree(c->br.flags); hipFree(c->br.occupied);
+  c->d_counters[0] = c->d_counters[1] = nullptr;
   c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr;
   for (int a = 0; a < 3; ++a) {
     hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); hipFree(c->d_tile_b0[a]); hipFree(c->d_tile_b1[a]);
@@ -282,13 +286,17 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
       uniform = count[a][v] == 1 && first[a][v] == first[a][v & ~7];
   c->tiles.uniform = uniform ? 1 : 0;
   c->counter_words = (((size_t)B.n + 3 + 63) / 64) * 64;      // padded: one aligned fill kernel; k_update_occupied reads whole quads
-  HIP_TRY(c, hipMalloc(&B.counters, c->counter_words * sizeof(uint32_t)));
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(c, hipMalloc(&c->d_counters[k], c->counter_words * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemset(c->d_counters[k], 0, c->counter_words * sizeof(uint32_t)));
+  }
+  c->counters_cur = 0; c->spare_clean = true;
+  B.counters = c->d_counters[0];
   if (!c->d_occ_counts) HIP_TRY(c, hipMalloc(&c->d_occ_counts, 2 * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_occ_counts, 0, 2 * sizeof(uint32_t)));      // a new grid: no occupied list yet
   B.num_occupied = c->d_occ_counts + c->occ_parity;
   HIP_TRY(c, hipMalloc(&B.flags, (size_t)B.n));
   HIP_TRY(c, hipMalloc(&B.occupied, (size_t)B.n * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemset(B.counters, 0, c->counter_words * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(B.flags, 0, (size_t)B.n));
   return TSDF_OK;
 }
@@ -797,7 +805,11 @@ int32_t tsdf_clear_bricks(tsdf_ctx* c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "bricks");
-  HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), c->stream));
+  if (c->spare_clean) {                                                  // the other buffer was zeroed by the last integrate(): swap
+    c->counters_cur ^= 1;
+    c->br.counters = c->d_counters[c->counters_cur];
+    c->spare_clean = false;
+  } else HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), c->stream));
   return TSDF_OK;
 }
 int32_t tsdf_mark_bricks(tsdf_ctx* c) {
@@ -856,6 +868,10 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
       pc.w = c->vw; pc.h = c->vh; pc.ntx = (c->vw + 7) / 8; pc.n_tiles = pc.ntx * ((c->vh + 7) / 8);
       c->peels_cleared = true;
     }
+  }
+  if (c->use_bricks && !c->full_classify && !c->spare_clean) {          // ... and zero the spare counter buffer for the next clearOccupiedBricks()
+    pc.zero = c->d_counters[c->counters_cur ^ 1]; pc.zero_words = (uint32_t)c->counter_words;
+    c->spare_clean = true;
   }
   launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
   timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)

@@ -117,11 +117,13 @@ __global__ __launch_bounds__(256) void k_classify_clear_tiles(Volume V, Bricks B
 constexpr int kScatterBlocks = 64;
 //   C  (optional) blocks past kScatterBlocks + kStaleBlocks: the peel tiles of the coming draw that the previous draw touched are
 //      reset here instead of in a launch of their own (k_clear_peel_tiles, k_raymarch.hip) -- independent work, same stream
-constexpr int kStaleBlocks = 192;
+//   D  (optional) kZeroBlocks blocks zero the spare brick-counter buffer: the next clearOccupiedBricks() is then a pointer swap
+constexpr int kStaleBlocks = 192, kZeroBlocks = 128;
 __global__ __launch_bounds__(256) void k_classify_lists(Volume V, Bricks B, TileState S, uint32_t frame, PeelClear PC) {
   const int lane = threadIdx.x & 63;
-  if (blockIdx.x >= kScatterBlocks + kStaleBlocks) {                                // ---- part C
-    const int t = (blockIdx.x - (kScatterBlocks + kStaleBlocks)) * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x >= kScatterBlocks + kStaleBlocks + kZeroBlocks) {                  // ---- part C
+    if (!PC.peels) return;
+    const int t = (blockIdx.x - (kScatterBlocks + kStaleBlocks + kZeroBlocks)) * 4 + (threadIdx.x >> 6);
     if (t >= PC.n_tiles || !PC.touched_prev[t]) return;
     const int px = (t % PC.ntx) * 8 + (lane & 7), py = (t / PC.ntx) * 8 + (lane >> 3);
     if (px < PC.w && py < PC.h) PC.peels[(size_t)py * PC.w + px] = make_uint4(__float_as_uint(1.0f), 0u, __float_as_uint(1.0f), 0u);   // clear (1,0,1,0)
@@ -145,6 +147,13 @@ __global__ __launch_bounds__(256) void k_classify_lists(Volume V, Bricks B, Tile
             if (V.slot) V.slot[stored_tile_index(V, tile)] = pos < V.pool_tiles ? pos : kNoSlot;
           }
     }
+    return;
+  }
+  if (blockIdx.x >= kScatterBlocks + kStaleBlocks) {                                // ---- part D: zero the spare brick counters
+    if (!PC.zero) return;
+    uint4* __restrict__ z = (uint4*)PC.zero;
+    const uint32_t quads = PC.zero_words >> 2;                                      // the buffer is padded to 64 words
+    for (uint32_t i = (blockIdx.x - (kScatterBlocks + kStaleBlocks)) * blockDim.x + threadIdx.x; i < quads; i += kZeroBlocks * blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
     return;
   }
   const uint32_t n_prev = *S.prev_count;                                           // ---- part B
@@ -435,9 +444,9 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
       if (full_classify) hipLaunchKernelGGL(k_classify_clear_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
       else {
         PeelClear none{};
-        const PeelClear& P = (pc && pc->peels) ? *pc : none;
+        const PeelClear& P = pc ? *pc : none;
         const int extra = P.peels ? (P.n_tiles + 3) / 4 : 0;
-        hipLaunchKernelGGL(k_classify_lists, dim3(kScatterBlocks + kStaleBlocks + extra), dim3(256), 0, st, V, B, S, frame_stamp, P);
+        hipLaunchKernelGGL(k_classify_lists, dim3(kScatterBlocks + kStaleBlocks + kZeroBlocks + extra), dim3(256), 0, st, V, B, S, frame_stamp, P);
       }
     }
     if (phase == 1) return;

@@ -191,7 +191,8 @@ void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels
 // full_classify: 1 = walk every tile (first frame, after anything that may have left non-clear data outside the previous active
 // list); 0 = scatter from the occupied bricks + check the previous list only (work follows the scene, not the volume)
 // PeelClear: the peel-tile reset of the coming draw (k_raymarch.hip's k_clear_peel_tiles) rides along in the k_classify_lists launch
-struct PeelClear { uint4* peels; const uint8_t* touched_prev; int w, h, ntx, n_tiles; };   // peels == nullptr: nothing to do
+// ... and so does the zeroing of the spare brick-counter buffer (`zero`, in 16-byte units of zero_words / 4)
+struct PeelClear { uint4* peels; const uint8_t* touched_prev; int w, h, ntx, n_tiles; uint32_t* zero; uint32_t zero_words; };   // null pointers: nothing to do
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
                       int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr);
 int integrate_box_cap();
