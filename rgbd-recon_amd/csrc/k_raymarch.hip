@@ -311,6 +311,9 @@ __device__ __forceinline__ uint32_t empty_run(const Volume& V, const uint32_t* p
 #ifndef RR_MARCH_BATCH
 #define RR_MARCH_BATCH 8
 #endif
+#ifndef RR_LONG_LANES
+#define RR_LONG_LANES 16
+#endif
 #ifndef RR_MARCH_BOUNDS
 #define RR_MARCH_BOUNDS 1
 #endif
@@ -506,8 +509,8 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   }
 }
 
-// Second pass of the march: EIGHT LANES per long ray, eight consecutive samples per lane (64 samples of a ray per round trip,
-// eight rays per wave).  Lane j starts 8j samples further along the ray; it gets there by performing the reference's own
+// Second pass of the march: kLanes (16) lanes per long ray, eight consecutive samples per lane (128 samples of a ray per round
+// trip, four rays per wave; with 8 lanes a 92-sample ray took two rounds: 64.7 -> 62.1 us for the whole draw stage).  Lane j starts 8j samples further along the ray; it gets there by performing the reference's own
 // chain of `pos += step` additions, so positions, densities, the first positive sample and the sample count are exactly
 // those of the one-at-a-time loop (:89-110).  A single lane walking a 92-sample ray issues ~14 k dependent instructions;
 // here the same ray is two rounds of ~1.4 k.
@@ -517,11 +520,12 @@ __device__ __forceinline__ void shade_hit(const ViewParams& P, const StreamTable
 template <bool kSparse>
 __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V, const RayTarget& R, const LongRay* __restrict__ longs,
                                            const uint32_t* __restrict__ long_count, uint32_t n_blocks, const StreamTable* T, const FrameImages* F) {
-  const int ln = threadIdx.x & 63, g = ln >> 3, j = ln & 7;
+  constexpr int kLanes = RR_LONG_LANES, kRays = 64 / kLanes;             // lanes per ray, rays per wave
+  const int ln = threadIdx.x & 63, g = ln / kLanes, j = ln % kLanes;
   const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = n_blocks * 4u;
   const uint32_t count = *long_count;
   const float sd = V.limit * 0.5f;
-  for (uint32_t r0 = wave * 8u; r0 < count; r0 += n_waves * 8u) {      // wave-uniform loop: the shuffles below need every lane
+  for (uint32_t r0 = wave * (uint32_t)kRays; r0 < count; r0 += n_waves * (uint32_t)kRays) {      // wave-uniform loop: the shuffles below need every lane
     const uint32_t r = r0 + (uint32_t)g;
     const bool live = r < count;
     LongRay L = longs[live ? r : r0];
@@ -560,28 +564,28 @@ __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V,
         }
       }
       // the ray's first hit is in the lowest lane of its group that found one
-      const uint32_t gm = (uint32_t)(__ballot(lhit && !done) >> (8 * g)) & 0xffu;
+      const uint32_t gm = (uint32_t)(__ballot(lhit && !done) >> (kLanes * g)) & ((1u << kLanes) - 1u);
       const float d7_before = __shfl(d[kBatch - 1], ln > 0 ? ln - 1 : 0);               // last sample of the lane one batch earlier
-      const int last = 8 * g + 7;
+      const int last = kLanes * g + kLanes - 1;
       const float d7_last = __shfl(d[kBatch - 1], last);
       const float3 p7_last = make_float3(__shfl(p[kBatch - 1].x, last), __shfl(p[kBatch - 1].y, last), __shfl(p[kBatch - 1].z, last));
       if (!done) {
         if (gm) {
           const int jw = __ffs((int)gm) - 1;
           // broadcast the winner's result to the group (every lane of the group keeps a copy; lane 0 writes it out)
-          const int src = 8 * g + jw;
+          const int src = kLanes * g + jw;
           const float wprev = lprev_set ? lprev : (j > 0 ? d7_before : prev);
           prev = __shfl(wprev, src);
           hit_pos = make_float3(__shfl(lhp.x, src), __shfl(lhp.y, src), __shfl(lhp.z, src));
           hit_d = __shfl(lhd, src);
           n += (uint32_t)(kBatch * jw) + __shfl(lk, src) + 1u;
           hit = true; done = true;
-        } else if (L.max_n - n <= (uint32_t)(8 * kBatch)) {
+        } else if (L.max_n - n <= (uint32_t)(kLanes * kBatch)) {
           n = L.max_n; done = true;
         } else {
           prev = d7_last;
           pos = make_float3(p7_last.x + step.x, p7_last.y + step.y, p7_last.z + step.z);
-          n += (uint32_t)(8 * kBatch);
+          n += (uint32_t)(kLanes * kBatch);
         }
       }
     }
