@@ -115,6 +115,15 @@ int32_t tsdf_draw_points(tsdf_ctx* ctx, const float modelview[16], const float p
 int32_t tsdf_set_min_length(tsdf_ctx* ctx, float min_length);
 int32_t tsdf_draw_trigrid(tsdf_ctx* ctx, const float modelview[16], const float projection[16]);
 
+/* ---- draw() host matrices.  Host only, no context, no GPU: the matrix block ReconIntegration::draw()
+ * builds before the raymarch -- vol_to_world = translate(bbox_min) * scale(bbox extent) (recon_integration.cpp:66-72),
+ * image_to_eye = inverse(scale(w/2, h/2, 1/2) * translate(1,1,1) * projection) (:182-193), NormalMatrix =
+ * inverseTranspose(modelview * vol_to_world) (:199), CameraPos in volume space (:202-205) -- exactly the values the draw
+ * calls hand to the kernels (formed in double, rounded to fp32 once).  out: 16 + 16 + 16 + 3 floats, column major.
+ * Returns TSDF_ERR_INVALID_ARGUMENT for a singular modelview / projection. */
+int32_t tsdf_view_matrices(const float modelview[16], const float projection[16], uint32_t view_w, uint32_t view_h,
+                           const float bbox_min[3], const float bbox_max[3], float out[51]);
+
 /* ---- inverse calibration volumes: the offline tool source/calib_inverter.cpp.
  * tsdf_frustum_from_volume: kinect::Frustum built from the 8 corner texels of a forward volume (getCornerPoints,
  *   calibration_inverter.cpp:117-133; planes + inside(): frustum.cpp) -> planes[6][4] (near far left right top bottom,

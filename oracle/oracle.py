@@ -245,9 +245,15 @@ class OracleRecon:
         return off, res
 
     def view_matrices(self, mv, proj):
-        out = np.zeros(35, np.float32)
+        """(image_to_eye, NormalMatrix, CameraPos) of draw(), recon_integration.cpp:182-205."""
+        m = self.view_matrices_all(mv, proj)
+        return m["image_to_eye"], m["normal_matrix"], m["camera_pos"]
+
+    def view_matrices_all(self, mv, proj):
+        """The whole matrix block of draw() (+ vol_to_world, :66-72) -> dict like rgbd_recon_amd.view_matrices."""
+        out = np.zeros(51, np.float32)
         self._L.orc_view_matrices(self._c, _p(_f32(mv)), _p(_f32(proj)), _p(out))
-        return out[:16].copy(), out[16:32].copy(), out[32:35].copy()
+        return {"vol_to_world": out[:16].copy(), "image_to_eye": out[16:32].copy(), "normal_matrix": out[32:48].copy(), "camera_pos": out[48:].copy()}
 
 
 # --- frame ingest helpers

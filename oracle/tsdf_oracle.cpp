@@ -13,6 +13,8 @@
 //   * orc_decode_dxt                      == external/squish DecompressImage   (tests/test_oracle_ingest.py)
 //   * the .stream record layout           == framework/io/FileBuffer           (tests/test_oracle_ingest.py)
 //   * (product side) .cv_* volume files   == calibration_volume.hpp read/write (tests/test_calib_io.py)
+//   * make_view / orc_view_matrices       == draw()'s matrix block on external/gloost Matrix + vendored glm, to 1e-6 of each
+//                                            matrix's largest element (tests/test_view_math.py; the product's tsdf_view_matrices too)
 // Everything else below -- TSDF path, pre-processing, inverse-LUT builder (CGAL absent), point / triangle-grid back-ends --
 // is restated, not run.
 //
@@ -1066,9 +1068,12 @@ void orc_get_preprocessed(orc_ctx* c, float* depth2, float* depth_rg, float* lab
 void orc_tex3d(const float* t, int nc, const uint32_t* res, float u, float v, float w, float* out) { tex3d(t, nc, res, u, v, w, out); }
 void orc_tex2d_linear(const float* t, int nc, int w, int h, int layer, float u, float v, float* out) { tex2d_linear(t, nc, w, h, layer, u, v, out); }
 float orc_tex2d_nearest(const float* t, int nc, int w, int h, int layer, float u, float v, int ch) { return tex2d_nearest(t, nc, w, h, layer, u, v, ch); }
-void orc_view_matrices(orc_ctx* c, const float* mv, const float* proj, float* out /* img_to_eye, normal, cam_vol(3) */) {
+// The matrix block of draw() alone (also cross-checked against the reference's own gloost/glm, oracle/ref/ref_view_math.cpp):
+// vol_to_world[16], image_to_eye[16], NormalMatrix[16], CameraPos[3].
+void orc_view_matrices(orc_ctx* c, const float* mv, const float* proj, float* out51) {
   view_mats V = make_view(c, mv, proj);
-  memcpy(out, V.img_to_eye.m, 64); memcpy(out + 16, V.normal.m, 64); out[32] = V.cam_vol.x; out[33] = V.cam_vol.y; out[34] = V.cam_vol.z;
+  memcpy(out51, V.v2w.m, 64); memcpy(out51 + 16, V.img_to_eye.m, 64); memcpy(out51 + 32, V.normal.m, 64);
+  out51[48] = V.cam_vol.x; out51[49] = V.cam_vol.y; out51[50] = V.cam_vol.z;
 }
 
 

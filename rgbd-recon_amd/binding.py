@@ -102,6 +102,18 @@ def write_calib_volume(path, kind, volume, depth_limits):
         raise TsdfError(-1, L.tsdf_calib_last_error().decode())
 
 
+# ---------------------------------------------------------------------- draw() host matrices (recon_integration.cpp:66-72,182-205)
+def view_matrices(mv, proj, view, bbox_min, bbox_max):
+    """-> dict(vol_to_world [16], image_to_eye [16], normal_matrix [16], camera_pos [3]), column major; host only (no GPU)."""
+    L = load_library()
+    out = np.zeros(51, np.float32)
+    rc = L.tsdf_view_matrices(_fp(_f32(mv).reshape(-1)), _fp(_f32(proj).reshape(-1)), C.c_uint32(int(view[0])), C.c_uint32(int(view[1])),
+                              _fp(_f32(bbox_min)), _fp(_f32(bbox_max)), _fp(out))
+    if rc != 0:
+        raise TsdfError(rc, "singular modelview / projection matrix")
+    return {"vol_to_world": out[:16].copy(), "image_to_eye": out[16:32].copy(), "normal_matrix": out[32:48].copy(), "camera_pos": out[48:].copy()}
+
+
 # ---------------------------------------------------------------------- inverse calibration volumes (source/calib_inverter.cpp)
 def frustum_from_volume(cv_xyz):
     """cv_xyz [rz][ry][rx][3] -> (planes [6][4], camera position): kinect::Frustum of the volume's corner texels (host only)."""

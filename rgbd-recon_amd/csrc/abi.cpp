@@ -323,21 +323,23 @@ void timer_end(tsdf_ctx* c, const char* name) {
 }
 
 // draw() matrix block, recon_integration.cpp:182-205 (+ vol_to_world :66-72)
-bool make_view_params(const tsdf_ctx* c, const float* mv16, const float* pr16, ViewParams* P) {
+// The matrices alone (no context): shared by make_view_params and the host-only tsdf_view_matrices.
+bool view_matrices(const float* bbox_min, const float* bbox_max, int vw, int vh, const float* mv16, const float* pr16, ViewParams* P, Mat4* v2w_out) {
   double mv[16], pr[16], v2w[16] = {0}, sc[16] = {0}, tr[16] = {0}, t0[16], t1[16];
   for (int i = 0; i < 16; ++i) { mv[i] = mv16[i]; pr[i] = pr16[i]; }
   for (int a = 0; a < 3; ++a) {
-    v2w[a * 5] = (double)(c->cfg.bbox_max[a] - c->cfg.bbox_min[a]);    // float subtraction like :66-68
-    v2w[12 + a] = c->cfg.bbox_min[a];
+    v2w[a * 5] = (double)(bbox_max[a] - bbox_min[a]);    // float subtraction like :66-68
+    v2w[12 + a] = bbox_min[a];
   }
   v2w[15] = 1.0;
+  if (v2w_out) *v2w_out = to_mat4(v2w);
   memcpy(P->mv.m, mv16, 64); memcpy(P->proj.m, pr16, 64);
   if (!mat_inv_d(v2w, t0)) return false;
   P->v2w_inv = to_mat4(t0);
   double mvi[16];
   if (!mat_inv_d(mv, mvi)) return false;
   P->mv_inv = to_mat4(mvi);
-  sc[0] = c->vw * 0.5; sc[5] = c->vh * 0.5; sc[10] = 0.5; sc[15] = 1.0;                  // :187-191
+  sc[0] = vw * 0.5; sc[5] = vh * 0.5; sc[10] = 0.5; sc[15] = 1.0;                        // :187-191
   tr[0] = tr[5] = tr[10] = tr[15] = 1.0; tr[12] = tr[13] = tr[14] = 1.0;                 // :184-186
   mat_mul_d(tr, pr, t0); mat_mul_d(sc, t0, t1);
   if (!mat_inv_d(t1, t0)) return false;
@@ -357,6 +359,11 @@ bool make_view_params(const tsdf_ctx* c, const float* mv16, const float* pr16, V
   for (int a = 0; a < 3; ++a) P->cam_world[a] = cw[a];
   const Mat4& W = P->v2w_inv;
   for (int r = 0; r < 3; ++r) P->cam_vol[r] = W.m[r] * cw[0] + W.m[4 + r] * cw[1] + W.m[8 + r] * cw[2] + W.m[12 + r] * cw[3];
+  return true;
+}
+
+bool make_view_params(const tsdf_ctx* c, const float* mv16, const float* pr16, ViewParams* P) {
+  if (!view_matrices(c->cfg.bbox_min, c->cfg.bbox_max, c->vw, c->vh, mv16, pr16, P, nullptr)) return false;
   P->w = c->vw; P->h = c->vh;
   P->shade_mode = c->shade_mode;
   P->skip = (c->skip_space && c->use_bricks) ? 1 : 0;                                     // :154, :510-513
@@ -936,6 +943,16 @@ int32_t tsdf_upload_normals(tsdf_ctx* c, const float* normals_rgb) {
   HIP_TRY(c, hipMemcpy(c->d_normal, padded.data(), np * sizeof(float4), hipMemcpyHostToDevice));
   return TSDF_OK;
 }
+int32_t tsdf_view_matrices(const float* mv, const float* pr, uint32_t vw, uint32_t vh, const float* bbox_min, const float* bbox_max, float* out) {
+  if (!mv || !pr || !bbox_min || !bbox_max || !out || !vw || !vh) return TSDF_ERR_INVALID_ARGUMENT;
+  ViewParams P;
+  Mat4 v2w;
+  if (!view_matrices(bbox_min, bbox_max, (int)vw, (int)vh, mv, pr, &P, &v2w)) return TSDF_ERR_INVALID_ARGUMENT;
+  memcpy(out, v2w.m, 64); memcpy(out + 16, P.img_to_eye.m, 64); memcpy(out + 32, P.normal.m, 64);
+  for (int a = 0; a < 3; ++a) out[48 + a] = P.cam_vol[a];
+  return TSDF_OK;
+}
+
 int32_t tsdf_draw_points(tsdf_ctx* c, const float* mv, const float* pr) {
   CHECK_CTX(c);
   if (!mv || !pr) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "null matrix");
