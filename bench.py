@@ -137,6 +137,12 @@ def main():
     if "RR_BENCH_DEVICE" in os.environ:
         local = int(os.environ["RR_BENCH_DEVICE"])
     torch.cuda.set_device(local)
+    # RR_BENCH_EXCHANGE_ALONE=1 (rehearsal, never set by the driver): one rank runs the whole slab exchange -- pack, RCCL
+    # collectives of a world of one, composite -- so that the cost of the collective path itself can be read on a 1-GPU box
+    alone = world == 1 and os.environ.get("RR_BENCH_EXCHANGE_ALONE") == "1"
+    if alone:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -149,7 +155,7 @@ def main():
     ext = scene["bbox_max"] - scene["bbox_min"]
     brick = [float(ext[a]) / cfg["res"][a] * 8 for a in range(3)]          # 8^3 voxels per brick
     frames_mode = world > 1 and args.parallel == "frames"
-    slab = mg.slab_range(cfg["res"][2], rank, world) if (world > 1 and not frames_mode) else (0, 0)
+    slab = mg.slab_range(cfg["res"][2], rank, world) if ((world > 1 and not frames_mode) or alone) else (0, 0)
     hip = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, slab=slab,
                                  recompute_halo=(args.halo == "recompute"), sparse_pool_tiles=args.sparse_pool)
     hip.setUseBricks(cfg["use_bricks"]); hip.setSpaceSkip(cfg["skip_space"]); hip.setColorFilling(cfg["fill_holes"])
@@ -158,7 +164,7 @@ def main():
     if args.preprocess:
         hip.upload_raw_frame(scene)
     drv = mg.SlabDriver(hip, 0 if frames_mode else rank, 1 if frames_mode else world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite,
-                        preprocess=args.preprocess)
+                        preprocess=args.preprocess, exchange_when_alone=alone)
     mv, pr = rr.scene.default_view(*VIEW)
     # extra frame slots (throughput mode): independent contexts on their own streams, fed round robin in the timed loop
     slots = [drv]
@@ -269,7 +275,7 @@ def main():
                    "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
                    "frames_in_flight": args.frames_in_flight,
                    "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
-                   "parallelism": "single GPU" if world == 1 else (f"{world} GPUs, each fusing its own frames (no exchange)" if frames_mode else
+                   "parallelism": ("single GPU, slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else (f"{world} GPUs, each fusing its own frames (no exchange)" if frames_mode else
                                                                     f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0")},
         "stage_ms": stages,
         "frame_device_ms": frame_ms,

@@ -45,15 +45,19 @@ class SlabDriver:
                created with recompute_halo); "recompute": the backend integrates its own halo layers, no collective.
     composite  "dense": every rank ships 24 B per view pixel to rank 0; "compact": one 32-byte record per ray that hit in
                the slab (the counts travel first so that only max(count) records per rank are gathered).
+    exchange_when_alone   world == 1 normally draws the frame directly; True runs the whole exchange (pack, collectives, composite)
+               with the one rank anyway -- used to drive the RCCL calls on a box with a single GPU.
     """
 
-    def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense", preprocess=False):
+    def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense", preprocess=False,
+                 exchange_when_alone=False):
         assert halo in ("exchange", "recompute") and composite in ("dense", "compact")
         self.b, self.rank, self.world, self.dev, self.group = backend, rank, world, torch.device(buf_device), group
         self.view, self.halo, self.composite = view, halo, composite
         self.preprocess = preprocess          # frames start from the raw sensor images: processTextures() instead of markBricks()
-        self.stage_cpu = world > 1 and dist.get_backend(group) == "gloo" and self.dev.type == "cuda"
-        if world > 1:
+        self.exchanging = world > 1 or exchange_when_alone
+        self.stage_cpu = self.exchanging and dist.get_backend(group) == "gloo" and self.dev.type == "cuda"
+        if self.exchanging:
             npx = view[0] * view[1]
             if halo == "exchange":
                 layers, nbytes = backend.halo_info()
@@ -105,7 +109,7 @@ class SlabDriver:
             b.markBricks()
         b.updateOccupiedBricks(False)
         b.integrate()
-        if self.world == 1:
+        if not self.exchanging:
             b.drawF(mv, proj)
             return
         if self.halo == "exchange":

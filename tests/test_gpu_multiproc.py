@@ -62,3 +62,54 @@ def test_two_rank_slab_driver_matches_single_context(halo, composite):
         p.join(900)
         assert p.exitcode == 0
     assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
+def _rccl_alone(port, q, halo, composite):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import rgbd_recon_amd as rr
+    mgpu = import_module("rgbd-recon_amd.multigpu")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))      # exactly bench.py's call
+    try:
+        scene = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
+        mv, pr = rr.scene.default_view(*KW["view"])
+        hip = rr.ReconIntegrationHip(scene, slab=mgpu.slab_range(KW["res"][2], 0, 1), recompute_halo=(halo == "recompute"), **KW)
+        hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        drv = mgpu.SlabDriver(hip, 0, 1, "cuda:0", view=KW["view"], halo=halo, composite=composite, exchange_when_alone=True)
+        for _ in range(3):
+            drv.frame(mv, pr)
+        dist.barrier()
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")                          # bench.py's max-over-ranks reduction
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        whole = rr.ReconIntegrationHip(scene, **KW)
+        whole.clearOccupiedBricks(); whole.markBricks(); whole.updateOccupiedBricks()
+        whole.integrate(); whole.drawF(mv, pr)
+        (wc, wdd), (sc, sdd) = whole.framebuffer(), hip.framebuffer()
+        ok = bool((sdd == wdd).all()) and bool(((sc == wc) | (np.isnan(sc) & np.isnan(wc))).all()) and int((wdd < 1).sum()) > 300
+        ok &= float(t.item()) == 1.5
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("halo,composite", [("exchange", "dense"), ("recompute", "compact")])
+def test_slab_exchange_over_rccl_with_one_rank(halo, composite):
+    """The collectives of the slab driver through RCCL itself (backend "nccl"), as far as one GPU allows: a world of one rank
+    runs pack -> all_gather_into_tensor -> unpack, partial march, export -> (counts all-gather +) gather -> composite, with the
+    same tensor views, dtypes and stream as N ranks would.  (Two ranks on one device are refused by RCCL; the two-rank
+    tests above use gloo.)"""
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_alone, args=(port, q, halo, composite))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) is True
