@@ -118,6 +118,13 @@ def main():
     if args.ingest:
         args.preprocess = True
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner from inside
+    # communicator creation on rank 0), so file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to
+    # the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch                      # first: the HIP runtime torch bundles is the one the library binds to
     import torch.distributed as dist
@@ -334,8 +341,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, cfg, limit, brick)
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or alone:
         dist.destroy_process_group()
 
 
