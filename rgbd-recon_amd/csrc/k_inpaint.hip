@@ -73,16 +73,21 @@ __device__ __forceinline__ void inpaint_pixel(const Atlas& A, int w, int lod, in
   float depth_av = 0.0f;
   int num = 0;
   float4 smp[16];
+  // the shader visits the window x-outer / y-inner (:43-44) and stores tap (x, y) at x + 4 y (:55): depth_av is summed in
+  // THAT order, the totals below in index order -- fp32 sums, so the two orders are part of the result
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float4 c = tc[i];
-    float d = td_[i];
-    if (ta[i].cls == 1) { c = make_float4(0.0f, 1.0f, 0.0f, 0.0f); d = 1.0f; }   // ViewLod::enable clear, view_lod.cpp:75-81
-    if (ta[i].cls == 0) { c = make_float4(0.0f, 0.0f, 0.0f, 0.0f); d = 0.0f; }
-    if (c.w <= 0.0f) c.x = -1.0f;
-    else { depth_av += d; ++num; }
-    smp[i] = make_float4(c.x, c.y, c.z, d);
-  }
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int i = x + y * 4;
+      float4 c = tc[i];
+      float d = td_[i];
+      if (ta[i].cls == 1) { c = make_float4(0.0f, 1.0f, 0.0f, 0.0f); d = 1.0f; }   // ViewLod::enable clear, view_lod.cpp:75-81
+      if (ta[i].cls == 0) { c = make_float4(0.0f, 0.0f, 0.0f, 0.0f); d = 0.0f; }
+      if (c.w <= 0.0f) c.x = -1.0f;
+      else { depth_av += d; ++num; }
+      smp[i] = make_float4(c.x, c.y, c.z, d);
+    }
   const size_t o = (size_t)fy * A.aw + fx;
   if (num == 0) {                                                                                      // :59-68
     const float d = smp[1 + 1 * 4].w;                     // the centre tap (pxi, pyi)

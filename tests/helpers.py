@@ -35,3 +35,41 @@ def tsdf_close(a, b, limit, rtol=1e-3):
     """north_star tolerance: |a-b| <= 1e-3 * max(|a|, |b|, limit); NaN equals NaN."""
     with np.errstate(invalid="ignore"):
         return (np.abs(a - b) <= rtol * np.maximum(np.maximum(np.abs(a), np.abs(b)), limit)) | (np.isnan(a) & np.isnan(b))
+
+
+def same(a, b):
+    """bit-for-bit equality of float arrays, NaN equal to NaN (the HIP path restates the oracle's fp32 operation order)."""
+    a, b = np.asarray(a), np.asarray(b)
+    with np.errstate(invalid="ignore"):
+        return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+def assert_same(a, b, what=""):
+    m = same(a, b)
+    if not m.all():
+        with np.errstate(invalid="ignore"):
+            d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))[~m]
+        raise AssertionError(f"{what}: {int((~m).sum())} of {m.size} values differ (largest difference {np.nanmax(d) if d.size else 0:.3g})")
+
+
+def assert_close_abs(a, b, atol, what=""):
+    with np.errstate(invalid="ignore"):
+        m = (np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)) <= atol) | same(a, b)
+    assert m.all(), f"{what}: {int((~m).sum())} of {m.size} values differ by more than {atol}"
+
+
+POW_ATOL = 1e-6      # shade mode 1 (shading.glsl:32-69) goes through pow(): glibc powf on the CPU, the device library's on the GPU (<= 1 ulp apart)
+
+
+def assert_frames_identical(hip, orc, what="", min_hits=1, colour_atol=0.0):
+    """the rendered frame of both sides (after drawF): framebuffer colour and depth, every value (colour_atol only for a shade
+    mode that calls pow())"""
+    (fc, fd), (gc, gd) = hip.framebuffer(), orc.framebuffer()
+    assert_same(fd, gd, f"{what} framebuffer depth")
+    if colour_atol:
+        assert_close_abs(fc, gc, colour_atol, f"{what} framebuffer colour")
+    else:
+        assert_same(fc, gc, f"{what} framebuffer colour")
+    n = int((fd < 1).sum())
+    assert n >= min_hits, f"{what}: only {n} covered pixels"
+    return n

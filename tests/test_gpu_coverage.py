@@ -4,7 +4,7 @@ and a sequence of different frames (the tile bookkeeping must reset tiles that s
 import numpy as np
 import pytest
 
-from helpers import tsdf_close
+from helpers import assert_frames_identical, assert_same
 from oracle.oracle import OracleRecon
 
 pytestmark = pytest.mark.gpu
@@ -21,15 +21,8 @@ def frame(o, mv, pr):
 
 
 def compare(hip, orc, limit=LIMIT):
-    a, b = hip.tsdf(), orc.tsdf()
-    assert tsdf_close(a, b, limit).all()
-    (fc, fd), (gc, gd) = hip.framebuffer(), orc.framebuffer()
-    assert ((fd < 1) != (gd < 1)).mean() <= 2e-3
-    both = (fd < 1) & (gd < 1)
-    assert (np.abs(fd[both] - gd[both]) > 1e-4).mean() <= 2e-3
-    with np.errstate(invalid="ignore"):
-        assert (np.abs(fc[both] - gc[both]) > 2e-3).mean() <= 1e-2
-    return both.sum()
+    assert_same(hip.tsdf(), orc.tsdf(), "tsdf")
+    return assert_frames_identical(hip, orc)
 
 
 @pytest.mark.parametrize("n_streams", [1, 8])
@@ -49,7 +42,7 @@ def test_lut_finer_than_volume_takes_the_global_path(rr):
     for o in (hip, orc):
         o.setUseBricks(False)
         o.integrate()
-    assert tsdf_close(hip.tsdf(), orc.tsdf(), 0.08).all()
+    assert_same(hip.tsdf(), orc.tsdf(), "tsdf (global-memory integrate)")
 
 
 def test_setters_between_frames(rr, small_scene):
