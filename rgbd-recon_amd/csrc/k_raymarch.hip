@@ -646,8 +646,11 @@ __device__ __forceinline__ void shade_list(const ViewParams& P, const StreamTabl
   const uint32_t n_hits = *hit_count;
   for (uint32_t i = b * blockDim.x + threadIdx.x; i < n_hits; i += nb * blockDim.x) shade_hit<kSparse>(P, T, F, V, R, hits[i]);
 }
+#ifndef RR_SHADE_BOUNDS
+#define RR_SHADE_BOUNDS 1
+#endif
 template <bool kSparse>
-__global__ __launch_bounds__(256) void k_shade(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
+__global__ __launch_bounds__(256, RR_SHADE_BOUNDS) void k_shade(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
                                                const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count) {
   shade_list<kSparse>(P, T, F, V, R, hits, hit_count, next_count, 0u);
 }
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(256) void k_shade(ViewParams P, StreamTable T, Fram
 // ramp) and overlaps two latency-bound kernels: 15 + 19 us -> ~21 us.
 constexpr uint32_t kLongBlocks = 512;
 template <bool kSparse>
-__global__ __launch_bounds__(256) void k_shade_and_long(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
+__global__ __launch_bounds__(256, RR_SHADE_BOUNDS) void k_shade_and_long(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
                                                         const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count,
                                                         const LongRay* __restrict__ longs, const uint32_t* __restrict__ long_count) {
   if (blockIdx.x < kLongBlocks) march_long<kSparse>(P, V, R, longs, long_count, kLongBlocks, &T, &F);
