@@ -7,8 +7,12 @@
 A "step" is one frame of the reference's per-frame call order (source/kinect_client.cpp:569-599,614):
 clearOccupiedBricks -> mark_brick (K6) -> updateOccupiedBricks -> integrate (K0+K1) -> drawF
 (K5 depth limits, K2 raymarch, K3/K4 hole filling), with the frame images already resident in HBM.
-N > 1 slab-partitions the SAME volume over the ranks (strong scaling) with an RCCL halo all-gather
-before the raymarch and a nearest-hit gather of the partial images (rgbd-recon_amd/multigpu.py).
+N > 1, --parallel auto (default): the reference rebuilds the volume from scratch every frame, so frames are independent
+units -- when the volume fits one GPU (every BASELINE configuration does) the ranks each fuse their own frames of the stream,
+no data-path collective, weak scaling; a volume that does not fit one GPU is Z-slab partitioned instead.  --parallel slabs
+forces the north-star partition: the SAME volume split into Z-slabs over the ranks (strong scaling), halo layers recomputed
+or RCCL all-gathered before the raymarch, nearest-hit gather of the partial images (rgbd-recon_amd/multigpu.py; DESIGN.md
+section 6 has the measured cost floor of that exchange against the 0.22 ms frame).
 
 Prints ONE JSON line on rank 0.
 """
@@ -96,10 +100,10 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"], help="N > 1: integrate the halo layers locally, or RCCL all-gather them")
     ap.add_argument("--composite", default="compact", choices=["compact", "dense"], help="N > 1: gather hit records, or whole partial images")
-    ap.add_argument("--parallel", default="slabs", choices=["slabs", "frames"],
-                    help="N > 1: 'slabs' = ONE volume split into Z-slabs with the RCCL exchange (the north-star partition, strong scaling); "
-                         "'frames' = every GPU fuses its own frames of the stream (each frame rebuilds the volume from scratch, so frames are "
-                         "independent: no exchange at all, weak scaling)")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "slabs", "frames"],
+                    help="N > 1: 'frames' = every GPU fuses its own frames of the stream (each frame rebuilds the volume from scratch, so frames "
+                         "are independent: no exchange at all, weak scaling); 'slabs' = ONE volume split into Z-slabs with the RCCL exchange "
+                         "(the north-star partition, strong scaling); 'auto' = frames while the dense volume fits half of one GPU's HBM, else slabs")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3, 4],
                     help="single GPU: process this many frames concurrently, one context + HIP stream per slot (every frame rebuilds the "
                          "volume from scratch, so frames are independent and the frame's 17 small latency-bound kernels overlap well). "
@@ -161,6 +165,11 @@ def main():
     scene = rr.scene.make_scene(n_streams=cfg["streams"], width=640, height=480, lut_res=LUT, inv_res=LUT)
     ext = scene["bbox_max"] - scene["bbox_min"]
     brick = [float(ext[a]) / cfg["res"][a] * 8 for a in range(3)]          # 8^3 voxels per brick
+    if alone:
+        args.parallel = "slabs"
+    if args.parallel == "auto":                # 4 B per voxel against half of the 288 GB of one MI355X: every BASELINE configuration -> frames
+        fits = 4 * cfg["res"][0] * cfg["res"][1] * cfg["res"][2] <= 144e9
+        args.parallel = "frames" if fits else "slabs"
     frames_mode = world > 1 and args.parallel == "frames"
     slab = mg.slab_range(cfg["res"][2], rank, world) if ((world > 1 and not frames_mode) or alone) else (0, 0)
     hip = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, slab=slab,
@@ -276,13 +285,13 @@ def main():
     out = {
         "metric": "frames/sec (integrate+raymarch) at %d^3 x %d streams" % (cfg["res"][0], cfg["streams"]),
         "value": (world if frames_mode else 1) * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if frames_mode else "strong", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.parallel == "frames" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "config": args.config, "streams": cfg["streams"], "res": list(cfg["res"]),
                    "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
                    "frames_in_flight": args.frames_in_flight,
                    "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
-                   "parallelism": ("single GPU, slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else (f"{world} GPUs, each fusing its own frames (no exchange)" if frames_mode else
+                   "parallelism": ("single GPU, slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else (f"{world} GPUs, frame-parallel: each rank fuses its own frames of the stream, no data-path collective (--parallel slabs = Z-slab partition of one volume)" if frames_mode else
                                                                     f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0")},
         "stage_ms": stages,
         "frame_device_ms": frame_ms,
