@@ -37,7 +37,6 @@ struct tsdf_ctx {
   Volume vol{};
   TileState tiles{};
   uint8_t* d_cls_all = nullptr;      // tile class of every stored tile (owned + halo)
-  uint32_t* d_pyr = nullptr;
   int halo_layers = 0;
   // bricks
   float brick_req[3]{};          // requested size (setBrickSize argument)
@@ -468,22 +467,6 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if ((rc = tryhip(hipMalloc(&c->d_cls_all, (size_t)V.n_stored_tiles), "hipMalloc(tiles)"))) return fail(rc);
   hipMemsetAsync(c->d_cls_all, kTileMixed, (size_t)V.n_stored_tiles, c->stream);   // halo layers keep this value for good
   V.cls = c->d_cls_all;
-  {                                               // empty-space pyramid: levels 1..4 = cells of 2, 4, 8, 16 tiles
-    int words = 0;
-    for (int l = 1; l <= 4; ++l) {
-      V.pyr_off[l] = words;
-      int cells = 1;
-      for (int a = 0; a < 3; ++a) { V.pyr_n[l][a] = (((c->res[a] + 7) / 8) + (1 << l) - 1) >> l; cells *= V.pyr_n[l][a]; }
-      words += (cells + 31) / 32;
-    }
-    V.pyr_off[0] = words;
-    V.pyr = nullptr;
-    if (kUseSkip) {                               // the experiment switch of tsdf_common.hpp; off in the shipped build
-      if (words * 4 > 60 * 1024) { c->err = "volume too large for the raymarch's LDS empty-space pyramid"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
-      if ((rc = tryhip(hipMalloc(&c->d_pyr, (size_t)words * sizeof(uint32_t)), "hipMalloc(pyramid)"))) return fail(rc);
-      V.pyr = c->d_pyr;
-    }
-  }
   S.cls = c->d_cls_all + (size_t)(V.int_tz0 - V.tz0) * V.nty * V.ntx;
   for (int k = 0; k < 2; ++k)
     if ((rc = tryhip(hipMalloc(&c->d_tile_list[k], (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
@@ -520,7 +503,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   release_view(c); release_bricks(c);
-  hipFree(c->tiles.stamp); hipFree(c->d_cls_all); hipFree(c->d_pyr); hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts);
+  hipFree(c->tiles.stamp); hipFree(c->d_cls_all); hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts);
   hipFree(c->vol.data); hipFree(c->vol.slot); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
   hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal);
   hipFree(c->d_depth_plane); hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);

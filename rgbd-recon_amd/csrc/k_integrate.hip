@@ -201,17 +201,6 @@ __device__ __forceinline__ int work_tile(const TileState& S, int w) {
   return ((S.n & 7) == 0) ? (w & 7) * (S.n >> 3) + (w >> 3) : w;
 }
 
-// Class of the tile a workgroup has just produced: thread-local "all my real voxels are -limit / +limit" bits are
-// AND-ed per wave and across the four waves through one LDS word (padding voxels past the volume never get sampled
-// and do not count).  Call with s_flag preset to 3 and a barrier between the preset and the first call.
-__device__ __forceinline__ void tile_class_vote(int* s_flag, bool in0, float v0, bool in1, float v1, float limit) {
-  const bool neg = (!in0 || v0 == -limit) && (!in1 || v1 == -limit);
-  const bool pos = (!in0 || v0 == limit) && (!in1 || v1 == limit);
-  const int m = (__all(neg) ? 1 : 0) | (__all(pos) ? 2 : 0);
-  if ((threadIdx.x & 63) == 0) atomicAnd(s_flag, m);
-}
-__device__ __forceinline__ uint8_t tile_class_from(int f) { return (f & 1) ? kTileMinus : ((f & 2) ? kTilePlus : kTileMixed); }
-
 // Generic path: every tap straight from global memory.  Used when a tile's LUT neighbourhood does not fit
 // the LDS budget (inverse LUT much finer than the TSDF).
 template <bool kList>
@@ -220,16 +209,12 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
   if (kList && blockIdx.x == 0 && threadIdx.x == 0) *S.next_count = 0u;              // the previous list was consumed by the classify launch
-  __shared__ int s_flag;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int tile = work_tile<kList>(S, w);
     int tx, ty, tz;
     tile_coords(V, tile, tx, ty, tz);
     if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
     float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx) << 9);
-    __syncthreads();
-    if (threadIdx.x == 0) s_flag = 3;
-    __syncthreads();
     float v[2];
     bool in[2];
 #pragma unroll
@@ -243,13 +228,7 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
       if (drawn) v[half] = integrate_voxel(T, F, limit, ((float)x + 0.5f) * sx, ((float)y + 0.5f) * sy, ((float)z + 0.5f) * sz);
       out[l] = v[half];
     }
-    if (kUseSkip) {
-      tile_class_vote(&s_flag, in[0], v[0], in[1], v[1], limit);
-      __syncthreads();
-      if (threadIdx.x == 0) S.cls[tile] = tile_class_from(s_flag);
-    } else if (threadIdx.x == 0) {
-      S.cls[tile] = kTileMixed;
-    }
+    if (threadIdx.x == 0) S.cls[tile] = kTileMixed;
   }
 }
 
@@ -296,7 +275,6 @@ __global__ __launch_bounds__(kThreads, RR_K1_BOUNDS) void k_integrate_tiles_lds(
   __shared__ float4 s_row[kChunk][kRowCap];     // x-pass results
   __shared__ int s_i0[kChunk][3][8], s_i1[kChunk][3][8];
   __shared__ float s_w[kChunk][3][8];
-  __shared__ int s_flag;
   const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
@@ -309,17 +287,15 @@ __global__ __launch_bounds__(kThreads, RR_K1_BOUNDS) void k_integrate_tiles_lds(
     if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
     float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
     constexpr int kVox = 512 / kThreads, kZStep = kThreads / 64;        // voxels per thread; their z spacing
-    static_assert(!kUseSkip || kThreads == 256, "the tile class vote of the skip experiment assumes two voxels per thread");
     // the voxels of this thread share x and y
     const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
-    bool drawn[kVox], inres[kVox];
+    bool drawn[kVox];
     float tsd[kVox], wsum[kVox];
-    if (tid == 0) s_flag = 3;                                           // ordered before the vote by the chunk barriers
 #pragma unroll
     for (int h = 0; h < kVox; ++h) {
       const int z = t3[2] * 8 + lz + kZStep * h;
-      drawn[h] = inres[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      drawn[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
       if (drawn[h] && per_voxel_check) drawn[h] = voxel_drawn(B, x, y, z);
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
       wsum[h] = 0.0f;
@@ -420,19 +396,9 @@ __global__ __launch_bounds__(kThreads, RR_K1_BOUNDS) void k_integrate_tiles_lds(
         }
       }
     }
-    float vv[kVox];
 #pragma unroll
-    for (int h = 0; h < kVox; ++h) {
-      vv[h] = drawn[h] ? tsd[h] : -limit;                               // clearImage(-limit), :249-250
-      out[tid + kThreads * h] = vv[h];
-    }
-    if (kUseSkip) {
-      tile_class_vote(&s_flag, inres[0], vv[0], inres[kVox - 1], vv[kVox - 1], limit);
-      __syncthreads();
-      if (tid == 0) S.cls[tile] = tile_class_from(s_flag);
-    } else if (tid == 0) {
-      S.cls[tile] = kTileMixed;
-    }
+    for (int h = 0; h < kVox; ++h) out[tid + kThreads * h] = drawn[h] ? tsd[h] : -limit;   // clearImage(-limit), :249-250
+    if (tid == 0) S.cls[tile] = kTileMixed;
   }
 }
 

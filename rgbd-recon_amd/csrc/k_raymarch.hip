@@ -214,100 +214,6 @@ __device__ __forceinline__ bool sample_owned(const Volume& V, float pz) {
 // nothing cost no shading registers or divergence, and the hit list length never goes through the host.
 struct Hit { float x, y, z; uint32_t pix; };   // refined sample position (volume space) + pixel index
 
-// Empty-space pyramid.  One workgroup per level-4 cell (16^3 tiles = 128^3 voxels) reduces the tile classes of its cell
-// to the bits of levels 1..4.  A tile past the volume counts as empty (nothing samples it), a tile this slab context does
-// not store counts as occupied.
-__global__ __launch_bounds__(256) void k_build_pyramid(Volume V) {
-  __shared__ uint8_t s1[512], s2[64], s3[8];
-  const int c4[3] = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
-  const int ntz = (V.res[2] + 7) >> 3;
-  for (int i = threadIdx.x; i < 512; i += blockDim.x) {                  // level-1 cells of this level-4 cell: 8^3
-    const int l1[3] = {c4[0] * 8 + (i & 7), c4[1] * 8 + ((i >> 3) & 7), c4[2] * 8 + (i >> 6)};
-    bool empty = true;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int tx = l1[0] * 2 + (k & 1), ty = l1[1] * 2 + ((k >> 1) & 1), tz = l1[2] * 2 + (k >> 2);
-      if (tx >= V.ntx || ty >= V.nty || tz >= ntz) continue;
-      if (tz < V.tz0 || tz >= V.tz1) { empty = false; continue; }
-      empty = empty && V.cls[((size_t)(tz - V.tz0) * V.nty + ty) * V.ntx + tx] == kTileMinus;
-    }
-    s1[i] = empty ? 1 : 0;
-    if (l1[0] < V.pyr_n[1][0] && l1[1] < V.pyr_n[1][1] && l1[2] < V.pyr_n[1][2]) {
-      const int bit = (l1[2] * V.pyr_n[1][1] + l1[1]) * V.pyr_n[1][0] + l1[0];
-      if (empty) atomicOr(&V.pyr[V.pyr_off[1] + (bit >> 5)], 1u << (bit & 31));
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {                                               // level 2: 4^3 per level-4 cell
-    const int i = threadIdx.x, x = i & 3, y = (i >> 2) & 3, z = i >> 4;
-    bool e = true;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) e = e && s1[((z * 2 + (k >> 2)) * 8 + (y * 2 + ((k >> 1) & 1))) * 8 + (x * 2 + (k & 1))];
-    s2[i] = e ? 1 : 0;
-    const int l2[3] = {c4[0] * 4 + x, c4[1] * 4 + y, c4[2] * 4 + z};
-    if (e && l2[0] < V.pyr_n[2][0] && l2[1] < V.pyr_n[2][1] && l2[2] < V.pyr_n[2][2]) {
-      const int bit = (l2[2] * V.pyr_n[2][1] + l2[1]) * V.pyr_n[2][0] + l2[0];
-      atomicOr(&V.pyr[V.pyr_off[2] + (bit >> 5)], 1u << (bit & 31));
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 8) {                                                // level 3: 2^3
-    const int i = threadIdx.x, x = i & 1, y = (i >> 1) & 1, z = i >> 2;
-    bool e = true;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) e = e && s2[((z * 2 + (k >> 2)) * 4 + (y * 2 + ((k >> 1) & 1))) * 4 + (x * 2 + (k & 1))];
-    s3[i] = e ? 1 : 0;
-    const int l3[3] = {c4[0] * 2 + x, c4[1] * 2 + y, c4[2] * 2 + z};
-    if (e && l3[0] < V.pyr_n[3][0] && l3[1] < V.pyr_n[3][1] && l3[2] < V.pyr_n[3][2]) {
-      const int bit = (l3[2] * V.pyr_n[3][1] + l3[1]) * V.pyr_n[3][0] + l3[0];
-      atomicOr(&V.pyr[V.pyr_off[3] + (bit >> 5)], 1u << (bit & 31));
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {                                               // level 4
-    bool e = true;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) e = e && s3[k];
-    if (e) {
-      const int bit = (c4[2] * V.pyr_n[4][1] + c4[1]) * V.pyr_n[4][0] + c4[0];
-      atomicOr(&V.pyr[V.pyr_off[4] + (bit >> 5)], 1u << (bit & 31));
-    }
-  }
-}
-
-// If the footprint of the sample at `pos` (q = pos * res - 0.5 in voxel units, taps floor(q) and floor(q) + 1) lies inside an
-// all-(-limit) cell of the pyramid, returns how many further steps keep it inside that cell (distance to the cell wall
-// along the ray, less a two-step safety margin); 0 otherwise.  The coarsest level that applies wins.
-__device__ __forceinline__ uint32_t empty_run(const Volume& V, const uint32_t* pyr, float3 pos, const float* dq) {
-  const float q[3] = {pos.x * (float)V.res[0] - 0.5f, pos.y * (float)V.res[1] - 0.5f, pos.z * (float)V.res[2] - 0.5f};
-  int iq[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) iq[a] = (int)fminf(fmaxf(floorf(q[a]), 0.0f), (float)(V.res[a] - 1));
-  for (int l = 4; l >= 1; --l) {
-    const int sh = 3 + l;
-    const int cx = iq[0] >> sh, cy = iq[1] >> sh, cz = iq[2] >> sh;
-    const int bit = (cz * V.pyr_n[l][1] + cy) * V.pyr_n[l][0] + cx;
-    if (!((pyr[V.pyr_off[l] + (bit >> 5)] >> (bit & 31)) & 1u)) continue;
-    const int cc[3] = {cx, cy, cz};
-    float m = 3.0e38f;
-    bool in_cell = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      // the footprint stays in the cell while lo <= q < hi; the outermost cells extend to infinity because out-of-range
-      // taps clamp onto their border voxels
-      const float lo = cc[a] == 0 ? -3.0e38f : (float)(cc[a] << sh);
-      const float hi = cc[a] == V.pyr_n[l][a] - 1 ? 3.0e38f : (float)(((cc[a] + 1) << sh) - 1);
-      in_cell = in_cell && (q[a] >= lo) && (q[a] < hi);
-      if (dq[a] > 0.0f) m = fminf(m, (hi - q[a]) / dq[a]);
-      else if (dq[a] < 0.0f) m = fminf(m, (lo - q[a]) / dq[a]);
-    }
-    if (!in_cell) continue;
-    const float mf = floorf(fminf(m, 1.0e6f)) - 2.0f;
-    return mf >= 1.0f ? (uint32_t)mf : 0u;
-  }
-  return 0u;
-}
-
 #ifndef RR_MARCH_BATCH
 #define RR_MARCH_BATCH 8
 #endif
@@ -323,11 +229,6 @@ template <bool kPartial, bool kSparse>
 __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count,
                                                                  LongRay* __restrict__ longs, uint32_t* __restrict__ long_count, uint32_t cap) {
   constexpr bool partial = kPartial;
-  extern __shared__ uint32_t s_pyr[];
-  if (kUseSkip) {
-    for (int i = threadIdx.x; i < V.pyr_off[0]; i += blockDim.x) s_pyr[i] = V.pyr[i];
-    __syncthreads();
-  }
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
   const float limit = V.limit, sd = limit * 0.5f;                       // sampleDistance, :34
   const int px = blockIdx.x * 16 + (wv & 1) * 8 + (ln & 7);
@@ -389,10 +290,8 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   // nothing but -limit, whole runs of samples are accounted for by just performing the reference's `pos += step`
   // additions, and (b) elsewhere four consecutive samples are fetched together and then examined in order.  Positions,
   // densities and counts are those of the one-at-a-time loop.
-  const float dq[3] = {step.x * (float)V.res[0], step.y * (float)V.res[1], step.z * (float)V.res[2]};   // voxels per step
   float prev = -limit;
   bool prev_valid = true;
-  bool try_skip = kUseSkip;                                             // the last samples seen were all exactly -limit
   float3 pos_prev = pos;
   uint32_t n = 0;
   bool hit = false;
@@ -411,21 +310,6 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
     }
   }
   while (n < max_n && !hit) {
-    if (try_skip) {
-      uint32_t cnt = empty_run(V, s_pyr, pos, dq);
-      if (cnt >= 3u) {
-        cnt += 1u;                                                      // the sample at pos itself
-        if (cnt > max_n - n) cnt = max_n - n;
-        for (uint32_t j = 0; j < cnt; ++j) {
-          pos_prev = pos;
-          pos = make_float3(pos.x + step.x, pos.y + step.y, pos.z + step.z);
-        }
-        n += cnt;
-        prev = -limit;
-        prev_valid = !partial;            // slab mode: the last sample may belong to a neighbour; a hit re-reads it
-        continue;
-      }
-    }
     float3 p[kBatch];
     float d[kBatch];
     bool own[kBatch];
@@ -438,13 +322,11 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
       d[k] = tex3d_tsdf<kSparse>(V, p[k].x, p[k].y, p[k].z);   // unconditional: taps are clamped into the allocation, and a predicated
                                                       // fetch would make the compiler wait for each sample's loads separately
     }
-    bool all_minus = true;
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       if (!hit && n < max_n) {
         n += 1;
         if (own[k]) {
-          all_minus = all_minus && (d[k] == -limit);
           if (d[k] > 0.0f) {
             hit = true;
             hit_pos = p[k];
@@ -460,7 +342,6 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
         }
       }
     }
-    try_skip = kUseSkip && all_minus;
     if (!hit) pos = make_float3(p[kBatch - 1].x + step.x, p[kBatch - 1].y + step.y, p[kBatch - 1].z + step.z);
     if (partial && !hit && !prev_valid) { n = max_n; break; }          // the batch ended outside the slab: nothing further is ours
     if (!partial && !hit && n >= cap && n < max_n) { deferred = true; break; }   // a long ray: k_march_long finishes it, one wave per ray
@@ -668,19 +549,14 @@ __global__ __launch_bounds__(256, RR_SHADE_BOUNDS) void k_shade_and_long(ViewPar
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
                      void* hit_list, uint32_t* hit_counters, int parity, int phase, void* long_list, uint32_t cap) {
   // phase 2: k_march alone; phase 3: k_shade alone; 0: everything (the split lets the caller time the march kernel alone)
-  if (kUseSkip && phase != 3) {
-    hipMemsetAsync(V.pyr, 0, (size_t)V.pyr_off[0] * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_build_pyramid, dim3(V.pyr_n[4][0], V.pyr_n[4][1], V.pyr_n[4][2]), dim3(256), 0, st, V);
-  }
   dim3 grid((P.w + 15) / 16, (P.h + 15) / 16);
-  const size_t lds = kUseSkip ? (size_t)V.pyr_off[0] * sizeof(uint32_t) : 0;
   // counters: [hit parity 0, hit parity 1, long parity 0, long parity 1]
-  const bool two_pass = !partial && !kUseSkip && P.skip && long_list && cap != 0xffffffffu;
+  const bool two_pass = !partial && P.skip && long_list && cap != 0xffffffffu;
   const bool sparse = V.slot != nullptr;
   if (phase != 3) {
     const uint32_t cap1 = two_pass ? cap : 0xffffffffu;
     LongRay* const ll = partial ? nullptr : (LongRay*)long_list;
-#define RR_LAUNCH_MARCH(PART, SP) hipLaunchKernelGGL((k_march<PART, SP>), grid, dim3(256), lds, st, P, V, R, (Hit*)hit_list, hit_counters + parity, ll, hit_counters + 2 + parity, cap1)
+#define RR_LAUNCH_MARCH(PART, SP) hipLaunchKernelGGL((k_march<PART, SP>), grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity, ll, hit_counters + 2 + parity, cap1)
     if (partial) { if (sparse) RR_LAUNCH_MARCH(true, true); else RR_LAUNCH_MARCH(true, false); }
     else { if (sparse) RR_LAUNCH_MARCH(false, true); else RR_LAUNCH_MARCH(false, false); }
 #undef RR_LAUNCH_MARCH

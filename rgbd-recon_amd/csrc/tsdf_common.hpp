@@ -47,31 +47,17 @@ struct Volume {
   uint32_t pool_tiles;
   const uint8_t* cls;  // tile class of every STORED tile, index ((tz - tz0) * nty + ty) * ntx + tx; halo layers stay kTileMixed
   int n_stored_tiles;
-  // Empty-space pyramid over the WHOLE volume, rebuilt before every raymarch: level l (1..4) has one bit per cell of
-  // 2^l tiles (16, 32, 64, 128 voxels) = 1 iff every tile of the cell is stored by this context and is kTileMinus.
-  uint32_t* pyr;       // bit arrays of the four levels, back to back
-  int pyr_off[5];      // word offset of level l (index 1..4); pyr_off[0] = total words
-  int pyr_n[5][3];     // cells per axis of level l
   float limit;
 };
 
 // Per-tile bookkeeping of the integrated tiles (index = tile id, x fastest, int_tz0 first):
 //   active  this frame: some voxel of the tile is in the voxel list of an occupied brick
-//   cls     what the tile's 2 KiB in HBM hold: 0 = every voxel is -limit (the clear value), 1 = every voxel is +limit,
-//           2 = anything else / unknown
-// integrate() clears only inactive tiles with cls != 0 and computes only active ones, so a frame's volume traffic
-// follows the occupied bricks instead of the whole volume (the reference clears everything, :249-250).  The raymarch
-// uses cls to skip the fetch of samples whose whole footprint lies in uniform tiles (the value is known exactly).
-constexpr uint8_t kTileMinus = 0, kTilePlus = 1, kTileMixed = 2;
+//   cls     what the tile's 2 KiB in HBM hold: kTileMinus = every voxel is -limit (the clear value), kTileMixed = anything else / unknown
+// integrate() clears only inactive tiles with cls != kTileMinus and computes only active ones, so a frame's volume traffic
+// follows the occupied bricks instead of the whole volume (the reference clears everything, :249-250).
+// (An empty-space pyramid over these classes for the raymarch was built and measured: it loses)
+constexpr uint8_t kTileMinus = 0, kTileMixed = 2;
 constexpr uint32_t kNoSlot = 0xffffffffu;
-// Empty-space run skipping in the raymarch (bit pyramid of all-(-limit) cells, k_raymarch.hip) and the per-tile class
-// vote in integrate that feeds it.  Measured on MI355X it LOSES (c2 march 68 -> 98 us, c1 280 -> 340 us, plus a 17 us
-// pyramid build): a skip decision costs about as many VALU instructions as the few samples it saves at 2.56 voxels per
-// step.  Kept behind this switch, off, with the measurement in DESIGN.md.
-#ifndef RR_USE_SKIP
-#define RR_USE_SKIP 0
-#endif
-constexpr bool kUseSkip = RR_USE_SKIP != 0;
 struct TileState {
   uint32_t* stamp;     // per integrated tile: the frame number that last put it on the active list (dedupes the scatter of k_classify_lists)
   uint8_t* cls;        // owned tiles only (points into Volume::cls at the first owned layer)
