@@ -578,7 +578,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
     }
   }
   // largest LUT texel box any 8^3 tile touches, with the kernel's own fp32 index arithmetic, against the LDS budget of
-  // k_integrate_tiles_lds: box dx*dy*dz <= 512, x-pass rows dy*dz*8 <= 512, y-pass planes dz*64 <= 512
+  // k_integrate_tiles_lds (kBoxCap texels)
   int worst[3] = {1, 1, 1};
   for (int a = 0; a < 3; ++a) {
     const float step = 1.0f / (float)c->res[a];
@@ -587,7 +587,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
     auto idx1 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k + 1, 0), n - 1); };
     for (int t = 0; t * 8 < c->res[a]; ++t) worst[a] = std::max(worst[a], idx1(std::min(t * 8 + 7, c->res[a] - 1)) - idx0(t * 8) + 1);
   }
-  c->lds_ok[i] = worst[0] * worst[1] * worst[2] <= integrate_box_cap() && worst[1] * worst[2] * 8 <= integrate_box_cap() && worst[2] * 64 <= integrate_box_cap();
+  c->lds_ok[i] = worst[0] * worst[1] * worst[2] <= integrate_box_cap();
   c->have_calib[i] = true;
   return TSDF_OK;
 }

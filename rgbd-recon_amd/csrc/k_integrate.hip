@@ -232,49 +232,36 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
   }
 }
 
-// LDS path.  The voxel grid is axis aligned with the inverse LUT, so the 512 voxels of a tile only ever touch a
-// small box of LUT texels per stream (4^3 at 512^3 over a 128^3 LUT) and the trilinear filter is separable over the
-// tile.  Per tile and chunk of kChunk streams:
-//   A  24 lanes per stream evaluate the per-axis GL filter set-up (i0, i1, weight) of the tile's 8 voxel coordinates
-//   B  the workgroup copies each stream's texel box HBM/L2 -> LDS with one batch of independent 16-B loads
-//   X  lerp along x for every (row of the box, voxel x)            dz*dy*8 lerps  (128)
-//   Y  lerp along y for every (box z-plane, voxel y, voxel x)      dz*8*8  lerps  (256)
-//   Z  each voxel lerps its two z-planes (512), issues the image gathers of ALL streams of the chunk together, and
-//      only then runs the order-dependent fusion rule on registers
-// The x -> y -> z order and every operand are those of tex3d_rgba_xyz, so the result is bit-identical, at 1.75 instead
-// of 7 three-component lerps per voxel and stream, and a voxel pays two dependent memory round trips per chunk.
-// Tuning knobs, values from A/B runs on MI355X (c2 / c1 integrate, ms): chunk 2, 4 waves/SIMD, 512-texel cap 0.139 / 0.509;
-// + both voxels of a thread in flight 0.108 / 0.463; + 384-texel cap, 5 waves 0.096 / 0.384; chunk 1, 6 waves/SIMD
-// 0.085 / 0.347; 7 waves/SIMD (72 VGPRs, no spill) 0.070 / 0.324 (chosen; 8 waves spills: 0.081 / 0.388).  The kernel is bound
-// by dependent-load latency per workgroup, so occupancy wins.  A software-pipelined variant (phase A once per tile, next
-// stream's box prefetched into registers, double-buffered box, fusion deferred behind the next stream's X/Y passes: three
-// barriers per stream instead of five, both round trips off the critical path) was bit-identical and SLOWER (0.084 / 0.414 at
-// 80 VGPRs + 23 KB LDS): the extra live state costs more occupancy than the overlap returns.
+// LDS path.  The voxel grid is axis aligned with the inverse LUT, so the 512 voxels of a tile only ever touch a small box of
+// LUT texels per stream (4^3 at 512^3 over a 128^3 LUT).  Per tile and stream:
+//   A  24 lanes evaluate the per-axis GL filter set-up (i0, i1, weight) of the tile's 8 voxel coordinates per axis
+//   B  the workgroup copies the stream's texel box HBM/L2 -> LDS with one batch of independent 16-B loads
+//   Z  each voxel reads its 8 box texels from LDS, lerps x -> y -> z (operands and order of tex3d_rgba_xyz: bit-identical),
+//      fetches the 2x2 image footprint and runs the order-dependent fusion rule on registers; (tsd, weight) are carried
+//      across the streams in registers
+// History, values from A/B runs on MI355X (c2 / c1 integrate, ms).  The first shape of this kernel exploited the separability of
+// the filter over a tile with two more LDS passes (X: lerp along x per box row, Y: along y per box plane; 1.75 instead of 7
+// lerps per voxel and stream) and was tuned for occupancy, because every workgroup is a chain of dependent round trips:
+// 2 streams per chunk, 4 waves/SIMD 0.139 / 0.509; both voxels of a thread in flight 0.108 / 0.463; smaller LDS cap, 5 waves
+// 0.096 / 0.384; 1 stream per chunk, 6 waves 0.085 / 0.347; 7 waves/SIMD (72 VGPRs, no spill) 0.070 / 0.324 (8 waves spill:
+// 0.081 / 0.388); a software-pipelined variant (next box prefetched, fusion deferred) 0.084 / 0.414; 128-thread workgroups
+// 0.074 / -; device code without the vectorizers 0.062 / 0.305.  At that point the PMC counters showed the launch 100 % VALU
+// issue, and the passes' own index arithmetic, loops and barriers issued more instructions than the 5.25 lerps they saved:
+// the direct form below is 0.062 / 0.297 with half the LDS and three barriers fewer per stream, and is what ships.  (Sharing the
+// x/y-lerped LUT planes between the z-neighbour voxels of a thread, wave-uniform, was also tried on top: 0.064 / 0.321.)
 #ifndef RR_K1_BOXCAP
 #define RR_K1_BOXCAP 384
 #endif
 #ifndef RR_K1_BOUNDS
 #define RR_K1_BOUNDS 7
 #endif
-#ifndef RR_K1_UNROLL_H
-#define RR_K1_UNROLL_H 2
-#endif
-constexpr int kBoxCap = RR_K1_BOXCAP;   // LUT texels per stream held in LDS; also caps the y-pass planes (dz * 64)
-constexpr int kRowCap = RR_K1_BOXCAP;   // x-pass results: dz*dy rows of 8
-#ifndef RR_K1_CHUNK
-#define RR_K1_CHUNK 1
-#endif
-constexpr int kChunk = RR_K1_CHUNK;
+constexpr int kBoxCap = RR_K1_BOXCAP;   // LUT texels per stream held in LDS
 
-// kThreads = 256 (shipped): two voxels per thread (z and z + 4); 128 (RR_K1_THREADS=128, experiment): four voxels per thread --
-// half the workgroup, twice as many tiles in flight per CU, meant to fill the last, mostly empty round of resident workgroups.
-// Measured slower (see launch_integrate): the per-tile chain gets longer by more than the extra tiles in flight return.
-template <bool kList, int kThreads>
-__global__ __launch_bounds__(kThreads, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
-  __shared__ float4 s_box[kChunk][kBoxCap];     // the texel box; after the x-pass it is reused for the y-pass results
-  __shared__ float4 s_row[kChunk][kRowCap];     // x-pass results
-  __shared__ int s_i0[kChunk][3][8], s_i1[kChunk][3][8];
-  __shared__ float s_w[kChunk][3][8];
+template <bool kList>
+__global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
+  __shared__ float4 s_box[kBoxCap];             // the stream's texel box, x fastest: ((z - mz) * dy + (y - my)) * dx + (x - mx)
+  __shared__ int s_i0[3][8], s_i1[3][8];        // per axis and voxel coordinate of the tile: the two texel indices ...
+  __shared__ float s_w[3][8];                   // ... and the weight of the GL LINEAR filter
   const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
@@ -286,109 +273,75 @@ __global__ __launch_bounds__(kThreads, RR_K1_BOUNDS) void k_integrate_tiles_lds(
     tile_coords(V, tile, t3[0], t3[1], t3[2]);
     if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
     float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
-    constexpr int kVox = 512 / kThreads, kZStep = kThreads / 64;        // voxels per thread; their z spacing
-    // the voxels of this thread share x and y
+    constexpr int kVox = 2;                                             // voxels per thread: local z = lz and lz + 4, same x and y
     const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
     bool drawn[kVox];
     float tsd[kVox], wsum[kVox];
 #pragma unroll
     for (int h = 0; h < kVox; ++h) {
-      const int z = t3[2] * 8 + lz + kZStep * h;
+      const int z = t3[2] * 8 + lz + 4 * h;
       drawn[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
       if (drawn[h] && per_voxel_check) drawn[h] = voxel_drawn(B, x, y, z);
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
       wsum[h] = 0.0f;
     }
-    for (int cb = 0; cb < T.n; cb += kChunk) {
-      const int nc = min(kChunk, T.n - cb);
+    for (int i = 0; i < T.n; ++i) {
+      const StreamLut& L = T.s[i];
       __syncthreads();                                                  // previous readers of s_* are done
-      if (tid < nc * 24) {                                              // phase A
-        const int c = tid / 24, a = (tid % 24) >> 3, k = tid & 7;
+      if (tid < 24) {                                                   // phase A
+        const int a = tid >> 3, k = tid & 7;
         const int coord = min(t3[a] * 8 + k, V.res[a] - 1);             // padding voxels reuse the last real coordinate
-        const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], T.s[cb + c].inv_res[a]);
-        s_i0[c][a][k] = ax.i0; s_i1[c][a][k] = ax.i1; s_w[c][a][k] = ax.a;
+        const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], L.inv_res[a]);
+        s_i0[a][k] = ax.i0; s_i1[a][k] = ax.i1; s_w[a][k] = ax.a;
       }
       __syncthreads();
-      for (int c = 0; c < nc; ++c) {                                    // phase B
-        const StreamLut& L = T.s[cb + c];
-        const int mx = s_i0[c][0][0], my = s_i0[c][1][0], mz = s_i0[c][2][0];
-        const int dx = s_i1[c][0][7] - mx + 1, dy = s_i1[c][1][7] - my + 1, dz = s_i1[c][2][7] - mz + 1;
+      const int mx = s_i0[0][0], my = s_i0[1][0], mz = s_i0[2][0];
+      const int dx = s_i1[0][7] - mx + 1, dy = s_i1[1][7] - my + 1, dz = s_i1[2][7] - mz + 1;
+      {                                                                 // phase B
         const int n = min(dx * dy * dz, kBoxCap);
-        for (int e = tid; e < n; e += kThreads) {
+        for (int e = tid; e < n; e += 256) {
           const int bx = e % dx, by = (e / dx) % dy, bz = e / (dx * dy);
           // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate and this launch is VALU-issue bound): operands are LUT
           // coordinates / resolutions <= 2048, the texel index fits 32 bits (tsdf_set_calibration rejects larger LUTs)
-          s_box[c][e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
-        }
-      }
-      __syncthreads();
-      for (int c = 0; c < nc; ++c) {                                    // pass X
-        const int mx = s_i0[c][0][0];
-        const int dx = s_i1[c][0][7] - mx + 1, dy = s_i1[c][1][7] - s_i0[c][1][0] + 1, dz = s_i1[c][2][7] - s_i0[c][2][0] + 1;
-        const int n1 = min(dy * dz * 8, kRowCap);
-        for (int e = tid; e < n1; e += kThreads) {
-          const int k = e & 7, row = e >> 3;
-          const int rb = __mul24(row, dx);
-          const float4 a = s_box[c][rb + (s_i0[c][0][k] - mx)], b = s_box[c][rb + (s_i1[c][0][k] - mx)];
-          const float3 r = lerp3(a, b, s_w[c][0][k]);
-          s_row[c][e] = make_float4(r.x, r.y, r.z, 0.0f);
-        }
-      }
-      __syncthreads();
-      for (int c = 0; c < nc; ++c) {                                    // pass Y (overwrites the box)
-        const int my = s_i0[c][1][0];
-        const int dy = s_i1[c][1][7] - my + 1, dz = s_i1[c][2][7] - s_i0[c][2][0] + 1;
-        const int n2 = min(dz * 64, kBoxCap);
-        for (int e = tid; e < n2; e += kThreads) {
-          const int k = e & 7, j = (e >> 3) & 7, bz = e >> 6;
-          const int zb = __mul24(bz, dy);
-          const float4 a = s_row[c][((zb + (s_i0[c][1][j] - my)) << 3) + k], b = s_row[c][((zb + (s_i1[c][1][j] - my)) << 3) + k];
-          const float3 r = lerp3(a, b, s_w[c][1][j]);
-          s_box[c][e] = make_float4(r.x, r.y, r.z, 0.0f);
+          s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
         }
       }
       __syncthreads();
       bool any_drawn = false;
 #pragma unroll
       for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
-      if (__ballot(any_drawn) != 0ull) {                                // pass Z + fusion
-#pragma unroll RR_K1_UNROLL_H
+      if (__ballot(any_drawn) != 0ull) {                                // phase Z
+        const int x0 = s_i0[0][lx] - mx, x1 = s_i1[0][lx] - mx;
+        const int y0 = __mul24(s_i0[1][ly] - my, dx), y1 = __mul24(s_i1[1][ly] - my, dx);
+        const int pl = __mul24(dx, dy);
+        const float wx = s_w[0][lx], wy = s_w[1][ly];
+#pragma unroll
         for (int h = 0; h < kVox; ++h) {
-          const int kz = lz + kZStep * h;
-          float3 pc[kChunk];
-          Dqs q[kChunk];
-#pragma unroll
-          for (int c = 0; c < kChunk; ++c) {
-            if (c < nc) {
-              const int mz = s_i0[c][2][0];
-              const float4 a = s_box[c][(((s_i0[c][2][kz] - mz) << 3) + ly) * 8 + lx], b = s_box[c][(((s_i1[c][2][kz] - mz) << 3) + ly) * 8 + lx];
-              pc[c] = lerp3(a, b, s_w[c][2][kz]);
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < kChunk; ++c)
-            if (c < nc && drawn[h]) q[c] = dqs_fetch(F, cb + c, pc[c].x, pc[c].y);
+          const int kz = lz + 4 * h;
+          const int z0 = __mul24(s_i0[2][kz] - mz, pl), z1 = __mul24(s_i1[2][kz] - mz, pl);
+          const float3 c00 = lerp3(s_box[z0 + y0 + x0], s_box[z0 + y0 + x1], wx), c10 = lerp3(s_box[z0 + y1 + x0], s_box[z0 + y1 + x1], wx);
+          const float3 c01 = lerp3(s_box[z1 + y0 + x0], s_box[z1 + y0 + x1], wx), c11 = lerp3(s_box[z1 + y1 + x0], s_box[z1 + y1 + x1], wx);
+          const float3 pc = lerp3(lerp3(c00, c10, wy), lerp3(c01, c11, wy), s_w[2][kz]);   // texture(cv_xyz_inv[i], position).xyz, :31
+          // the gather and the fusion rule are two branches on purpose: in one branch the compiler keeps voxel 1's loads behind
+          // voxel 0's arithmetic; apart, the unrolled loop has both voxels' gathers in flight together
+          Dqs q;
+          if (drawn[h]) q = dqs_fetch(F, i, pc.x, pc.y);
           if (drawn[h]) {
-            float weighted_tsd = tsd[h], total_weight = wsum[h];
-#pragma unroll
-            for (int c = 0; c < kChunk; ++c) {                          // tsdf_integration.vs:30-55, in stream order
-              if (c < nc) {
-                bool skip = false;
-                if (dqs_silhouette(q[c]) < 1.0f) {
-                  if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
-                }
-                if (!skip) {
-                  const float sdist = pc[c].z - dqs_depth(q[c]);
-                  if (sdist <= -limit) {
-                    weighted_tsd = -limit;
-                  } else if (sdist >= limit) {
-                  } else {
-                    const float weight = dqs_quality(q[c]);
-                    weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
-                    total_weight += weight;
-                  }
-                }
+            float weighted_tsd = tsd[h], total_weight = wsum[h];        // tsdf_integration.vs:30-55, in stream order
+            bool skip = false;
+            if (dqs_silhouette(q) < 1.0f) {
+              if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
+            }
+            if (!skip) {
+              const float sdist = pc.z - dqs_depth(q);
+              if (sdist <= -limit) {
+                weighted_tsd = -limit;
+              } else if (sdist >= limit) {
+              } else {
+                const float weight = dqs_quality(q);
+                weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
+                total_weight += weight;
               }
             }
             tsd[h] = weighted_tsd; wsum[h] = total_weight;
@@ -397,7 +350,7 @@ __global__ __launch_bounds__(kThreads, RR_K1_BOUNDS) void k_integrate_tiles_lds(
       }
     }
 #pragma unroll
-    for (int h = 0; h < kVox; ++h) out[tid + kThreads * h] = drawn[h] ? tsd[h] : -limit;   // clearImage(-limit), :249-250
+    for (int h = 0; h < kVox; ++h) out[tid + 256 * h] = drawn[h] ? tsd[h] : -limit;   // clearImage(-limit), :249-250
     if (tid == 0) S.cls[tile] = kTileMixed;
   }
 }
@@ -417,14 +370,11 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     }
     if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
-    // A/B (c2 / c3 / c4 integrate, us): 256 threads 69 / 119 / 383, 128 threads 74 / 128 / 415 -- the smaller workgroup loses
-    static const int wg = (getenv("RR_K1_THREADS") && atoi(getenv("RR_K1_THREADS")) == 128) ? 128 : 256;
-    if (lds_ok && wg == 128) hipLaunchKernelGGL((k_integrate_tiles_lds<true, 128>), grid, dim3(128), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
-    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, 256>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
   } else {
     if (phase == 1) return;
-    if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, 256>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+    if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
   }
 }
