@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 #define RR_K1_BOUNDS 7
 #endif
 constexpr int kBoxCap = RR_K1_BOXCAP;   // LUT texels per stream held in LDS
+static_assert(kBoxCap <= 1024, "phase B's division-free index decomposition is exact below 1024 only");
 
 template <bool kList>
 __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
@@ -300,8 +301,13 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       const int dx = s_i1[0][7] - mx + 1, dy = s_i1[1][7] - my + 1, dz = s_i1[2][7] - mz + 1;
       {                                                                 // phase B
         const int n = min(dx * dy * dz, kBoxCap);
+        // e -> (bx, by, bz) without integer division (three of them are ~45 VALU instructions; the launch is VALU-issue bound):
+        // floor((e + .5) * (1 / d)) in fp32 equals e / d for all 0 <= e < 1024, 1 <= d <= 1024 (checked exhaustively)
+        const float rdx = 1.0f / (float)dx, rdy = 1.0f / (float)dy;
         for (int e = tid; e < n; e += 256) {
-          const int bx = e % dx, by = (e / dx) % dy, bz = e / (dx * dy);
+          const int row = (int)(((float)e + 0.5f) * rdx);               // e / dx
+          const int bz = (int)(((float)row + 0.5f) * rdy);              // row / dy
+          const int bx = e - __mul24(row, dx), by = row - __mul24(bz, dy);
           // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate and this launch is VALU-issue bound): operands are LUT
           // coordinates / resolutions <= 2048, the texel index fits 32 bits (tsdf_set_calibration rejects larger LUTs)
           s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
