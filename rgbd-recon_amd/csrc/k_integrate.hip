@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 
 // LDS path.  The voxel grid is axis aligned with the inverse LUT, so the 512 voxels of a tile only ever touch a small box of
 // LUT texels per stream (4^3 at 512^3 over a 128^3 LUT).  Per tile and stream:
-//   A  24 lanes evaluate the per-axis GL filter set-up (i0, i1, weight) of the tile's 8 voxel coordinates per axis
+//   A  (once per tile, all streams) 24 lanes per stream evaluate the per-axis GL filter set-up (i0, i1, weight) of the tile's
+//      8 voxel coordinates per axis
 //   B  the workgroup copies the stream's texel box HBM/L2 -> LDS with one batch of independent 16-B loads
 //   Z  each voxel reads its 8 box texels from LDS, lerps x -> y -> z (operands and order of tex3d_rgba_xyz: bit-identical),
 //      fetches the 2x2 image footprint and runs the order-dependent fusion rule on registers; (tsd, weight) are carried
@@ -261,8 +262,8 @@ static_assert(kBoxCap <= 1024, "phase B's division-free index decomposition is e
 template <bool kList>
 __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
   __shared__ float4 s_box[kBoxCap];             // the stream's texel box, x fastest: ((z - mz) * dy + (y - my)) * dx + (x - mx)
-  __shared__ int s_i0[3][8], s_i1[3][8];        // per axis and voxel coordinate of the tile: the two texel indices ...
-  __shared__ float s_w[3][8];                   // ... and the weight of the GL LINEAR filter
+  __shared__ int s_i0a[TSDF_MAX_STREAMS][3][8], s_i1a[TSDF_MAX_STREAMS][3][8];   // per stream, axis and voxel coordinate of the tile: the two texel indices ...
+  __shared__ float s_wa[TSDF_MAX_STREAMS][3][8];                                 // ... and the weight of the GL LINEAR filter
   const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
@@ -287,16 +288,20 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
       wsum[h] = 0.0f;
     }
+    __syncthreads();                                                    // the previous tile's readers of s_* are done
+    for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
+      const int i = t / 24, a = (t % 24) >> 3, k = t & 7;
+      const int coord = min(t3[a] * 8 + k, V.res[a] - 1);               // padding voxels reuse the last real coordinate
+      const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], T.s[i].inv_res[a]);
+      s_i0a[i][a][k] = ax.i0; s_i1a[i][a][k] = ax.i1; s_wa[i][a][k] = ax.a;
+    }
+    __syncthreads();
     for (int i = 0; i < T.n; ++i) {
       const StreamLut& L = T.s[i];
-      __syncthreads();                                                  // previous readers of s_* are done
-      if (tid < 24) {                                                   // phase A
-        const int a = tid >> 3, k = tid & 7;
-        const int coord = min(t3[a] * 8 + k, V.res[a] - 1);             // padding voxels reuse the last real coordinate
-        const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], L.inv_res[a]);
-        s_i0[a][k] = ax.i0; s_i1[a][k] = ax.i1; s_w[a][k] = ax.a;
-      }
-      __syncthreads();
+      const int (*s_i0)[8] = s_i0a[i];
+      const int (*s_i1)[8] = s_i1a[i];
+      const float (*s_w)[8] = s_wa[i];
+      if (i) __syncthreads();                                           // the previous stream's readers of s_box are done
       const int mx = s_i0[0][0], my = s_i0[1][0], mz = s_i0[2][0];
       const int dx = s_i1[0][7] - mx + 1, dy = s_i1[1][7] - my + 1, dz = s_i1[2][7] - mz + 1;
       {                                                                 // phase B
