@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 #define RR_K1_BOXCAP 384
 #endif
 #ifndef RR_K1_BOUNDS
-#define RR_K1_BOUNDS 7
+#define RR_K1_BOUNDS 8      // waves per SIMD: the direct form needs 63 VGPRs (no spill); 7 waves: c2 60.4 / c1 276.8 us, 8 waves: 58.0 / 268.8 us
 #endif
 constexpr int kBoxCap = RR_K1_BOXCAP;   // LUT texels per stream held in LDS
 static_assert(kBoxCap <= 1024, "phase B's division-free index decomposition is exact below 1024 only");
