@@ -305,10 +305,11 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       const int mx = s_i0[0][0], my = s_i0[1][0], mz = s_i0[2][0];
       const int dx = s_i1[0][7] - mx + 1, dy = s_i1[1][7] - my + 1, dz = s_i1[2][7] - mz + 1;
       {                                                                 // phase B
-        const int n = min(dx * dy * dz, kBoxCap);
+        const int n = min(__mul24(__mul24(dx, dy), dz), kBoxCap);
         // e -> (bx, by, bz) without integer division (three of them are ~45 VALU instructions; the launch is VALU-issue bound):
-        // floor((e + .5) * (1 / d)) in fp32 equals e / d for all 0 <= e < 1024, 1 <= d <= 1024 (checked exhaustively)
-        const float rdx = 1.0f / (float)dx, rdy = 1.0f / (float)dy;
+        // floor((e + .5) * (1 / d)) in fp32 equals e / d for all 0 <= e < 1024, 1 <= d <= 1024 (checked exhaustively; the quotient is at
+        // least 0.5 / d away from the next integer, four orders of magnitude more than the 1 ulp of the hardware reciprocal)
+        const float rdx = __builtin_amdgcn_rcpf((float)dx), rdy = __builtin_amdgcn_rcpf((float)dy);
         for (int e = tid; e < n; e += 256) {
           const int row = (int)(((float)e + 0.5f) * rdx);               // e / dx
           const int bz = (int)(((float)row + 0.5f) * rdy);              // row / dy
