@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       const int dx = s_i1[0][7] - mx + 1, dy = s_i1[1][7] - my + 1, dz = s_i1[2][7] - mz + 1;
       {                                                                 // phase B
         const int n = min(__mul24(__mul24(dx, dy), dz), kBoxCap);
-        // e -> (bx, by, bz) without integer division (three of them are ~45 VALU instructions; the launch is VALU-issue bound):
+        // e -> (bx, by, bz) without integer division (three of them are ~45 VALU instructions, and VALU issue is this launch's largest cost):
         // floor((e + .5) * (1 / d)) in fp32 equals e / d for all 0 <= e < 1024, 1 <= d <= 1024 (checked exhaustively; the quotient is at
         // least 0.5 / d away from the next integer, four orders of magnitude more than the 1 ulp of the hardware reciprocal)
         const float rdx = __builtin_amdgcn_rcpf((float)dx), rdy = __builtin_amdgcn_rcpf((float)dy);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
           const int row = (int)(((float)e + 0.5f) * rdx);               // e / dx
           const int bz = (int)(((float)row + 0.5f) * rdy);              // row / dy
           const int bx = e - __mul24(row, dx), by = row - __mul24(bz, dy);
-          // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate and this launch is VALU-issue bound): operands are LUT
+          // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): operands are LUT
           // coordinates / resolutions <= 2048, the texel index fits 32 bits (tsdf_set_calibration rejects larger LUTs)
           s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
         }
