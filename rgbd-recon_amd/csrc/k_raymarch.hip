@@ -223,9 +223,19 @@ struct Hit { float x, y, z; uint32_t pix; };   // refined sample position (volum
 #ifndef RR_MARCH_BOUNDS
 #define RR_MARCH_BOUNDS 1
 #endif
-constexpr int kBatch = RR_MARCH_BATCH;   // samples in flight per ray
+// samples in flight per ray in the first march pass: with depth limits (rays of ~8 samples, capped at `cap`) a small batch
+// wastes fewer fetches past the hit and needs fewer registers; the dense march (hundreds of samples per ray) wants the deep one
+constexpr int kBatchDense = RR_MARCH_BATCH;
+#ifndef RR_MARCH_BATCH_SKIP
+#define RR_MARCH_BATCH_SKIP 3
+#endif
+constexpr int kBatchSkip = RR_MARCH_BATCH_SKIP;
+#ifndef RR_LONG_BATCH
+#define RR_LONG_BATCH 3
+#endif
+constexpr int kLongBatch = RR_LONG_BATCH;   // samples per lane and round in the long-ray pass
 
-template <bool kPartial, bool kSparse>
+template <bool kPartial, bool kSparse, int kBatch>
 __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count,
                                                                  LongRay* __restrict__ longs, uint32_t* __restrict__ long_count, uint32_t cap) {
   constexpr bool partial = kPartial;
@@ -390,8 +400,8 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   }
 }
 
-// Second pass of the march: kLanes (16) lanes per long ray, eight consecutive samples per lane (128 samples of a ray per round
-// trip, four rays per wave; with 8 lanes a 92-sample ray took two rounds: 64.7 -> 62.1 us for the whole draw stage).  Lane j starts 8j samples further along the ray; it gets there by performing the reference's own
+// Second pass of the march: kLanes lanes per long ray, kLongBatch consecutive samples per lane (kLanes * kLongBatch samples of a
+// ray per round trip, 64 / kLanes rays per wave; shapes measured in DESIGN.md section 4).  Lane j starts 8j samples further along the ray; it gets there by performing the reference's own
 // chain of `pos += step` additions, so positions, densities, the first positive sample and the sample count are exactly
 // those of the one-at-a-time loop (:89-110).  A single lane walking a 92-sample ray issues ~14 k dependent instructions;
 // here the same ray is two rounds of ~1.4 k.
@@ -420,53 +430,53 @@ __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V,
     float3 hit_pos = pos;
     float hit_d = 0.0f;
     while (__ballot(!done)) {
-      float3 p[kBatch];
-      float d[kBatch];
+      float3 p[kLongBatch];
+      float d[kLongBatch];
       p[0] = pos;
       for (int t = 0; t < j; ++t) {
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) p[0] = make_float3(p[0].x + step.x, p[0].y + step.y, p[0].z + step.z);
+        for (int k = 0; k < kLongBatch; ++k) p[0] = make_float3(p[0].x + step.x, p[0].y + step.y, p[0].z + step.z);
       }
 #pragma unroll
-      for (int k = 1; k < kBatch; ++k) p[k] = make_float3(p[k - 1].x + step.x, p[k - 1].y + step.y, p[k - 1].z + step.z);
+      for (int k = 1; k < kLongBatch; ++k) p[k] = make_float3(p[k - 1].x + step.x, p[k - 1].y + step.y, p[k - 1].z + step.z);
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) d[k] = tex3d_tsdf<kSparse>(V, p[k].x, p[k].y, p[k].z);     // unconditional: taps are clamped into the allocation
+      for (int k = 0; k < kLongBatch; ++k) d[k] = tex3d_tsdf<kSparse>(V, p[k].x, p[k].y, p[k].z);     // unconditional: taps are clamped into the allocation
       // examine this lane's eight samples in order
       bool lhit = false, lprev_set = false;
       float lprev = 0.0f, lhd = 0.0f;
       float3 lhp = pos;
       uint32_t lk = 0;
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) {
-        const bool valid = n + (uint32_t)(kBatch * j + k) < L.max_n;
+      for (int k = 0; k < kLongBatch; ++k) {
+        const bool valid = n + (uint32_t)(kLongBatch * j + k) < L.max_n;
         if (!lhit && valid) {
           if (d[k] > 0.0f) { lhit = true; lk = (uint32_t)k; lhp = p[k]; lhd = d[k]; }
           else { lprev = d[k]; lprev_set = true; }
         }
       }
       // the ray's first hit is in the lowest lane of its group that found one
-      const uint32_t gm = (uint32_t)(__ballot(lhit && !done) >> (kLanes * g)) & ((1u << kLanes) - 1u);
-      const float d7_before = __shfl(d[kBatch - 1], ln > 0 ? ln - 1 : 0);               // last sample of the lane one batch earlier
+      const unsigned long long gm = (__ballot(lhit && !done) >> (kLanes * g)) & (kLanes >= 64 ? ~0ull : ((1ull << (kLanes & 63)) - 1ull));
+      const float d7_before = __shfl(d[kLongBatch - 1], ln > 0 ? ln - 1 : 0);               // last sample of the lane one batch earlier
       const int last = kLanes * g + kLanes - 1;
-      const float d7_last = __shfl(d[kBatch - 1], last);
-      const float3 p7_last = make_float3(__shfl(p[kBatch - 1].x, last), __shfl(p[kBatch - 1].y, last), __shfl(p[kBatch - 1].z, last));
+      const float d7_last = __shfl(d[kLongBatch - 1], last);
+      const float3 p7_last = make_float3(__shfl(p[kLongBatch - 1].x, last), __shfl(p[kLongBatch - 1].y, last), __shfl(p[kLongBatch - 1].z, last));
       if (!done) {
         if (gm) {
-          const int jw = __ffs((int)gm) - 1;
+          const int jw = __ffsll((long long)gm) - 1;
           // broadcast the winner's result to the group (every lane of the group keeps a copy; lane 0 writes it out)
           const int src = kLanes * g + jw;
           const float wprev = lprev_set ? lprev : (j > 0 ? d7_before : prev);
           prev = __shfl(wprev, src);
           hit_pos = make_float3(__shfl(lhp.x, src), __shfl(lhp.y, src), __shfl(lhp.z, src));
           hit_d = __shfl(lhd, src);
-          n += (uint32_t)(kBatch * jw) + __shfl(lk, src) + 1u;
+          n += (uint32_t)(kLongBatch * jw) + __shfl(lk, src) + 1u;
           hit = true; done = true;
-        } else if (L.max_n - n <= (uint32_t)(kLanes * kBatch)) {
+        } else if (L.max_n - n <= (uint32_t)(kLanes * kLongBatch)) {
           n = L.max_n; done = true;
         } else {
           prev = d7_last;
           pos = make_float3(p7_last.x + step.x, p7_last.y + step.y, p7_last.z + step.z);
-          n += (uint32_t)(kLanes * kBatch);
+          n += (uint32_t)(kLanes * kLongBatch);
         }
       }
     }
@@ -556,9 +566,10 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
   if (phase != 3) {
     const uint32_t cap1 = two_pass ? cap : 0xffffffffu;
     LongRay* const ll = partial ? nullptr : (LongRay*)long_list;
-#define RR_LAUNCH_MARCH(PART, SP) hipLaunchKernelGGL((k_march<PART, SP>), grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity, ll, hit_counters + 2 + parity, cap1)
-    if (partial) { if (sparse) RR_LAUNCH_MARCH(true, true); else RR_LAUNCH_MARCH(true, false); }
-    else { if (sparse) RR_LAUNCH_MARCH(false, true); else RR_LAUNCH_MARCH(false, false); }
+#define RR_LAUNCH_MARCH(PART, SP, B) hipLaunchKernelGGL((k_march<PART, SP, B>), grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity, ll, hit_counters + 2 + parity, cap1)
+    if (partial) { if (sparse) RR_LAUNCH_MARCH(true, true, kBatchDense); else RR_LAUNCH_MARCH(true, false, kBatchDense); }
+    else if (two_pass) { if (sparse) RR_LAUNCH_MARCH(false, true, kBatchSkip); else RR_LAUNCH_MARCH(false, false, kBatchSkip); }
+    else { if (sparse) RR_LAUNCH_MARCH(false, true, kBatchDense); else RR_LAUNCH_MARCH(false, false, kBatchDense); }
 #undef RR_LAUNCH_MARCH
   }
   if (phase == 2) return;
