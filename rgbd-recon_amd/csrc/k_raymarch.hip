@@ -150,27 +150,31 @@ void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, f
 }
 
 // ------------------------------------------------------------------------------------------- K2
-// blendColors(), tsdf_raymarch.fs:295-330.  Streams are taken four at a time: the inverse-LUT taps of the whole chunk are
+// blendColors(), tsdf_raymarch.fs:295-330.  Streams are taken kShadeChunk at a time: the inverse-LUT taps of the whole chunk are
 // issued together, then the colour-LUT taps, then the image footprints; the accumulation itself stays in stream order.
+#ifndef RR_SHADE_CHUNK
+#define RR_SHADE_CHUNK 4
+#endif
+constexpr int kShadeChunk = RR_SHADE_CHUNK;   // streams whose taps are in flight together
 __device__ float4 blend_colors(const StreamTable& T, const FrameImages& F, float limit, float3 sp) {
   float3 tc = make_float3(0, 0, 0), tc2 = make_float3(0, 0, 0);
   float tw = 0.0f, tw2 = 0.0f;
-  for (int cb = 0; cb < T.n; cb += 4) {
-    const int nc = min(4, T.n - cb);
-    float3 pc[4], col[4];
-    float2 pcol[4];
-    Dqs q[4];
+  for (int cb = 0; cb < T.n; cb += kShadeChunk) {
+    const int nc = min(kShadeChunk, T.n - cb);
+    float3 pc[kShadeChunk], col[kShadeChunk];
+    float2 pcol[kShadeChunk];
+    Dqs q[kShadeChunk];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < kShadeChunk; ++c)
       if (c < nc) pc[c] = tex3d_rgba_xyz(T.s[cb + c].inv, T.s[cb + c].inv_res, sp.x, sp.y, sp.z);
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < kShadeChunk; ++c)
       if (c < nc) pcol[c] = tex3d_rg(T.s[cb + c].uv, T.s[cb + c].uv_res, pc[c].x, pc[c].y, pc[c].z);
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < kShadeChunk; ++c)
       if (c < nc) { col[c] = color_bilinear(F, cb + c, pcol[c].x, pcol[c].y); q[c] = dqs_fetch(F, cb + c, pc[c].x, pc[c].y); }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < kShadeChunk; ++c)
       if (c < nc) {
         const float dist = fabsf(dqs_depth(q[c]) - pc[c].z);
         float quality = 0.0f;
