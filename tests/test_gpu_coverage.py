@@ -45,6 +45,22 @@ def test_lut_finer_than_volume_takes_the_global_path(rr):
     assert_same(hip.tsdf(), orc.tsdf(), "tsdf (global-memory integrate)")
 
 
+@pytest.mark.parametrize("res,inv_res", [((40, 40, 40), 28), ((40, 48, 56), 28), ((24, 24, 24), 20)])
+def test_lds_box_near_its_capacity(rr, res, inv_res):
+    """LUT nearly as fine as the volume: a tile's texel box is 6..7 texels per axis (up to 343 of the 384 the LDS path holds),
+    boxes of different shapes per axis, partial tiles at the volume border -- still the LDS kernel, dense and culled."""
+    sc = rr.scene.make_scene(n_streams=3, width=96, height=72, lut_res=16, inv_res=inv_res)
+    kw = dict(KW, res=res, brick_size=[2.0 / 5, 2.2 / 5, 2.0 / 5], limit=0.08)
+    hip, orc = rr.ReconIntegrationHip(sc, **kw), OracleRecon(sc, **kw)
+    for use_bricks in (False, True):
+        for o in (hip, orc):
+            o.setUseBricks(use_bricks)
+            o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks(); o.integrate()
+        a = hip.tsdf()
+        assert_same(a, orc.tsdf(), f"tsdf (use_bricks={use_bricks})")
+        assert (np.abs(a) < 0.08).sum() > 500
+
+
 def test_setters_between_frames(rr, small_scene):
     hip, orc = rr.ReconIntegrationHip(small_scene, **KW), OracleRecon(small_scene, **KW)
     mv, pr = rr.scene.default_view(*KW["view"])
