@@ -62,7 +62,10 @@ struct tsdf_ctx {
   StreamTable luts{};
   std::vector<void*> lut_allocs;
   bool have_calib[TSDF_MAX_STREAMS]{};
-  bool lds_ok[TSDF_MAX_STREAMS]{};   // the stream's per-tile LUT box fits the integrate kernel's LDS budget
+  // the stream's per-tile LUT box against the integrate kernel's LDS budget: 0 = does not fit (global-memory kernel), 1 = the box fits
+  // (direct 8-tap form), 2 = the separable passes' rows and planes fit as well (the fastest form)
+  int lds_ok[TSDF_MAX_STREAMS]{};
+  int k1_form_cap = 2;           // RR_K1_FORM=1 forces the direct form, 0 the global-memory kernel
   FrameImages frame{};
   float* d_depth_plane = nullptr;
   float* d_stage_depth = nullptr; float* d_stage_q = nullptr; float* d_stage_s = nullptr; uint8_t* d_stage_col = nullptr;
@@ -189,6 +192,7 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   HIP_TRY(c, hipMalloc(&c->d_hit_counters, 4 * sizeof(uint32_t)));
   HIP_TRY(c, hipMemsetAsync(c->d_hit_counters, 0, 4 * sizeof(uint32_t), c->stream));
   if (const char* e = getenv("RR_MARCH_CAP")) c->march_cap = (uint32_t)atoi(e);
+  if (const char* e = getenv("RR_K1_FORM")) c->k1_form_cap = atoi(e);     // A/B and test hook, read when the context is created
   if (const char* e = getenv("RR_IMAGE_TILES")) c->use_tile_history = atoi(e) != 0;
   c->hit_parity = 0;
   // the atlas starts as ViewLod::enable() leaves it (colour (0,1,0,0), depth 1); regions no kernel writes keep that
@@ -587,7 +591,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
     auto idx1 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k + 1, 0), n - 1); };
     for (int t = 0; t * 8 < c->res[a]; ++t) worst[a] = std::max(worst[a], idx1(std::min(t * 8 + 7, c->res[a] - 1)) - idx0(t * 8) + 1);
   }
-  c->lds_ok[i] = worst[0] * worst[1] * worst[2] <= integrate_box_cap();
+  c->lds_ok[i] = worst[0] * worst[1] * worst[2] > integrate_box_cap() ? 0 : ((worst[1] * worst[2] * 8 <= integrate_row_cap() && worst[2] * 64 <= integrate_box_cap()) ? 2 : 1);
   c->have_calib[i] = true;
   return TSDF_OK;
 }
@@ -839,8 +843,9 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   if (c->vol.slot && !c->use_bricks) FAIL(c, TSDF_ERR_STATE, "a sparse tile pool needs brick culling (setUseBricks(true)): without it every tile is active");
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "2integrate");
-  bool lds = true;
-  for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = lds && c->lds_ok[i];
+  int lds = 2;
+  for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = std::min(lds, c->lds_ok[i]);
+  lds = std::min(lds, c->k1_form_cap);
   if (c->use_bricks) {
     // this frame's list / count, the previous integrate()'s (trusted unless something else may have written the volume)
     TileState& S = c->tiles;
@@ -863,9 +868,9 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     pc.zero = c->d_counters[c->counters_cur ^ 1]; pc.zero_words = (uint32_t)c->counter_words;
     c->spare_clean = true;
   }
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
   timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds ? 1 : 0, 0, c->frame_stamp, 2);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 2);
   timer_end(c, "k_integrate_tiles");
   if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
   else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them

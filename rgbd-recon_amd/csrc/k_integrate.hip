@@ -233,23 +233,26 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 }
 
 // LDS path.  The voxel grid is axis aligned with the inverse LUT, so the 512 voxels of a tile only ever touch a small box of
-// LUT texels per stream (4^3 at 512^3 over a 128^3 LUT).  Per tile and stream:
-//   A  (once per tile, all streams) 24 lanes per stream evaluate the per-axis GL filter set-up (i0, i1, weight) of the tile's
-//      8 voxel coordinates per axis
+// LUT texels per stream (3^3 .. 5^3 at the BASELINE sizes).  Per tile:
+//   A  (once, all streams) 24 lanes per stream evaluate the per-axis GL filter set-up (i0, i1, weight) of the tile's 8 voxel
+//      coordinates per axis
+// and per stream:
 //   B  the workgroup copies the stream's texel box HBM/L2 -> LDS with one batch of independent 16-B loads
-//   Z  each voxel reads its 8 box texels from LDS, lerps x -> y -> z (operands and order of tex3d_rgba_xyz: bit-identical),
-//      fetches the 2x2 image footprint and runs the order-dependent fusion rule on registers; (tsd, weight) are carried
+//   kSep: X  lerp along x for every (box row, voxel x), Y  lerp along y for every (box plane, voxel y, voxel x) -- the filter is
+//         separable over a tile -- and Z reads 2 taps and does the z lerp: 1.75 instead of 7 lerps per voxel and stream
+//   else: Z reads the voxel's 8 box texels and lerps x -> y -> z itself (for LUT boxes whose rows / planes exceed s_row / s_box)
+//   Z  then fetches the 2x2 image footprint and runs the order-dependent fusion rule on registers; (tsd, weight) are carried
 //      across the streams in registers
-// History, values from A/B runs on MI355X (c2 / c1 integrate, ms).  The first shape of this kernel exploited the separability of
-// the filter over a tile with two more LDS passes (X: lerp along x per box row, Y: along y per box plane; 1.75 instead of 7
-// lerps per voxel and stream) and was tuned for occupancy, because every workgroup is a chain of dependent round trips:
-// 2 streams per chunk, 4 waves/SIMD 0.139 / 0.509; both voxels of a thread in flight 0.108 / 0.463; smaller LDS cap, 5 waves
-// 0.096 / 0.384; 1 stream per chunk, 6 waves 0.085 / 0.347; 7 waves/SIMD (72 VGPRs, no spill) 0.070 / 0.324 (8 waves spill:
-// 0.081 / 0.388); a software-pipelined variant (next box prefetched, fusion deferred) 0.084 / 0.414; 128-thread workgroups
-// 0.074 / -; device code without the vectorizers 0.062 / 0.305.  At that point the PMC counters showed the launch 100 % VALU
-// issue, and the passes' own index arithmetic, loops and barriers issued more instructions than the 5.25 lerps they saved:
-// the direct form below is 0.062 / 0.297 with half the LDS and three barriers fewer per stream, and is what ships.  (Sharing the
-// x/y-lerped LUT planes between the z-neighbour voxels of a thread, wave-uniform, was also tried on top: 0.064 / 0.321.)
+// Operands and the x -> y -> z order are those of tex3d_rgba_xyz in every form: bit-identical.
+// History, values from A/B runs on MI355X (c2 / c1 integrate, ms).  Separable form tuned for occupancy, because every workgroup
+// is a chain of dependent round trips: 2 streams per chunk, 4 waves/SIMD 0.139 / 0.509; both voxels of a thread in flight
+// 0.108 / 0.463; smaller LDS cap, 5 waves 0.096 / 0.384; 1 stream per chunk, 6 waves 0.085 / 0.347; 7 waves/SIMD (72 VGPRs)
+// 0.070 / 0.324; a software-pipelined variant 0.084 / 0.414; 128-thread workgroups 0.074 / -; device code without the
+// vectorizers 0.062 / 0.305.  Then the direct form (0.063 / 0.291), on it: division-free box indexing 0.0616 / 0.281, phase A
+// hoisted out of the stream loop 0.0604 / 0.277, 8 waves/SIMD at 63 VGPRs 0.0580 / 0.269, hardware reciprocal 0.0577 / 0.260 --
+// and with all of that in place the separable passes once more: 0.0542 / 0.2518 (the x pass alone: 0.0556 / 0.253).  Neither the
+// vector pipe (60 %) nor the LDS pipe (65 %) is saturated; the passes cut the traffic of both.  (Sharing the x/y-lerped LUT
+// planes between z-neighbour voxels of a thread on top of the direct form: 0.064 / 0.321.)
 #ifndef RR_K1_BOXCAP
 #define RR_K1_BOXCAP 384
 #endif
@@ -257,11 +260,13 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 #define RR_K1_BOUNDS 8      // waves per SIMD: the direct form needs 63 VGPRs (no spill); 7 waves: c2 60.4 / c1 276.8 us, 8 waves: 58.0 / 268.8 us
 #endif
 constexpr int kBoxCap = RR_K1_BOXCAP;   // LUT texels per stream held in LDS
+constexpr int kRowCap = 512;           // (separable form) x-pass results: dz * dy rows of 8
 static_assert(kBoxCap <= 1024, "phase B's division-free index decomposition is exact below 1024 only");
 
-template <bool kList>
+template <bool kList, bool kSep>
 __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
   __shared__ float4 s_box[kBoxCap];             // the stream's texel box, x fastest: ((z - mz) * dy + (y - my)) * dx + (x - mx)
+  __shared__ float4 s_row[kSep ? kRowCap : 1];  // (separable form) x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
   __shared__ int s_i0a[TSDF_MAX_STREAMS][3][8], s_i1a[TSDF_MAX_STREAMS][3][8];   // per stream, axis and voxel coordinate of the tile: the two texel indices ...
   __shared__ float s_wa[TSDF_MAX_STREAMS][3][8];                                 // ... and the weight of the GL LINEAR filter
   const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
@@ -320,6 +325,22 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         }
       }
       __syncthreads();
+      if (kSep) {                                                       // passes X and Y
+        const int n1 = min(__mul24(__mul24(dy, dz), 8), kRowCap);
+        for (int e = tid; e < n1; e += 256) {
+          const int k = e & 7, rb = __mul24(e >> 3, dx);
+          const float3 r = lerp3(s_box[rb + (s_i0[0][k] - mx)], s_box[rb + (s_i1[0][k] - mx)], s_w[0][k]);
+          s_row[e] = make_float4(r.x, r.y, r.z, 0.0f);
+        }
+        __syncthreads();
+        const int n2 = min(dz << 6, kBoxCap);
+        for (int e = tid; e < n2; e += 256) {                           // the y-lerped planes overwrite the box
+          const int k = e & 7, j = (e >> 3) & 7, zb = __mul24(e >> 6, dy);
+          const float3 r = lerp3(s_row[((zb + (s_i0[1][j] - my)) << 3) + k], s_row[((zb + (s_i1[1][j] - my)) << 3) + k], s_w[1][j]);
+          s_box[e] = make_float4(r.x, r.y, r.z, 0.0f);
+        }
+        __syncthreads();
+      }
       bool any_drawn = false;
 #pragma unroll
       for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
@@ -332,9 +353,14 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         for (int h = 0; h < kVox; ++h) {
           const int kz = lz + 4 * h;
           const int z0 = __mul24(s_i0[2][kz] - mz, pl), z1 = __mul24(s_i1[2][kz] - mz, pl);
-          const float3 c00 = lerp3(s_box[z0 + y0 + x0], s_box[z0 + y0 + x1], wx), c10 = lerp3(s_box[z0 + y1 + x0], s_box[z0 + y1 + x1], wx);
-          const float3 c01 = lerp3(s_box[z1 + y0 + x0], s_box[z1 + y0 + x1], wx), c11 = lerp3(s_box[z1 + y1 + x0], s_box[z1 + y1 + x1], wx);
-          const float3 pc = lerp3(lerp3(c00, c10, wy), lerp3(c01, c11, wy), s_w[2][kz]);   // texture(cv_xyz_inv[i], position).xyz, :31
+          float3 pc;                                                    // texture(cv_xyz_inv[i], position).xyz, :31
+          if (kSep) {
+            pc = lerp3(s_box[(((s_i0[2][kz] - mz) << 3) + ly) * 8 + lx], s_box[(((s_i1[2][kz] - mz) << 3) + ly) * 8 + lx], s_w[2][kz]);
+          } else {
+            const float3 c00 = lerp3(s_box[z0 + y0 + x0], s_box[z0 + y0 + x1], wx), c10 = lerp3(s_box[z0 + y1 + x0], s_box[z0 + y1 + x1], wx);
+            const float3 c01 = lerp3(s_box[z1 + y0 + x0], s_box[z1 + y0 + x1], wx), c11 = lerp3(s_box[z1 + y1 + x0], s_box[z1 + y1 + x1], wx);
+            pc = lerp3(lerp3(c00, c10, wy), lerp3(c01, c11, wy), s_w[2][kz]);
+          }
           // the gather and the fusion rule are two branches on purpose: in one branch the compiler keeps voxel 1's loads behind
           // voxel 0's arithmetic; apart, the unrolled loop has both voxels' gathers in flight together
           Dqs q;
@@ -382,15 +408,18 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     }
     if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
-    if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
   } else {
     if (phase == 1) return;
-    if (lds_ok) hipLaunchKernelGGL(k_integrate_tiles_lds<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+    if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
   }
 }
 int integrate_box_cap() { return kBoxCap; }
+int integrate_row_cap() { return kRowCap; }
 
 __global__ __launch_bounds__(256) void k_fill_u8(uint8_t* __restrict__ p, uint8_t v, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;

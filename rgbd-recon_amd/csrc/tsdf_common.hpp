@@ -182,6 +182,7 @@ struct PeelClear { uint4* peels; const uint8_t* touched_prev; int w, h, ntx, n_t
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
                       int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr);
 int integrate_box_cap();
+int integrate_row_cap();
 void launch_mark_all_mixed(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
 void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* linear);

@@ -61,6 +61,19 @@ def test_lds_box_near_its_capacity(rr, res, inv_res):
         assert (np.abs(a) < 0.08).sum() > 500
 
 
+@pytest.mark.parametrize("form", ["2", "1", "0"])
+def test_all_three_integrate_kernels_give_the_same_volume(rr, small_scene, form, monkeypatch):
+    """RR_K1_FORM caps the kernel choice when a context is created: 2 = separable LDS passes, 1 = direct 8-tap LDS form,
+    0 = every tap from global memory.  The choice is normally made from the LUT box size; each must be bit-identical."""
+    monkeypatch.setenv("RR_K1_FORM", form)
+    hip, orc = rr.ReconIntegrationHip(small_scene, **KW), OracleRecon(small_scene, **KW)
+    for use_bricks in (True, False):
+        for o in (hip, orc):
+            o.setUseBricks(use_bricks)
+            o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks(); o.integrate()
+        assert_same(hip.tsdf(), orc.tsdf(), f"tsdf (form {form}, use_bricks={use_bricks})")
+
+
 def test_setters_between_frames(rr, small_scene):
     hip, orc = rr.ReconIntegrationHip(small_scene, **KW), OracleRecon(small_scene, **KW)
     mv, pr = rr.scene.default_view(*KW["view"])
