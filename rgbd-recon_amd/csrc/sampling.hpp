@@ -17,14 +17,16 @@ __device__ __forceinline__ Axis axis_linear(float u, int n) {
   float fl = floorf(f);
   Axis r;
   r.a = f - fl;
-  int i = (int)fminf(fmaxf(fl, -1.0f), (float)n);
-  r.i0 = clampi(i, 0, n - 1);
-  r.i1 = clampi(i + 1, 0, n - 1);
+  // clamp(floor, 0, n - 1) and clamp(floor + 1, 0, n - 1) as one v_med3_f32 each, on the integer-valued floats (exact below 2^24;
+  // a NaN coordinate gives texel 0 for both, as the integer clamps did): 5 instead of 8 instructions per axis
+  const float hi = (float)(n - 1);
+  r.i0 = (int)__builtin_amdgcn_fmed3f(fl, 0.0f, hi);
+  r.i1 = (int)__builtin_amdgcn_fmed3f(fl + 1.0f, 0.0f, hi);
   return r;
 }
 __device__ __forceinline__ int axis_nearest(float u, int n) {
   float f = floorf(u * (float)n);
-  return clampi((int)fminf(fmaxf(f, -1.0f), (float)n), 0, n - 1);
+  return (int)__builtin_amdgcn_fmed3f(f, 0.0f, (float)(n - 1));
 }
 
 __device__ __forceinline__ float3 lerp3(float4 a, float4 b, float t) {
