@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       own[k] = (n + k < max_n) && (!partial || sample_owned(V, p[k].z));
-      d[k] = tex3d_tsdf<kSparse>(V, p[k].x, p[k].y, p[k].z);   // unconditional: taps are clamped into the allocation, and a predicated
+      d[k] = tex3d_tsdf<kSparse, !kPartial>(V, p[k].x, p[k].y, p[k].z);   // unconditional: taps are clamped into the allocation, and a predicated
                                                       // fetch would make the compiler wait for each sample's loads separately
     }
 #pragma unroll
@@ -444,7 +444,7 @@ __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V,
 #pragma unroll
       for (int k = 1; k < kLongBatch; ++k) p[k] = make_float3(p[k - 1].x + step.x, p[k - 1].y + step.y, p[k - 1].z + step.z);
 #pragma unroll
-      for (int k = 0; k < kLongBatch; ++k) d[k] = tex3d_tsdf<kSparse>(V, p[k].x, p[k].y, p[k].z);     // unconditional: taps are clamped into the allocation
+      for (int k = 0; k < kLongBatch; ++k) d[k] = tex3d_tsdf<kSparse, true>(V, p[k].x, p[k].y, p[k].z);   // (the long pass only exists for whole-volume contexts)     // unconditional: taps are clamped into the allocation
       // examine this lane's eight samples in order
       bool lhit = false, lprev_set = false;
       float lprev = 0.0f, lhd = 0.0f;

@@ -106,13 +106,17 @@ __device__ __forceinline__ uint32_t vol_off_z(const Volume& V, int z) { return (
 __device__ __forceinline__ size_t vol_index(const Volume& V, int x, int y, int z) { return (size_t)(vol_off_x(x) + vol_off_y(V, y) + vol_off_z(V, z)); }
 
 struct TsdfTaps { Axis X, Y, Z; };
+// kWhole: the context is known to store every plane of the volume (the filter's own clamps already keep the taps inside).
+template <bool kWhole = false>
 __device__ __forceinline__ TsdfTaps tsdf_taps(const Volume& V, float u, float v, float w) {
   TsdfTaps t;
   t.X = axis_linear(u, V.res[0]); t.Y = axis_linear(v, V.res[1]); t.Z = axis_linear(w, V.res[2]);
-  // A slab context stores only planes [zlo, zhi].  Owned samples never leave them; a NaN position (NaN voxels exist,
-  // tsdf_integration.vs:52) would clamp to plane 0, so keep the taps inside the allocation (the result is NaN anyway).
-  t.Z.i0 = clampi(t.Z.i0, V.zlo, V.zhi);
-  t.Z.i1 = clampi(t.Z.i1, V.zlo, V.zhi);
+  if (!kWhole) {
+    // A slab context stores only planes [zlo, zhi].  Owned samples never leave them; a NaN position (NaN voxels exist,
+    // tsdf_integration.vs:52) would clamp to plane 0, so keep the taps inside the allocation (the result is NaN anyway).
+    t.Z.i0 = clampi(t.Z.i0, V.zlo, V.zhi);
+    t.Z.i1 = clampi(t.Z.i1, V.zlo, V.zhi);
+  }
   return t;
 }
 // sparse pool: the tap's tile goes through the slot table (one dependent load more per tap; unallocated tiles read -limit)
@@ -144,8 +148,8 @@ __device__ __forceinline__ float tsdf_fetch(const Volume& V, const TsdfTaps& t) 
   const float c11 = lerpf(d[b11 + x0], d[b11 + x1], t.X.a);
   return lerpf(lerpf(c00, c10, t.Y.a), lerpf(c01, c11, t.Y.a), t.Z.a);
 }
-template <bool kSparse>
-__device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) { return tsdf_fetch<kSparse>(V, tsdf_taps(V, u, v, w)); }
+template <bool kSparse, bool kWhole = false>
+__device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) { return tsdf_fetch<kSparse>(V, tsdf_taps<kWhole>(V, u, v, w)); }
 
 __device__ __forceinline__ float4 mat_mul(const Mat4& a, float x, float y, float z, float w) {
   return make_float4(a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w,
