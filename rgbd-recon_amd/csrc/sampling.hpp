@@ -71,12 +71,14 @@ __device__ __forceinline__ float2 tex3d_rg(const float2* __restrict__ t, const i
 struct Dqs { float4 t00, t10, t01, t11; float ax, ay; };
 __device__ __forceinline__ Dqs dqs_fetch(const FrameImages& F, int layer, float u, float v) {
   const Axis X = axis_linear(u, F.w), Y = axis_linear(v, F.h);
-  const float4* __restrict__ b = F.dqs;
+  // uniform base + 32-bit BYTE offsets (the packed images of a context are far below 4 GiB: tsdf_create checks it): the loads become
+  // `global_load_dwordx3 v, voffset, s[base]`, no 64-bit vector add per tap
+  const char* __restrict__ b = (const char*)F.dqs;
   // 24-bit multiplies: full rate, and every operand (layer < 16, image rows/widths, w*h of a depth image) is far below 2^24
   const uint32_t base = (uint32_t)__mul24(layer, F.w * F.h), r0 = base + (uint32_t)__mul24(Y.i0, F.w), r1 = base + (uint32_t)__mul24(Y.i1, F.w);
   Dqs r;
-  r.t00 = b[r0 + X.i0]; r.t10 = b[r0 + X.i1];
-  r.t01 = b[r1 + X.i0]; r.t11 = b[r1 + X.i1];
+  r.t00 = *(const float4*)(b + ((r0 + (uint32_t)X.i0) << 4)); r.t10 = *(const float4*)(b + ((r0 + (uint32_t)X.i1) << 4));
+  r.t01 = *(const float4*)(b + ((r1 + (uint32_t)X.i0) << 4)); r.t11 = *(const float4*)(b + ((r1 + (uint32_t)X.i1) << 4));
   r.ax = X.a; r.ay = Y.a;
   return r;
 }
