@@ -1,6 +1,8 @@
 """-m gpu: configurations and state changes around the hot path, each against the oracle on identical inputs:
 stream counts 1 and 8 (the reference hard-codes 5), unequal LUT / colour resolutions, every setter the operator has,
 and a sequence of different frames (the tile bookkeeping must reset tiles that stop being occupied)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -72,6 +74,34 @@ def test_all_three_integrate_kernels_give_the_same_volume(rr, small_scene, form,
             o.setUseBricks(use_bricks)
             o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks(); o.integrate()
         assert_same(hip.tsdf(), orc.tsdf(), f"tsdf (form {form}, use_bricks={use_bricks})")
+
+
+def test_nan_and_out_of_range_lut_coordinates_sample_like_the_oracle(rr):
+    """The inverse LUT may hold anything (the reference blends its -1 "invalid" marker into neighbouring texels): NaN, infinities
+    and coordinates far outside [0, 1] must pick the same image texels as the oracle's GL clamp rule (the kernels clamp the
+    integer-valued float index with v_med3_f32; the oracle with fmin / fmax and integer clamps) -- in all three integrate kernels
+    and in the shading's LUT chain."""
+    sc = dict(rr.scene.make_scene(n_streams=3, width=96, height=72, lut_res=16, inv_res=24))
+    inv = sc["cv_xyz_inv"].copy()
+    rng = np.random.default_rng(5)
+    n = inv.shape[1]
+    for i, vals in enumerate(([np.nan, np.nan, 0.5], [np.inf, -np.inf, 0.4], [7.5, -3.25, 0.45])):
+        idx = rng.choice(n, n // 50, replace=False)
+        inv[i, idx, :3] = np.array(vals, np.float32)
+    sc["cv_xyz_inv"] = inv
+    mv, pr = rr.scene.default_view(*KW["view"])
+    for form in ("2", "1", "0"):
+        os.environ["RR_K1_FORM"] = form
+        try:
+            hip, orc = rr.ReconIntegrationHip(sc, **KW), OracleRecon(sc, **KW)
+        finally:
+            del os.environ["RR_K1_FORM"]
+        for o in (hip, orc):
+            o.setUseBricks(False)
+            o.integrate()
+            o.drawF(mv, pr)
+        assert_same(hip.tsdf(), orc.tsdf(), f"tsdf (form {form})")
+        assert_frames_identical(hip, orc, f"frame (form {form})", min_hits=0)
 
 
 def test_setters_between_frames(rr, small_scene):
