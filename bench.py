@@ -69,27 +69,28 @@ def algorithmic_bytes(cfg, n_streams, world):
 
 
 def cpu_baseline(scene, cfg, limit, brick):
-    """The oracle (kind "port": the reference has no CPU path) on a bounded sample of the
-    same workload: the full integrate() of the configuration, and drawF() on a 640x360 window of the
-    1280x720 view (1/4 of the rays), scaled by 4."""
+    """The oracle (kind "port": the reference has no CPU path) on the same workload at full size: three frames of
+    clear/mark/update bricks + integrate() + drawF() at the bench view, the fastest one reported (the first frame pays the
+    first touch of the volume)."""
     from oracle.oracle import OracleRecon
     import rgbd_recon_amd as rr
     cores = os.cpu_count() or 1
-    sv = (640, 360)
-    o = OracleRecon(scene, res=cfg["res"], brick_size=brick, limit=limit, view=sv)
+    o = OracleRecon(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW)
     o.setUseBricks(cfg["use_bricks"]); o.setSpaceSkip(cfg["skip_space"]); o.setColorFilling(cfg["fill_holes"])
-    mv, pr = rr.scene.default_view(*sv)
-    t0 = time.perf_counter()
-    o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks()
-    o.integrate()
-    t1 = time.perf_counter()
-    o.drawF(mv, pr)
-    t2 = time.perf_counter()
-    scale = (VIEW[0] * VIEW[1]) / float(sv[0] * sv[1])
-    t_frame = (t1 - t0) + (t2 - t1) * scale
-    return {"value": 1.0 / t_frame, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/libtsdf_oracle.so, OpenMP {cores} threads: bricks+integrate full size {t1 - t0:.2f} s; "
-                      f"drawF on a {sv[0]}x{sv[1]} window {t2 - t1:.2f} s scaled x{scale:.0f} to {VIEW[0]}x{VIEW[1]}"}
+    mv, pr = rr.scene.default_view(*VIEW)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks()
+        o.integrate()
+        t1 = time.perf_counter()
+        o.drawF(mv, pr)
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1)
+    return {"value": 1.0 / best[0], "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/libtsdf_oracle.so, OpenMP {cores} threads, fastest of 3 full-size frames: bricks+integrate {best[1]:.2f} s, "
+                      f"drawF at {VIEW[0]}x{VIEW[1]} {best[2]:.2f} s"}
 
 
 def main():
