@@ -41,6 +41,18 @@ def test_create_without_a_device_fails_loudly(rr):
     assert e.value.code == -3 and "no CPU fallback" in str(e.value)
 
 
+def test_bench_refuses_to_run_without_a_device():
+    """bench.py measures the HIP path or nothing: without a GPU it exits non-zero with a message and prints no JSON line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and p.stdout.strip() == "" and "no CPU fallback" in p.stderr
+
+
 def test_bad_config_is_rejected_before_touching_the_gpu(rr):
     lib = rr.load_library()
     cfg = rr.TsdfConfig()
