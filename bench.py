@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of integrate() + drawF() on the synthetic scene of SURVEY.md §8d.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one frame of the reference's per-frame call order (source/kinect_client.cpp:569-599,614):
 clearOccupiedBricks -> mark_brick (K6) -> updateOccupiedBricks -> integrate (K0+K1) -> drawF
 (K5 depth limits, K2 raymarch, K3/K4 hole filling), with the frame images already resident in HBM.
-N > 1, --parallel auto (default): the reference rebuilds the volume from scratch every frame, so frames are independent
-units -- when the volume fits one GPU (every BASELINE configuration does) the ranks each fuse their own frames of the stream,
-no data-path collective, weak scaling; a volume that does not fit one GPU is Z-slab partitioned instead.  --parallel slabs
-forces the north-star partition: the SAME volume split into Z-slabs over the ranks (strong scaling), halo layers recomputed
-or RCCL all-gathered before the raymarch, nearest-hit gather of the partial images (rgbd-recon_amd/multigpu.py; DESIGN.md
-section 6 has the measured cost floor of that exchange against the 0.22 ms frame).
+
+Scene.  Two frames of the same rig are resident (two device frame slots): A = the scene of SURVEY.md §8d, B = the same
+objects moved.  The timed region ALTERNATES them, so every step pays what a moving scene costs the incremental bookkeeping
+(every active tile of the previous frame goes stale and is reset, the image-space dirty tiles change); `value` is that
+moving-scene rate.  The static rate (the same frame every step: the best case) is reported beside it as `static`.
+
+N > 1: the north-star partition -- ONE volume split into Z-slabs over the ranks (strong scaling: `value` = frames of the one
+volume per second), halo tile layers recomputed locally (default) or RCCL all-gathered, nearest-hit gather of one 32-byte record
+per hit ray to rank 0 (rgbd-recon_amd/multigpu.py).  Before anything is timed rank 0 checks the composite of both frames
+against an unpartitioned context, bit for bit, and the run fails if they differ.
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,8 +44,10 @@ CONFIGS = {
 }
 VIEW = (1280, 720)
 LUT = 128
+LIMIT = 0.01
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")   # per-kernel HBM bytes from separate rocprofv3 --pmc passes
+MOVED = dict(sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2))  # frame B: both objects somewhere else (every tile churns)
 
 
 def measured_traffic(config, kernel, key="hbm_bytes"):
@@ -55,17 +61,40 @@ def measured_traffic(config, kernel, key="hbm_bytes"):
         return None
 
 
-def algorithmic_bytes(cfg, n_streams, world):
-    """BASELINE.md §3 / SURVEY.md §8d dense byte counts, per launch of each kernel on ONE rank."""
-    V = cfg["res"][0] * cfg["res"][1] * cfg["res"][2] // world
-    L = LUT ** 3 // world
-    P = 640 * 480
-    R = VIEW[0] * VIEW[1]
-    integrate = 4 * V + n_streams * 16 * L + n_streams * 16 * P
-    raymarch = 4 * V + 24 * R + n_streams * 15 * P
-    march = 4 * V + 24 * R                     # k_march alone: the volume + the per-pixel peel/hit records (k_shade reads the images)
-    inpaint = 67 * R
-    return dict(integrate=integrate, raymarch=raymarch, march=march, inpaint=inpaint)
+def dense_bytes(res, n_streams):
+    """BASELINE.md §3 / SURVEY.md §8d dense byte counts per launch: every voxel, every LUT texel, every image pixel once."""
+    V = res[0] * res[1] * res[2]
+    L, P, R = LUT ** 3, 640 * 480, VIEW[0] * VIEW[1]
+    return dict(integrate=4 * V + n_streams * 16 * L + n_streams * 16 * P, march=4 * V + 24 * R, inpaint=67 * R)
+
+
+def culled_integrate_bytes(np, hip, scenes, res, n_streams):
+    """Algorithmic bytes of ONE culled integrate launch = what its work units -- the active 8^3-voxel tiles -- must move at least:
+         2 KiB stored per active tile
+       + 16 B x N x (distinct inverse-LUT texels inside the tiles' texel boxes; all streams share the LUT grid)
+       + 16 B x (valid depth pixels of the frame's N images: the packed {depth, quality, silhouette} texels under the surface)
+    averaged over the frames of the timed region.  (the dense formula only applies with use_bricks off.)"""
+    tot, tiles_n = 0.0, []
+    for k, sc in enumerate(scenes):
+        hip.select_frame_slot(k)
+        hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate()
+        tiles, _ = hip.active_tiles()
+        touched = np.zeros((LUT, LUT, LUT), bool)
+        rng = []
+        for a in range(3):                               # the kernel's own fp32 index arithmetic (axis_linear, sampling.hpp)
+            n = np.float32(LUT)
+            step = np.float32(1.0) / np.float32(res[a])
+            v0 = np.minimum(tiles[:, a] * 8, res[a] - 1).astype(np.float32)
+            v1 = np.minimum(tiles[:, a] * 8 + 7, res[a] - 1).astype(np.float32)
+            lo = np.clip(np.floor((v0 + np.float32(0.5)) * step * n - np.float32(0.5)), 0, LUT - 1).astype(np.int64)
+            hi = np.clip(np.floor((v1 + np.float32(0.5)) * step * n - np.float32(0.5)) + 1, 0, LUT - 1).astype(np.int64)
+            rng.append((lo, hi))
+        for i in range(tiles.shape[0]):
+            touched[rng[2][0][i]:rng[2][1][i] + 1, rng[1][0][i]:rng[1][1][i] + 1, rng[0][0][i]:rng[0][1][i] + 1] = True
+        valid_px = int((sc["depth"][..., 0] > 0).sum())
+        tot += 2048.0 * tiles.shape[0] + 16.0 * n_streams * int(touched.sum()) + 16.0 * valid_px
+        tiles_n.append(int(tiles.shape[0]))
+    return tot / len(scenes), tiles_n
 
 
 def cpu_baseline(scene, cfg, limit, brick):
@@ -89,8 +118,12 @@ def cpu_baseline(scene, cfg, limit, brick):
         if best is None or t2 - t0 < best[0]:
             best = (t2 - t0, t1 - t0, t2 - t1)
     return {"value": 1.0 / best[0], "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/libtsdf_oracle.so, OpenMP {cores} threads, fastest of 3 full-size frames: bricks+integrate {best[1]:.2f} s, "
+            "sample": f"oracle/libtsdf_oracle.so, OpenMP {cores} threads, fastest of 3 full-size frames of scene A: bricks+integrate {best[1]:.2f} s, "
                       f"drawF at {VIEW[0]}x{VIEW[1]} {best[2]:.2f} s"}
+
+
+def same(np, a, b):
+    return bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
 
 
 def main():
@@ -101,27 +134,28 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"], help="N > 1: integrate the halo layers locally, or RCCL all-gather them")
     ap.add_argument("--composite", default="compact", choices=["compact", "dense"], help="N > 1: gather hit records, or whole partial images")
-    ap.add_argument("--parallel", default="auto", choices=["auto", "slabs", "frames"],
-                    help="N > 1: 'frames' = every GPU fuses its own frames of the stream (each frame rebuilds the volume from scratch, so frames "
-                         "are independent: no exchange at all, weak scaling); 'slabs' = ONE volume split into Z-slabs with the RCCL exchange "
-                         "(the north-star partition, strong scaling); 'auto' = frames while the dense volume fits half of one GPU's HBM, else slabs")
+    ap.add_argument("--scene", default="moving", choices=["moving", "static"], help="alternate two resident frames in the timed region (default), or repeat one")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3, 4],
                     help="single GPU: process this many frames concurrently, one context + HIP stream per slot (every frame rebuilds the "
-                         "volume from scratch, so frames are independent and the frame's 17 small latency-bound kernels overlap well). "
+                         "volume from scratch, so frames are independent and the frame's small latency-bound kernels overlap well). "
                          "A throughput mode: the latency of a frame does not improve, and per-kernel times (roofline) are measured under "
                          "contention.  Default 1")
     ap.add_argument("--sparse-pool", type=int, default=0, metavar="TILES",
                     help="store the TSDF in a sparse pool of this many 8^3-voxel tiles (2 KiB each) instead of a dense array "
                          "(BASELINE.json configs[4] 'sparse-brick allocation'); needs a culled configuration")
-    ap.add_argument("--preprocess", action="store_true", help="also run the image pre-processing passes (f1) every frame, from the raw depth/colour")
+    ap.add_argument("--preprocess", action="store_true", help="also run the image pre-processing passes (f1) every frame, from the raw depth/colour (static scene)")
     ap.add_argument("--ingest", default=None, choices=["f32-rgb8", "f32-dxt1", "u8-rgb8", "u8-dxt1", "u8-dxt5"],
                     help="also measure the wire path (f2): every frame arrives as one host message, is copied through the pinned double "
                          "buffer, unpacked/decoded on the GPU and pre-processed (implies --preprocess); reported beside `value`, never as it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true", help="leave the per-kernel HIP event timers off")
+    ap.add_argument("--no-c1", action="store_true", help="skip the dense configs[1] kernel timings (`roofline_c1`)")
+    ap.add_argument("--long-steps", type=int, default=1000, help="steps of the extra long pass reported as `long_run` (0 = skip)")
     args = ap.parse_args()
     if args.ingest:
         args.preprocess = True
+    if args.preprocess or args.frames_in_flight > 1:
+        args.scene = "static"
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner from inside
     # communicator creation on rank 0), so file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to
@@ -160,50 +194,89 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    slabs_mode = world > 1 or alone
+    if slabs_mode and (args.frames_in_flight > 1 or args.ingest):
+        raise SystemExit("--frames-in-flight / --ingest are single-GPU options")
 
     cfg = CONFIGS[args.config]
-    limit = 0.01
-    scene = rr.scene.make_scene(n_streams=cfg["streams"], width=640, height=480, lut_res=LUT, inv_res=LUT)
+    n_streams = cfg["streams"]
+    mk = dict(n_streams=n_streams, width=640, height=480, lut_res=LUT, inv_res=LUT)
+    scene = rr.scene.make_scene(**mk)
+    scenes = [scene] + ([rr.scene.make_scene(**mk, **MOVED)] if args.scene == "moving" else [])
     ext = scene["bbox_max"] - scene["bbox_min"]
     brick = [float(ext[a]) / cfg["res"][a] * 8 for a in range(3)]          # 8^3 voxels per brick
-    if alone:
-        args.parallel = "slabs"
-    if args.parallel == "auto":                # 4 B per voxel against half of the 288 GB of one MI355X: every BASELINE configuration -> frames
-        fits = 4 * cfg["res"][0] * cfg["res"][1] * cfg["res"][2] <= 144e9
-        args.parallel = "frames" if fits else "slabs"
-    frames_mode = world > 1 and args.parallel == "frames"
-    slab = mg.slab_range(cfg["res"][2], rank, world) if ((world > 1 and not frames_mode) or alone) else (0, 0)
-    hip = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, slab=slab,
-                                 recompute_halo=(args.halo == "recompute"), sparse_pool_tiles=args.sparse_pool)
-    hip.setUseBricks(cfg["use_bricks"]); hip.setSpaceSkip(cfg["skip_space"]); hip.setColorFilling(cfg["fill_holes"])
-    stream = torch.cuda.current_stream()
-    hip.set_stream(stream.cuda_stream)         # kernels, HIP event timers and the collectives share one stream
+    slab = mg.slab_range(cfg["res"][2], rank, world) if slabs_mode else (0, 0)
+
+    def make_ctx(slab=(0, 0), recompute=False, sparse=0):
+        h = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=VIEW, device=local, slab=slab,
+                                   recompute_halo=recompute, sparse_pool_tiles=sparse)
+        h.setUseBricks(cfg["use_bricks"]); h.setSpaceSkip(cfg["skip_space"]); h.setColorFilling(cfg["fill_holes"])
+        for k, sc in enumerate(scenes[1:], 1):            # the second resident frame
+            h.select_frame_slot(k); h.upload_frame(sc)
+        h.select_frame_slot(0)
+        return h
+
+    hip = make_ctx(slab, args.halo == "recompute" and slabs_mode, args.sparse_pool)
+    # ONE explicit torch stream carries the context's kernels, the HIP event timers and the collectives (multigpu.py: the handle
+    # of torch's default stream is 0 and cannot be handed over)
+    stream = torch.cuda.Stream()
     if args.preprocess:
         hip.upload_raw_frame(scene)
-    drv = mg.SlabDriver(hip, 0 if frames_mode else rank, 1 if frames_mode else world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite,
-                        preprocess=args.preprocess, exchange_when_alone=alone)
+    drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite,
+                        preprocess=args.preprocess, exchange_when_alone=alone, stream=stream)
     mv, pr = rr.scene.default_view(*VIEW)
+    nsc = len(scenes)
+
+    def step(d, i):
+        if nsc > 1:
+            d.b.select_frame_slot(i % nsc)
+        d.frame(mv, pr)
+
     # extra frame slots (throughput mode): independent contexts on their own streams, fed round robin in the timed loop
     slots = [drv]
     if args.frames_in_flight > 1:
-        if world > 1 or args.ingest:
-            raise SystemExit("--frames-in-flight is a single-GPU option (and not combined with --ingest)")
         for _ in range(args.frames_in_flight - 1):
-            h2 = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW, device=local, sparse_pool_tiles=args.sparse_pool)
-            h2.setUseBricks(cfg["use_bricks"]); h2.setSpaceSkip(cfg["skip_space"]); h2.setColorFilling(cfg["fill_holes"])
-            s2 = torch.cuda.Stream()
-            h2.set_stream(s2.cuda_stream)
+            h2 = make_ctx(sparse=args.sparse_pool)
             if args.preprocess:
                 h2.upload_raw_frame(scene)
             slots.append(mg.SlabDriver(h2, 0, 1, f"cuda:{local}", view=VIEW, preprocess=args.preprocess))
-            slots[-1]._stream = s2                  # keep the torch stream alive
-        for d in slots * 5:
-            d.frame(mv, pr)
+        for k, d in enumerate(slots * 5):
+            step(d, k)
 
     def barrier():
+        for d in slots:
+            d.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- N > 1: the partition must reproduce the unpartitioned frame, bit for bit, before it is worth timing
+    slab_check = None
+    if slabs_mode:
+        ok = True
+        got = []
+        for k in range(nsc):
+            for _ in range(mg.SlabDriver.LAG + 1):         # also past the frames that gather the full capacity
+                step(drv, k)
+            drv.finish()
+            if rank == 0:
+                got.append((hip.view_images()[:3], hip.framebuffer()))
+        if rank == 0:
+            whole = make_ctx()
+            for k in range(nsc):
+                whole.select_frame_slot(k)
+                whole.clearOccupiedBricks(); whole.markBricks(); whole.updateOccupiedBricks(False); whole.integrate(); whole.drawF(mv, pr)
+                (wa, wd, wn, _), (wc, wdd) = whole.view_images(), whole.framebuffer()
+                (sa, sd, sn), (sc, sdd) = got[k]
+                ok &= same(np, sa, wa) and same(np, sd, wd) and same(np, sn, wn) and same(np, sc, wc) and same(np, sdd, wdd) and int((wd < 1).sum()) > 1000
+            whole.close()
+            del whole
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{local}" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.broadcast(flag, src=0)
+        if int(flag.item()) != 1:
+            raise SystemExit("slab partition does NOT reproduce the unpartitioned frame: refusing to time it")
+        slab_check = f"rank 0: raymarch colour/depth/sample counts and the hole-filled framebuffer of {nsc} frame(s) bit-identical to an unpartitioned context"
 
     # host -> device frame upload, outside the timed region (value = HBM-resident rate); reported for the PCIe-inclusive figure
     hip.sync()
@@ -212,25 +285,25 @@ def main():
         hip.upload_frame(scene)
     hip.sync()
     upload_ms = (time.perf_counter() - tu0) / 5 * 1e3
-    for _ in range(args.warmup):
-        drv.frame(mv, pr)
+    for i in range(args.warmup):
+        step(drv, i)
     # The HIP runtime has a one-time stall of ~18 ms a few thousand launches into a process (measured: 600 timed steps after 20
     # warm-up frames ran 12 % slower than after 700; 200 or 30 000 steps did not show it).  Whatever W the caller asks for, run
     # the launch path into its steady state before anything is timed.
-    for _ in range(max(0, 800 - args.warmup)):
-        drv.frame(mv, pr)
+    for i in range(max(0, 800 - args.warmup)):
+        step(drv, i)
     barrier()
 
-    # Stage breakdown, OUTSIDE the timed region: every recorded HIP event costs a few microseconds of stream time (17 launches
-    # and 9 nested timers per frame add ~15 % to a 0.29 ms frame), so the full set of timers runs on its own short pass ...
+    # Stage breakdown, OUTSIDE the timed region: every recorded HIP event costs a few microseconds of stream time, so the full set
+    # of timers runs on its own short pass ...
     stages = {}
     dom = None
     if not args.no_timers:
         hip.set_timer_filter(None)
         hip.enable_timers(True)
         nb = max(10, min(50, args.steps))
-        for _ in range(nb):
-            drv.frame(mv, pr)
+        for i in range(nb):
+            step(drv, i)
         barrier()
         hip.enable_timers(False)
         for name in ("0ingest", "1preprocess", "bricks", "2integrate", "k_integrate_tiles", "brickdraw", "draw", "k_march", "holefill", "3recon"):
@@ -253,26 +326,56 @@ def main():
     for i in range(args.steps):
         if timing and stride > 1:
             hip.enable_timers(i % stride == 0)
-        slots[i % len(slots)].frame(mv, pr)
+        step(slots[i % len(slots)], i // len(slots) if len(slots) > 1 else i)
     barrier()
     dt = time.perf_counter() - t0
     hip.enable_timers(False)
     hip.set_timer_filter(None)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local}" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    dt = max_over_ranks(dt)
     dom_ms = None
     if dom:
         n, ms = hip.timer_stats(dom)
         dom_ms = ms / n if n else None
+
+    def timed(n_steps, sel):
+        barrier()
+        t = time.perf_counter()
+        for i in range(n_steps):
+            sel(i)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t)
+
+    # the static scene (best case of the incremental bookkeeping: nothing churns), same number of steps
+    static = None
+    if nsc > 1:
+        def st(i):
+            drv.frame(mv, pr)
+        hip.select_frame_slot(0)
+        timed(20, st)
+        ds = timed(args.steps, st)
+        static = {"value": args.steps / ds, "ms_per_step": ds / args.steps * 1e3, "note": "frame A every step: no tile goes stale, the dirty-tile history is a no-op"}
+    long_run = None
+    if args.long_steps and args.frames_in_flight == 1:
+        dl = timed(args.long_steps, lambda i: step(drv, i))
+        long_run = {"steps": args.long_steps, "value": args.long_steps / dl, "ms_per_step": dl / args.long_steps * 1e3,
+                    "note": "a second, longer pass of the same loop (the contract's timed region above is exactly --steps)"}
     # per-frame device time distribution (SURVEY.md section 8d asks for median and p95): one event pair per frame, own short pass
     frame_ms = None
     if not args.no_timers:
         hip.timer_reserve("frame", 100)
         hip.set_timer_filter(["frame"])
         hip.enable_timers(True)
-        for _ in range(100):
+        for i in range(100):
+            if nsc > 1:
+                hip.select_frame_slot(i % nsc)
             hip.timer_begin("frame"); drv.frame(mv, pr); hip.timer_end("frame")
         barrier()
         hip.enable_timers(False)
@@ -282,51 +385,94 @@ def main():
             frame_ms = {"frames": int(smp.size), "median": float(np.median(smp)), "p95": float(smp[min(smp.size - 1, int(0.95 * smp.size))]),
                         "min": float(smp[0]), "max": float(smp[-1]), "note": "HIP events around whole frames on rank 0, separate pass after the timed region"}
     ratio = hip.occupiedRatio()
-    ab = algorithmic_bytes(cfg, cfg["streams"], 1 if frames_mode else world)
     out = {
-        "metric": "frames/sec (integrate+raymarch) at %d^3 x %d streams" % (cfg["res"][0], cfg["streams"]),
-        "value": (world if frames_mode else 1) * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.parallel == "frames" else "strong", "vs_baseline": None,
+        "metric": "frames/sec (integrate+raymarch) at %d^3 x %d streams" % (cfg["res"][0], n_streams),
+        "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["name"], "config": args.config, "streams": cfg["streams"], "res": list(cfg["res"]),
-                   "view": list(VIEW), "limit": limit, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
+        "config": {"workload": cfg["name"], "config": args.config, "streams": n_streams, "res": list(cfg["res"]),
+                   "view": list(VIEW), "limit": LIMIT, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
+                   "scene": "two resident frames alternating every step (objects moved: every active tile churns)" if nsc > 1 else "one static frame",
                    "frames_in_flight": args.frames_in_flight,
                    "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
-                   "parallelism": ("single GPU, slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else (f"{world} GPUs, frame-parallel: each rank fuses its own frames of the stream, no data-path collective (--parallel slabs = Z-slab partition of one volume)" if frames_mode else
-                                                                    f"{world} Z-slabs, halo {args.halo}, RCCL {args.composite} hit gather to rank 0")},
+                   "parallelism": ("single GPU, slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else
+                                  f"ONE volume in {world} Z-slabs (strong scaling), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame"},
+        "static": static,
+        "long_run": long_run,
         "stage_ms": stages,
         "frame_device_ms": frame_ms,
         "stage_ms_note": "per-stage device time from a separate all-timers pass before the timed region (not part of `value`)",
         "upload_ms_per_frame": upload_ms,
         "pcie_inclusive_frames_per_s": 1e3 / (upload_ms + dt / args.steps * 1e3),
     }
-    if dom_ms:
-        key = "integrate" if dom == "k_integrate_tiles" else "march"
-        ach = ab[key] / (dom_ms * 1e-3) / 1e9
-        kname = "k_integrate_tiles_lds" if key == "integrate" else "k_march"
-        traffic = measured_traffic(args.config, kname)
-        valu = measured_traffic(args.config, kname, "valu_insts")
-        out["roofline"] = {"bound": "hbm", "kernel": kname,
-                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "algorithmic_bytes": ab[key], "avg_launch_ms": dom_ms,
-                           "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                           # what actually binds this kernel: VALU wave-instructions (PMC) x 4 issue cycles over the
-                           # 1024 SIMDs' cycles at 2.4 GHz during the launch
-                           # share of the SIMDs' vector issue capacity: a SIMD-32 issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md,
-                           # "Wave scheduling"), 1024 SIMDs at 2.4 GHz
-                           "valu_issue_frac": (valu * 2.0 / (1024 * 2.4e9 * dom_ms * 1e-3)) if valu else None,
-                           "timing": "HIP events around this kernel alone, recorded on the launch stream in every frame of the timed region",
-                           "note": "algorithmic bytes are the DENSE figures of BASELINE.md section 3; with brick culling the launch touches "
-                                   "only occupied tiles (occupied_brick_ratio), so achieved may exceed what HBM really moved (traffic)"}
-        frame_bytes = ab["integrate"] + ab["raymarch"] + (ab["inpaint"] if cfg["fill_holes"] else 0)
-        out["frame_roofline"] = {"algorithmic_bytes": frame_bytes, "achieved": frame_bytes / (dt / args.steps) / 1e9,
-                                 "frac": frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
+    if slabs_mode:
+        out["slab_check"] = slab_check
+        out["regathers"] = drv.regathers
+
+    # ---- roofline of the dominant kernel: ALGORITHMIC bytes of the units the launch really processes / its measured time
+    def roofline(kname, alg, ms, cfgname, note):
+        ach = alg / (ms * 1e-3) / 1e9
+        kn = "k_integrate_tiles_lds" if kname == "k_integrate_tiles" else "k_march"
+        traffic = measured_traffic(cfgname, kn)
+        valu = measured_traffic(cfgname, kn, "valu_insts")
+        return {"bound": "hbm", "kernel": kn, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "algorithmic_bytes": alg, "avg_launch_ms": ms,
+                "traffic_frac": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                # share of the SIMDs' vector issue capacity: a SIMD-32 issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md,
+                # "Wave scheduling"), 1024 SIMDs at 2.4 GHz
+                "valu_issue_frac": (valu * 2.0 / (1024 * 2.4e9 * ms * 1e-3)) if valu else None,
+                "timing": "HIP events around this kernel alone, recorded on the launch stream", "note": note}
+
+    db = dense_bytes(cfg["res"], n_streams)
+    if dom_ms and world == 1 and not alone:
+        if dom == "k_integrate_tiles" and cfg["use_bricks"]:
+            alg, tiles_n = culled_integrate_bytes(np, hip, scenes, cfg["res"], n_streams)
+            note = (f"units = active 8^3-voxel tiles of the launch ({tiles_n} in the timed frames): 2 KiB stored per tile + 16 B x N x distinct inverse-LUT "
+                    f"texels of their boxes + 16 B x valid depth pixels; the DENSE figure of BASELINE.md section 3 ({db['integrate']} B) does not apply to a culled launch")
+        elif dom == "k_integrate_tiles":
+            alg, note = db["integrate"], "dense launch: 4V + N*16*L + N*16*P (BASELINE.md section 3)"
+        else:
+            alg, note = db["march"], "dense march: 4V + 24R (BASELINE.md section 3); with depth limits the rays sample only inside occupied bricks, so this is an upper figure"
+        out["roofline"] = roofline(dom, alg, dom_ms, args.config, note)
+    # ---- the dense configuration (configs[1]): both kernels against the dense byte counts, in the same line
+    if world == 1 and not alone and not args.no_c1 and not args.no_timers and args.config != "c1" and args.frames_in_flight == 1:
+        c1 = CONFIGS["c1"]
+        sc1 = scene if n_streams == c1["streams"] else rr.scene.make_scene(n_streams=c1["streams"], width=640, height=480, lut_res=LUT, inv_res=LUT)
+        ext1 = sc1["bbox_max"] - sc1["bbox_min"]
+        h1 = rr.ReconIntegrationHip(sc1, res=c1["res"], brick_size=[float(ext1[a]) / c1["res"][a] * 8 for a in range(3)], limit=LIMIT, view=VIEW, device=local)
+        h1.setUseBricks(False); h1.setSpaceSkip(False); h1.setColorFilling(False)
+        h1.set_stream(stream.cuda_stream)
+
+        def f1():
+            h1.clearOccupiedBricks(); h1.markBricks(); h1.updateOccupiedBricks(False); h1.integrate(); h1.drawF(mv, pr)
+        with torch.cuda.stream(stream):
+            for _ in range(30):
+                f1()
+            h1.set_timer_filter(["k_integrate_tiles", "k_march"]); h1.enable_timers(True)
+            for _ in range(100):
+                f1()
+            h1.sync()
+            h1.enable_timers(False)
+            h1.sync()
+            tc0 = time.perf_counter()
+            for _ in range(100):
+                f1()
+            h1.sync()
+            c1_ms = (time.perf_counter() - tc0) / 100 * 1e3
+        d1 = dense_bytes(c1["res"], c1["streams"])
+        r1 = {"workload": c1["name"], "ms_per_frame": c1_ms, "frames_per_s": 1e3 / c1_ms}
+        for tname, key in (("k_integrate_tiles", "integrate"), ("k_march", "march")):
+            n, ms = h1.timer_stats(tname)
+            if n:
+                r1[key] = roofline(tname, d1[key], ms / n, "c1", "dense launch, dense bytes of BASELINE.md section 3")
+        out["roofline_c1"] = r1
+        h1.close()
     if args.ingest and world == 1:
         dfmt, cfmt = args.ingest.split("-")
         cf, df = {"rgb8": rr.COLOR_RGB8, "dxt1": rr.COLOR_DXT1, "dxt5": rr.COLOR_DXT5}[cfmt], {"f32": rr.DEPTH_F32, "u8": rr.DEPTH_U8}[dfmt]
         msg = rr.scene.make_wire_message(scene, cf, df, timestamp=1.0)
         hip.setWireFormat(cf, df)
-        for i in range(cfg["streams"]):
+        for i in range(n_streams):
             hip.setDepthCompression(i, df == rr.DEPTH_U8, 0.5, 4.5)
         if df == rr.DEPTH_U8:
             # pre_morph.fs validates the normalised 8-bit codes against 0.5..4.5 "metres" (reference quirk):
@@ -350,8 +496,30 @@ def main():
                          "wire_inclusive_frames_per_s": 1.0 / dti, "gpu_unpack_ms": (ms_u / n_u) if n_u else None,
                          "note": "host message -> pinned copy -> H2D -> GPU unpack/DXT decode -> pre-process -> integrate -> drawF, "
                                  "one frame in flight; `value` above stays the HBM-resident rate"}
+    # ---- PCIe-inclusive rate with the upload of frame f + 1 overlapping the compute of frame f (double-buffered frame slots,
+    # pinned staging filled in place as the reference's reader thread fills the mapped PBO): never `value`
+    if world == 1 and not alone and not args.preprocess and args.frames_in_flight == 1:
+        with torch.cuda.stream(stream):
+            for k in range(2):                            # both staging buffers hold a frame (the producer's job)
+                st_d, st_q, st_s, st_c = hip.frame_staging()
+                sc = scenes[k % nsc]
+                st_d[...] = sc["depth"]; st_q[...] = sc["quality"]; st_s[...] = sc["silhouette"]; st_c[...] = sc["color"]
+                hip.upload_frame_async(None)
+                hip.select_frame_slot(hip.current_frame_slot() ^ 1)
+            hip.sync()
+            ko = max(50, args.steps)
+            for phase in range(2):
+                t0 = time.perf_counter()
+                for i in range(ko):
+                    hip.upload_frame_async(None)          # frame f + 1 starts travelling ...
+                    drv.frame(mv, pr)                      # ... while frame f is computed
+                    hip.select_frame_slot(hip.current_frame_slot() ^ 1)
+                hip.sync()
+                dto = (time.perf_counter() - t0) / ko
+        out["pcie_overlapped"] = {"frames_per_s": 1.0 / dto, "ms_per_frame": dto * 1e3, "bytes_per_frame": int(scene["depth"].nbytes + scene["quality"].nbytes + scene["silhouette"].nbytes + scene["color"].nbytes),
+                                  "note": "tsdf_upload_frame_async of the next frame (pinned staging -> copy stream -> other frame slot) overlapped with the compute of the current one"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(scene, cfg, limit, brick)
+        out["cpu_baseline"] = cpu_baseline(scene, cfg, LIMIT, brick)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -75,6 +75,10 @@ const char* tsdf_last_error(const tsdf_ctx* ctx);   /* ctx may be NULL: error of
 /* sparse contexts: tiles the last integrate() needed / pool capacity (synchronises the stream) */
 int32_t tsdf_sparse_pool_stats(tsdf_ctx* ctx, uint32_t* tiles_needed, uint32_t* pool_tiles);
 int32_t tsdf_set_stream(tsdf_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL: back to own) */
+/* adopt the process's NULL ("legacy default") stream, whose handle is 0 and therefore cannot be passed to tsdf_set_stream:
+ * torch.cuda.default_stream().cuda_stream is 0, so this is how a context is ordered with work issued on torch's default
+ * stream (the reference has one implicit GL command stream; this is its HIP counterpart) */
+int32_t tsdf_adopt_null_stream(tsdf_ctx* ctx);
 int32_t tsdf_sync(tsdf_ctx* ctx);
 
 /* ---- inputs ------------------------------------------------------------------------------------ */
@@ -91,6 +95,23 @@ int32_t tsdf_set_calibration(tsdf_ctx* ctx, uint32_t stream,
  * (GRAD_NORMALS, tsdf_raymarch.fs:46). */
 int32_t tsdf_upload_frame(tsdf_ctx* ctx, const float* depth_rg, const float* quality,
                           const float* silhouette, const uint8_t* colour_rgb);
+
+/* Asynchronous upload: NetKinectArray keeps the incoming frame in a double-buffered, mapped PBO (framework/double_pixel_buffer.cpp:18-81:
+ * the reader thread memcpy's into the back buffer, NetKinectArray.cpp:516-520; update() swaps and starts the PBO -> texture
+ * DMA, :225-236).  Here: two device frame slots, a pinned host staging ring and a copy stream.
+ *   tsdf_frame_staging       pinned host pointers of the next upload's staging buffer (the mapped back PBO): a producer that
+ *                            writes the images there pays no extra host copy.  Blocks while that buffer's previous upload is in flight.
+ *   tsdf_upload_frame_async  send the frame to the slot that is NOT current, on the copy stream; returns at once.  NULL (or the
+ *                            staging pointer) = "already in the staging buffer"; other pointers are memcpy'd there first.
+ *                            with_colour = 0 leaves the slot's colour image as it is.
+ *   tsdf_select_frame_slot   make a slot current (update()'s swap): the context's stream waits -- on the GPU -- for the slot's
+ *                            upload; everything queued afterwards reads the new frame.  Also switches between two resident
+ *                            frames without any upload (tsdf_upload_frame fills the current slot). */
+int32_t tsdf_frame_staging(tsdf_ctx* ctx, float** depth_rg, float** quality, float** silhouette, uint8_t** colour_rgb);
+int32_t tsdf_upload_frame_async(tsdf_ctx* ctx, const float* depth_rg, const float* quality, const float* silhouette,
+                                const uint8_t* colour_rgb, int32_t with_colour);
+int32_t tsdf_select_frame_slot(tsdf_ctx* ctx, uint32_t slot);
+int32_t tsdf_current_frame_slot(const tsdf_ctx* ctx, uint32_t* slot);
 
 /* ---- calibration volume files (format only): kinect::CalibrationVolume<T>::read / write,
  * framework/calibration/calibration_volume.hpp:30-38,62-78 -- u32 res[3]; f32 depth_min, depth_max; T[res.x*res.y*res.z].
@@ -215,6 +236,10 @@ int32_t tsdf_download_volume(tsdf_ctx* ctx, float* tsdf);                       
 int32_t tsdf_upload_volume(tsdf_ctx* ctx, const float* tsdf);
 int32_t tsdf_download_bricks(tsdf_ctx* ctx, uint32_t* counters, uint8_t* occupied_flags);
 int32_t tsdf_upload_brick_counters(tsdf_ctx* ctx, const uint32_t* counters);
+/* the 8^3-voxel storage tiles the last culled integrate() computed -- the launch's work units (the reference draws the voxel
+ * lists of the occupied bricks, recon_integration.cpp:254-258): x-fastest tile indices relative to tile layer grid[2];
+ * grid = {tiles along x, tiles along y, first integrated tile layer, number of integrated tiles}.  ids may be NULL (count only) */
+int32_t tsdf_download_active_tiles(tsdf_ctx* ctx, uint32_t* ids, uint32_t capacity, uint32_t* count, uint32_t grid[4]);
 /* raymarch target level 0: rgba [h][w][4], depth [h][w], nsamples [h][w], depth peels [h][w][4]; any may be NULL */
 int32_t tsdf_download_image(tsdf_ctx* ctx, float* rgba, float* depth, float* nsamples, float* peels);
 int32_t tsdf_upload_image(tsdf_ctx* ctx, const float* rgba, const float* depth);
@@ -233,7 +258,9 @@ int32_t tsdf_export_partial_dev(tsdf_ctx* ctx, void* dst_dev);
 /* nearest-hit select over n gathered partial images into this context's raymarch target */
 int32_t tsdf_composite_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n);
 /* The same exchange in compact form: one 32-byte record {pixel, nsamples, depth, pad, rgba} per ray that hit inside this
- * slab, behind a 32-byte header {count, overflow, ...}.  dst must hold 32 + 32 * capacity bytes. */
+ * slab, behind a 32-byte header {records written = min(hits, capacity), hits, overflow flag, ...}.  dst must hold
+ * 32 + 32 * capacity bytes.  The hit list stays valid until the next tsdf_raymarch: a second call with a larger capacity
+ * re-exports the same frame (how the slab driver repairs an under-sized gather without a per-frame host synchronisation). */
 int32_t tsdf_export_hits_dev(tsdf_ctx* ctx, void* dst_dev, uint32_t capacity);
 /* n record buffers, stride_bytes apart, composited into this context's raymarch target (rank 0) */
 int32_t tsdf_composite_hits_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n, uint64_t stride_bytes);

@@ -233,7 +233,16 @@ class ReconIntegrationHip:
             pass
 
     def set_stream(self, hip_stream_ptr):
-        self._ck(self._L.tsdf_set_stream(self._c, C.c_void_p(hip_stream_ptr)))
+        """Adopt a caller-owned HIP stream.  None: back to the context's own stream.  0 is the handle of the process's NULL
+        ("legacy default") stream -- what torch.cuda.default_stream().cuda_stream returns -- and is adopted as such
+        (tsdf_adopt_null_stream); passed to tsdf_set_stream it would mean "back to own" and leave the context's kernels
+        unordered against torch ops and RCCL collectives on the default stream."""
+        if hip_stream_ptr is None:
+            self._ck(self._L.tsdf_set_stream(self._c, None))
+        elif int(hip_stream_ptr) == 0:
+            self._ck(self._L.tsdf_adopt_null_stream(self._c))
+        else:
+            self._ck(self._L.tsdf_set_stream(self._c, C.c_void_p(int(hip_stream_ptr))))
 
     def sync(self):
         self._ck(self._L.tsdf_sync(self._c))
@@ -249,6 +258,31 @@ class ReconIntegrationHip:
         col = np.ascontiguousarray(scene["color"], np.uint8)
         self._ck(self._L.tsdf_upload_frame(self._c, _fp(_f32(scene["depth"])), _fp(_f32(scene["quality"])),
                                            _fp(_f32(scene["silhouette"])), col.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    # asynchronous upload into the frame slot that is not current (double PBO analog) + slot switch
+    def frame_staging(self):
+        """numpy views of the pinned staging buffer of the next upload_frame_async (depth_rg, quality, silhouette, colour)"""
+        h, w, ch, cw = self._dims
+        p = [C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_uint8)()]
+        self._ck(self._L.tsdf_frame_staging(self._c, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(p[3])))
+        return (np.ctypeslib.as_array(p[0], shape=(self.n, h, w, 2)), np.ctypeslib.as_array(p[1], shape=(self.n, h, w)),
+                np.ctypeslib.as_array(p[2], shape=(self.n, h, w)), np.ctypeslib.as_array(p[3], shape=(self.n, ch, cw, 3)))
+
+    def upload_frame_async(self, scene=None, with_colour=True):
+        """scene None: the staging buffer was filled in place (frame_staging)"""
+        if scene is None:
+            self._ck(self._L.tsdf_upload_frame_async(self._c, None, None, None, None, int(with_colour)))
+            return
+        col = np.ascontiguousarray(scene["color"], np.uint8) if with_colour else None
+        self._ck(self._L.tsdf_upload_frame_async(self._c, _fp(_f32(scene["depth"])), _fp(_f32(scene["quality"])), _fp(_f32(scene["silhouette"])),
+                                                 col.ctypes.data_as(C.POINTER(C.c_uint8)) if col is not None else None, int(with_colour)))
+
+    def select_frame_slot(self, slot): self._ck(self._L.tsdf_select_frame_slot(self._c, int(slot)))
+
+    def current_frame_slot(self):
+        s = C.c_uint32()
+        self._ck(self._L.tsdf_current_frame_slot(self._c, C.byref(s)))
+        return s.value
 
     # ------------------------------------------------------------------ NetKinectArray side: raw frame -> processTextures()
     def upload_raw_frame(self, scene):
@@ -383,6 +417,16 @@ class ReconIntegrationHip:
         cnt, fl = np.empty(n, np.uint32), np.empty(n, np.uint8)
         self._ck(self._L.tsdf_download_bricks(self._c, cnt.ctypes.data_as(C.POINTER(C.c_uint32)), fl.ctypes.data_as(C.POINTER(C.c_uint8))))
         return cnt, fl
+
+    def active_tiles(self):
+        """(tile coordinates [n][3] (x, y, z in units of 8 voxels), number of integrated tiles) of the last culled integrate()"""
+        n, grid = C.c_uint32(), (C.c_uint32 * 4)()
+        self._ck(self._L.tsdf_download_active_tiles(self._c, None, 0, C.byref(n), grid))
+        ids = np.zeros(max(1, n.value), np.uint32)
+        self._ck(self._L.tsdf_download_active_tiles(self._c, ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size, C.byref(n), grid))
+        ids = ids[:n.value].astype(np.int64)
+        ntx, nty, tz0 = int(grid[0]), int(grid[1]), int(grid[2])
+        return np.stack([ids % ntx, (ids // ntx) % nty, tz0 + ids // (ntx * nty)], -1), int(grid[3])
 
     def set_counters(self, a):
         a = np.ascontiguousarray(a, np.uint32)

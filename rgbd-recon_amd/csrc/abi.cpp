@@ -60,16 +60,24 @@ struct tsdf_ctx {
   uint32_t* h_num_occupied = nullptr;   // pinned
   // calibration + frame
   StreamTable luts{};
-  std::vector<void*> lut_allocs;
+  void* lut_alloc[TSDF_MAX_STREAMS][3]{};   // per stream: cv_xyz_inv, cv_uv, cv_xyz device copies (freed when the stream is re-calibrated)
   bool have_calib[TSDF_MAX_STREAMS]{};
   // the stream's per-tile LUT box against the integrate kernel's LDS budget: 0 = does not fit (global-memory kernel), 1 = the box fits
   // (direct 8-tap form), 2 = the separable passes' rows and planes fit as well (the fastest form)
   int lds_ok[TSDF_MAX_STREAMS]{};
   int k1_form_cap = 2;           // RR_K1_FORM=1 forces the direct form, 0 the global-memory kernel
-  FrameImages frame{};
-  float* d_depth_plane = nullptr;
+  FrameImages frame{};           // the CURRENT frame slot's images (what mark / integrate / draw read)
+  // Two frame slots (the reference's double PBO + texture arrays, NetKinectArray.cpp:225-236): while the path computes on slot
+  // `cur_slot`, tsdf_upload_frame_async fills the other one on a copy stream; tsdf_select_frame_slot makes it current.
+  struct FrameSlot { float4* dqs = nullptr; float* depth = nullptr; uchar4* color = nullptr; bool have = false;
+                     hipEvent_t ready = nullptr; bool pending = false;      // recorded on the copy stream after the slot's upload + pack
+                     hipEvent_t released = nullptr; bool in_use = false; }; // recorded on the compute stream when the slot stopped being current
+  FrameSlot slots[2];
+  int cur_slot = 0;
+  hipStream_t copy_stream = nullptr;
+  uint8_t* h_stage[2]{}; hipEvent_t stage_done[2]{}; bool stage_busy[2]{}; int stage_k = 0;   // pinned host staging ring of the async upload
   float* d_stage_depth = nullptr; float* d_stage_q = nullptr; float* d_stage_s = nullptr; uint8_t* d_stage_col = nullptr;
-  bool have_frame = false;
+  uint8_t* d_astage = nullptr;   // device staging of the async upload (its own: the copy stream runs beside the compute stream)
   // pre-processing state (NetKinectArray side)
   PreParams pre{};
   float* d_raw = nullptr; float* d_depth2 = nullptr; float2* d_depth_rg = nullptr; float4* d_lab = nullptr; float2* d_depth_b = nullptr; float4* d_normal = nullptr;
@@ -373,6 +381,26 @@ bool make_view_params(const tsdf_ctx* c, const float* mv16, const float* pr16, V
   return true;
 }
 
+// frame slots: device images of one frame {packed depth/quality/silhouette, depth plane, RGBA8 colour}
+int32_t alloc_frame_slot(tsdf_ctx* c, int k) {
+  tsdf_ctx::FrameSlot& S = c->slots[k];
+  if (S.dqs) return TSDF_OK;
+  const size_t np = (size_t)c->cfg.num_streams * c->cfg.depth_w * c->cfg.depth_h, nc = (size_t)c->cfg.num_streams * c->cfg.color_w * c->cfg.color_h;
+  HIP_TRY(c, hipMalloc((void**)&S.dqs, np * sizeof(float4)));
+  HIP_TRY(c, hipMalloc((void**)&S.depth, np * sizeof(float)));
+  HIP_TRY(c, hipMalloc((void**)&S.color, nc * sizeof(uchar4)));
+  HIP_TRY(c, hipMemsetAsync(S.color, 0, nc * sizeof(uchar4), c->stream));
+  HIP_TRY(c, hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+  HIP_TRY(c, hipEventCreateWithFlags(&S.released, hipEventDisableTiming));
+  return TSDF_OK;
+}
+void use_frame_slot(tsdf_ctx* c, int k) {
+  c->cur_slot = k;
+  c->frame.dqs = c->slots[k].dqs; c->frame.depth = c->slots[k].depth; c->frame.color = c->slots[k].color;
+}
+
+int halo_layers_for(float limit, int res_z) { return (int)ceilf((limit * (float)res_z + 2.0f) / 8.0f); }
+
 RayTarget ray_target(tsdf_ctx* c) {
   RayTarget R{};
   if (c->fill_holes) { R.color = c->atlas.color; R.depth = c->atlas.depth; R.stride = c->atlas.aw; R.clear[0] = 0; R.clear[1] = 1; R.clear[2] = 0; R.clear[3] = 0; }
@@ -434,8 +462,11 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if (z0 == 0 && z1 == 0) z1 = (uint32_t)c->res[2];
   if (z1 > (uint32_t)c->res[2] || z0 >= z1 || (z0 % 8) != 0 || (z1 % 8 != 0 && z1 != (uint32_t)c->res[2])) { c->err = "slab range must be tile (8) aligned and inside the volume"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
   V.own_tz0 = (int)z0 / 8; V.own_tz1 = ((int)z1 + 7) / 8;
-  // trilinear + gradient taps reach limit/2 (in unit-cube z) + one voxel past a slab face
-  c->halo_layers = (int)ceilf((cfg->limit * 0.5f * (float)c->res[2] + 2.0f) / 8.0f);
+  // How far past a slab face an owned sample can make this context read (x = limit/2 * res_z voxels = one sampleDistance):
+  // the refined hit position lies up to one step behind the owned sample (tsdf_raymarch.fs:99-101), its gradient taps another
+  // sampleDistance further (:140-149), and the trilinear footprint of that tap half a voxel + one plane beyond:
+  // ceil(2x + 0.5) planes below the face, floor(2x + 0.5) + 1 above.  (limit * res_z + 2) planes cover both.
+  c->halo_layers = halo_layers_for(cfg->limit, c->res[2]);
   const bool whole = (V.own_tz0 == 0 && V.own_tz1 == ntz);
   V.tz0 = whole ? 0 : std::max(0, V.own_tz0 - c->halo_layers);
   V.tz1 = whole ? ntz : std::min(ntz, V.own_tz1 + c->halo_layers);
@@ -485,15 +516,12 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   FrameImages& F = c->frame;
   F.w = (int)cfg->depth_w; F.h = (int)cfg->depth_h; F.cw = (int)cfg->color_w; F.ch = (int)cfg->color_h;
   const size_t np = (size_t)cfg->num_streams * F.w * F.h, nc = (size_t)cfg->num_streams * F.cw * F.ch;
-  if ((rc = tryhip(hipMalloc((void**)&F.dqs, np * sizeof(float4)), "hipMalloc(frame)"))) return fail(rc);
-  if ((rc = tryhip(hipMalloc((void**)&F.color, nc * sizeof(uchar4)), "hipMalloc(colour)"))) return fail(rc);
-  if ((rc = tryhip(hipMalloc(&c->d_depth_plane, np * sizeof(float)), "hipMalloc(depth)"))) return fail(rc);
-  F.depth = c->d_depth_plane;
+  if ((rc = alloc_frame_slot(c, 0))) return fail(rc);
+  use_frame_slot(c, 0);
   if ((rc = tryhip(hipMalloc(&c->d_stage_depth, np * 8), "hipMalloc(stage)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc(&c->d_stage_q, np * 4), "hipMalloc(stage)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc(&c->d_stage_s, np * 4), "hipMalloc(stage)"))) return fail(rc);
   if ((rc = tryhip(hipMalloc(&c->d_stage_col, nc * 3), "hipMalloc(stage)"))) return fail(rc);
-  hipMemsetAsync((void*)F.color, 0, nc * sizeof(uchar4), c->stream);
   c->luts.n = (int)cfg->num_streams;
   c->pre.filter_textures = 1; c->pre.refine = 1;                      // NetKinectArray.cpp:63-69
   if ((rc = setup_view(c, cfg->view_w, cfg->view_h))) return fail(rc);
@@ -505,13 +533,17 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
 int32_t tsdf_destroy(tsdf_ctx* c) {
   CHECK_CTX(c);
   hipSetDevice(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  hipStreamSynchronize(c->stream);          // (a null handle is the NULL stream: tsdf_adopt_null_stream)
   release_view(c); release_bricks(c);
   hipFree(c->tiles.stamp); hipFree(c->d_cls_all); hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts);
-  hipFree(c->vol.data); hipFree(c->vol.slot); hipFree((void*)c->frame.dqs); hipFree((void*)c->frame.color);
+  hipFree(c->vol.data); hipFree(c->vol.slot); 
+  for (auto& sl : c->slots) { hipFree(sl.dqs); hipFree(sl.depth); hipFree(sl.color); if (sl.ready) hipEventDestroy(sl.ready); if (sl.released) hipEventDestroy(sl.released); }
+  for (int k = 0; k < 2; ++k) { if (c->h_stage[k]) hipHostFree(c->h_stage[k]); if (c->stage_done[k]) hipEventDestroy(c->stage_done[k]); }
+  hipFree(c->d_astage);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal);
-  hipFree(c->d_depth_plane); hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
-  for (void* p : c->lut_allocs) hipFree(p);
+  hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
+  for (auto& per : c->lut_alloc) for (void* p : per) hipFree(p);
   if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
   hipFree(c->d_occ_counts);
   for (int k = 0; k < 2; ++k) { if (c->h_wire[k]) hipHostFree(c->h_wire[k]); if (c->wire_done[k]) hipEventDestroy(c->wire_done[k]); }
@@ -535,8 +567,19 @@ int32_t tsdf_sparse_pool_stats(tsdf_ctx* c, uint32_t* need, uint32_t* cap) {
 }
 int32_t tsdf_set_stream(tsdf_ctx* c, void* s) {
   CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stream = s ? (hipStream_t)s : c->own_stream;
+  return TSDF_OK;
+}
+// The process's NULL ("legacy default") stream has the handle 0, which tsdf_set_stream reads as "back to the context's own
+// stream": adopting it needs an entry point of its own.  torch.cuda.default_stream().cuda_stream IS 0, so a caller that wants
+// the context's kernels ordered with torch ops / RCCL collectives issued on torch's default stream must call this one.
+int32_t tsdf_adopt_null_stream(tsdf_ctx* c) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = nullptr;                         // hipStream_t 0: every launch / copy / event record below goes to the NULL stream
   return TSDF_OK;
 }
 int32_t tsdf_sync(tsdf_ctx* c) { CHECK_CTX(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return TSDF_OK; }
@@ -548,29 +591,37 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
   HIP_TRY(c, hipSetDevice(c->device));
   StreamLut& L = c->luts.s[i];
   auto vol_n = [](const uint32_t r[3]) { return (size_t)r[0] * r[1] * r[2]; };
-  for (int a = 0; a < 3; ++a) if (ri[a] < 1 || ri[a] > 2048) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "LUT resolution out of range");
-  if ((uint64_t)ri[0] * ri[1] * ri[2] > (1ull << 31)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "inverse LUT larger than 2^31 texels (the kernels index it with 32 bits)");
+  // every LUT is indexed with 24-bit multiplies per axis and a 32-bit texel index in the kernels: the same bounds for all three
+  auto check_res = [&](const uint32_t r[3], const char* what) -> int32_t {
+    for (int a = 0; a < 3; ++a) if (r[a] < 1 || r[a] > 2048) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "%s resolution out of range [1, 2048]", what);
+    if ((uint64_t)r[0] * r[1] * r[2] > (1ull << 31)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "%s larger than 2^31 texels (the kernels index it with 32 bits)", what);
+    return TSDF_OK;
+  };
+  if (int32_t rc = check_res(ri, "cv_xyz_inv")) return rc;
+  if (uv) { if (!ru) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_uv resolution missing"); if (int32_t rc = check_res(ru, "cv_uv")) return rc; }
+  if (xyz) { if (!rx) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_xyz resolution missing"); if (int32_t rc = check_res(rx, "cv_xyz")) return rc; }
+  // re-calibration of a stream: queued kernels may still read the old volumes; wait, then free what this call replaces
+  if (c->have_calib[i]) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  auto replace = [&](int slot, void* fresh) { if (c->lut_alloc[i][slot]) hipFree(c->lut_alloc[i][slot]); c->lut_alloc[i][slot] = fresh; };
   float4* d_inv = nullptr;
   HIP_TRY(c, hipMalloc(&d_inv, vol_n(ri) * sizeof(float4)));
-  c->lut_allocs.push_back(d_inv);
+  replace(0, d_inv);
   HIP_TRY(c, hipMemcpy(d_inv, inv, vol_n(ri) * sizeof(float4), hipMemcpyHostToDevice));
   L.inv = d_inv; for (int a = 0; a < 3; ++a) L.inv_res[a] = (int)ri[a];
   if (uv) {
-    if (!ru) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_uv resolution missing");
     float2* d = nullptr;
     HIP_TRY(c, hipMalloc(&d, vol_n(ru) * sizeof(float2)));
-    c->lut_allocs.push_back(d);
+    replace(1, d);
     HIP_TRY(c, hipMemcpy(d, uv, vol_n(ru) * sizeof(float2), hipMemcpyHostToDevice));
     L.uv = d; for (int a = 0; a < 3; ++a) L.uv_res[a] = (int)ru[a];
   }
   if (xyz) {
-    if (!rx) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_xyz resolution missing");
     const size_t n = vol_n(rx);
     std::vector<float> padded(n * 4);
     for (size_t k = 0; k < n; ++k) { padded[4 * k] = xyz[3 * k]; padded[4 * k + 1] = xyz[3 * k + 1]; padded[4 * k + 2] = xyz[3 * k + 2]; padded[4 * k + 3] = 0.0f; }
     float4* d = nullptr;
     HIP_TRY(c, hipMalloc(&d, n * sizeof(float4)));
-    c->lut_allocs.push_back(d);
+    replace(2, d);
     HIP_TRY(c, hipMemcpy(d, padded.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     L.xyz = d; for (int a = 0; a < 3; ++a) L.xyz_res[a] = (int)rx[a];
     // CalibVolumes::addVolume builds the sensor's frustum from this volume (CalibVolumes.cpp:122) and getCameraPositions()
@@ -605,15 +656,88 @@ int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quali
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_depth, depth_rg, np * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_q, quality, np * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_s, silhouette, np * 4, hipMemcpyHostToDevice, c->stream));
-  launch_pack_frame(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, c->d_depth_plane, np);
+  launch_pack_frame(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, (float*)c->frame.depth, np);
   if (colour) {
     HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
     launch_pack_color(c->stream, c->d_stage_col, (uchar4*)F.color, nc);
   }
   HIP_TRY(c, hipGetLastError());
-  c->have_frame = true;
+  c->slots[c->cur_slot].have = true;
   return TSDF_OK;
 }
+
+// ---- asynchronous frame upload: NetKinectArray's double PBO (framework/double_pixel_buffer.cpp:18-81; readLoop's memcpy into the
+// mapped back buffer NetKinectArray.cpp:516-520; update() = swap + PBO -> texture DMA, :225-236) as two device frame slots, a pinned
+// host staging ring and a copy stream.  While the path computes on the current slot the next frame travels into the other one.
+static int32_t ensure_async_upload(tsdf_ctx* c) {
+  if (c->copy_stream) return TSDF_OK;
+  const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h, nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
+  const size_t bytes = np * 16 + nc * 3;
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_stage[k], bytes, hipHostMallocDefault));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->stage_done[k], hipEventDisableTiming));
+  }
+  HIP_TRY(c, hipMalloc((void**)&c->d_astage, bytes));
+  if (int32_t rc = alloc_frame_slot(c, 0)) return rc;
+  if (int32_t rc = alloc_frame_slot(c, 1)) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));                             // the new slot's colour memset
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  return TSDF_OK;
+}
+int32_t tsdf_frame_staging(tsdf_ctx* c, float** depth_rg, float** quality, float** silhouette, uint8_t** colour) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int32_t rc = ensure_async_upload(c)) return rc;
+  const int k = c->stage_k;
+  if (c->stage_busy[k]) { HIP_TRY(c, hipEventSynchronize(c->stage_done[k])); c->stage_busy[k] = false; }   // its last upload has left the buffer
+  const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h;
+  uint8_t* b = c->h_stage[k];
+  if (depth_rg) *depth_rg = (float*)b;
+  if (quality) *quality = (float*)(b + np * 8);
+  if (silhouette) *silhouette = (float*)(b + np * 12);
+  if (colour) *colour = b + np * 16;
+  return TSDF_OK;
+}
+int32_t tsdf_upload_frame_async(tsdf_ctx* c, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour, int32_t with_colour) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  float *sd, *sq, *ss; uint8_t* sc;
+  if (int32_t rc = tsdf_frame_staging(c, &sd, &sq, &ss, &sc)) return rc;   // (waits for the staging buffer)
+  const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h, nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
+  // NULL (or the staging pointer itself): the producer wrote the staging buffer in place, as readLoop() writes the mapped PBO
+  if (depth_rg && depth_rg != sd) memcpy(sd, depth_rg, np * 8);
+  if (quality && quality != sq) memcpy(sq, quality, np * 4);
+  if (silhouette && silhouette != ss) memcpy(ss, silhouette, np * 4);
+  if (colour && colour != sc) { memcpy(sc, colour, nc * 3); with_colour = 1; }
+  const int k = c->stage_k, t = c->cur_slot ^ 1;
+  tsdf_ctx::FrameSlot& S = c->slots[t];
+  if (S.in_use) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, S.released, 0));   // the path's reads of slot t were all queued before `released`
+  const size_t bytes = np * 16 + (with_colour ? nc * 3 : 0);
+  HIP_TRY(c, hipMemcpyAsync(c->d_astage, c->h_stage[k], bytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(c, hipEventRecord(c->stage_done[k], c->copy_stream));
+  c->stage_busy[k] = true; c->stage_k ^= 1;
+  launch_pack_frame(c->copy_stream, (const float*)c->d_astage, (const float*)(c->d_astage + np * 8), (const float*)(c->d_astage + np * 12), S.dqs, S.depth, np);
+  if (with_colour) launch_pack_color(c->copy_stream, c->d_astage + np * 16, S.color, nc);
+  HIP_TRY(c, hipEventRecord(S.ready, c->copy_stream));
+  S.pending = true; S.have = true;
+  HIP_TRY(c, hipGetLastError());
+  return TSDF_OK;
+}
+int32_t tsdf_select_frame_slot(tsdf_ctx* c, uint32_t slot) {
+  CHECK_CTX(c);
+  if (slot > 1) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "frame slot must be 0 or 1");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int32_t rc = alloc_frame_slot(c, (int)slot)) return rc;
+  tsdf_ctx::FrameSlot& N = c->slots[slot];
+  if ((int)slot != c->cur_slot) {
+    tsdf_ctx::FrameSlot& O = c->slots[c->cur_slot];
+    if (O.released) { HIP_TRY(c, hipEventRecord(O.released, c->stream)); O.in_use = true; }
+  }
+  if (N.pending) { HIP_TRY(c, hipStreamWaitEvent(c->stream, N.ready, 0)); N.pending = false; }   // the path waits on the GPU, not on the host
+  use_frame_slot(c, (int)slot);
+  return TSDF_OK;
+}
+int32_t tsdf_current_frame_slot(const tsdf_ctx* c, uint32_t* slot) { CHECK_CTX(c); if (!slot) return TSDF_ERR_INVALID_ARGUMENT; *slot = (uint32_t)c->cur_slot; return TSDF_OK; }
 
 // ---- image pre-processing (NetKinectArray::processTextures)
 static int32_t ensure_pre_buffers(tsdf_ctx* c) {
@@ -759,12 +883,12 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
   PreBuffers B{};
   B.raw = c->d_raw; B.depth2 = c->d_depth2; B.fdepth = c->use_processed_depth ? c->d_depth2 : c->d_raw;
   B.depth_rg = c->d_depth_rg; B.lab = c->d_lab; B.depth_b = c->d_depth_b; B.normal = c->d_normal;
-  B.dqs = (float4*)c->frame.dqs; B.depth_plane = c->d_depth_plane;
+  B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
   timer_begin(c, "1preprocess");
   launch_preprocess(c->stream, P, B, c->luts, c->frame, c->br);
   timer_end(c, "1preprocess");
   HIP_TRY(c, hipGetLastError());
-  c->have_frame = true;
+  c->slots[c->cur_slot].have = true;
   return TSDF_OK;
 }
 int32_t tsdf_download_preprocessed(tsdf_ctx* c, float* depth2, float* depth_rg, float* lab, float* depth_b, float* sil, float* normals, float* quality) {
@@ -786,7 +910,7 @@ int32_t tsdf_download_preprocessed(tsdf_ctx* c, float* depth2, float* depth_rg, 
 }
 
 static int32_t require_inputs(tsdf_ctx* c, bool need_xyz, bool need_uv) {
-  if (!c->have_frame) FAIL(c, TSDF_ERR_STATE, "no frame uploaded (tsdf_upload_frame)");
+  if (!c->slots[c->cur_slot].have) FAIL(c, TSDF_ERR_STATE, "no frame uploaded (tsdf_upload_frame)");
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) {
     if (!c->have_calib[i]) FAIL(c, TSDF_ERR_STATE, "stream %u has no calibration (tsdf_set_calibration)", i);
     if (need_xyz && !c->luts.s[i].xyz) FAIL(c, TSDF_ERR_STATE, "stream %u has no cv_xyz volume", i);
@@ -958,7 +1082,7 @@ int32_t tsdf_draw_points(tsdf_ctx* c, const float* mv, const float* pr) {
   Q.normals = c->d_normal;
   if (!c->d_comp_key) HIP_TRY(c, hipMalloc(&c->d_comp_key, (size_t)c->vw * c->vh * sizeof(unsigned long long)));
   FrameImages F = c->frame;
-  F.depth = c->d_depth_plane;
+  F.depth = (float*)c->frame.depth;
   timer_begin(c, "points");
   launch_draw_points(c->stream, P, Q, c->luts, F, c->d_comp_key, c->d_fb_c, c->d_fb_d);
   timer_end(c, "points");
@@ -1020,7 +1144,7 @@ int32_t tsdf_set_tsdf_limit(tsdf_ctx* c, float limit) {
   CHECK_CTX(c);
   if (!(limit > 0.0f)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit must be > 0");
   const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
-  if (!whole && (int)ceilf((limit * 0.5f * (float)c->res[2] + 2.0f) / 8.0f) > c->halo_layers) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit needs a wider slab halo than this context allocated");
+  if (!whole && halo_layers_for(limit, c->res[2]) > c->halo_layers) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit needs a wider slab halo than this context allocated");
   c->vol.limit = limit;
   launch_mark_all_mixed(c->stream, c->tiles);    // the clear value changed: no tile is known to hold it
   c->full_classify = true;
@@ -1090,6 +1214,21 @@ int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
   launch_mark_all_mixed(c->stream, c->tiles);
   c->full_classify = true;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSDF_OK;
+}
+// the storage tiles the last culled integrate() computed (its compacted work list): ids are x-fastest tile indices relative to
+// the first integrated tile layer; grid = {tiles along x, tiles along y, first integrated tile layer, integrated tiles}
+int32_t tsdf_download_active_tiles(tsdf_ctx* c, uint32_t* ids, uint32_t capacity, uint32_t* count, uint32_t grid[4]) {
+  CHECK_CTX(c);
+  if (!count) return TSDF_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int p = c->tile_parity ^ 1;                                       // integrate() flipped the parity after its launches
+  uint32_t n = 0;
+  HIP_TRY(c, hipMemcpy(&n, c->d_tile_counts + p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  *count = n;
+  if (grid) { grid[0] = (uint32_t)c->vol.ntx; grid[1] = (uint32_t)c->vol.nty; grid[2] = (uint32_t)c->vol.int_tz0; grid[3] = (uint32_t)c->tiles.n; }
+  if (ids && capacity) HIP_TRY(c, hipMemcpy(ids, c->d_tile_list[p], (size_t)std::min(n, capacity) * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return TSDF_OK;
 }
 int32_t tsdf_download_bricks(tsdf_ctx* c, uint32_t* counters, uint8_t* flags) {

@@ -643,11 +643,12 @@ namespace rr {
 // ---- compact exchange: instead of 24 B for every view pixel, a slab ships one 32-byte record per ray that hit in it
 struct HitRecord { uint32_t pix; float ns; float depth; uint32_t pad; float4 color; };
 static_assert(sizeof(HitRecord) == 32, "HitRecord is 32 bytes");
-// buffer = [count, overflow, 6 pad words][records...]
+// buffer = [written, hit, overflow, 5 pad words][records...]
 __global__ __launch_bounds__(256) void k_export_hits(RayTarget R, int w, const Hit* __restrict__ hits, const uint32_t* __restrict__ hit_count,
                                                      uint32_t* __restrict__ header, HitRecord* __restrict__ rec, uint32_t capacity) {
   const uint32_t n_hits = *hit_count, n = n_hits < capacity ? n_hits : capacity;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { header[0] = n; header[1] = n_hits > capacity ? 1u : 0u; }
+  // header: [records written, rays that hit (may exceed the capacity: the receiver then asks again with a larger one), overflow flag]
+  if (blockIdx.x == 0 && threadIdx.x == 0) { header[0] = n; header[1] = n_hits; header[2] = n_hits > capacity ? 1u : 0u; }
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t pix = hits[i].pix;
     const int px = (int)(pix % (uint32_t)w), py = (int)(pix / (uint32_t)w);

@@ -18,8 +18,22 @@ no multi-GPU path at all; what is partitioned here is the reference's single vol
 
 The exchange works on plain device pointers across the C ABI (tsdf_halo_*_dev, tsdf_export_partial_dev,
 tsdf_composite_dev); torch only owns the buffers and the collective.
+
+Stream order.  The backend's kernels and torch's collectives must share ONE stream: the driver creates an explicit
+`torch.cuda.Stream`, hands its (non-zero) handle to the backend and issues every collective under
+`torch.cuda.stream(...)`.  (torch's default stream has the handle 0, which `tsdf_set_stream` reads as "back to the
+context's own stream": a driver that passed it left the kernels on a private non-blocking stream, unordered against the
+collectives.  binding.set_stream now maps 0 to tsdf_adopt_null_stream, and this driver does not rely on it.)
+
+No host synchronisation per frame.  The compact composite gathers a FIXED number of records per rank, decided from the
+all-gathered hit counts of the frame `LAG` frames earlier (identical on every rank, read from a pinned copy whose event
+completed long ago) times 1.5.  A frame whose slab hit more rays than that is detected from the same counts: `finish()`
+-- the call that precedes any read of the result -- re-exports and re-gathers that frame with the exact size, so results
+never depend on the guess.  All ranks see the same counts, so they take the same decision at the same frame.
 """
 from __future__ import annotations
+
+import contextlib
 
 import torch
 import torch.distributed as dist
@@ -44,34 +58,57 @@ class SlabDriver:
     halo       "exchange": all-gather of the boundary tile layers before the raymarch (the backend must NOT have been
                created with recompute_halo); "recompute": the backend integrates its own halo layers, no collective.
     composite  "dense": every rank ships 24 B per view pixel to rank 0; "compact": one 32-byte record per ray that hit in
-               the slab (the counts travel first so that only max(count) records per rank are gathered).
+               the slab, a fixed number per rank and frame (see the module docstring).
     exchange_when_alone   world == 1 normally draws the frame directly; True runs the whole exchange (pack, collectives, composite)
                with the one rank anyway -- used to drive the RCCL calls on a box with a single GPU.
+    stream     the torch stream everything runs on (default: a new one).  CUDA buffers only.
+    min_capacity  smallest number of hit records gathered per rank (compact composite).
     """
 
+    LAG = 2            # frames between a hit count and its use as the gather size: its pinned copy has long arrived, the host never waits
+
     def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense", preprocess=False,
-                 exchange_when_alone=False):
+                 exchange_when_alone=False, stream=None, min_capacity=4096):
         assert halo in ("exchange", "recompute") and composite in ("dense", "compact")
         self.b, self.rank, self.world, self.dev, self.group = backend, rank, world, torch.device(buf_device), group
         self.view, self.halo, self.composite = view, halo, composite
         self.preprocess = preprocess          # frames start from the raw sensor images: processTextures() instead of markBricks()
         self.exchanging = world > 1 or exchange_when_alone
         self.stage_cpu = self.exchanging and dist.get_backend(group) == "gloo" and self.dev.type == "cuda"
+        self.stream = None
+        if self.dev.type == "cuda":
+            self.stream = stream if stream is not None else torch.cuda.Stream(self.dev)
+            assert self.stream.cuda_stream != 0, "the NULL stream cannot be handed to tsdf_set_stream"
+            backend.set_stream(self.stream.cuda_stream)
+        self.frame_no = 0
+        self.last = None                      # (frame number, gathered capacity) of the latest compact frame, until finish() has checked it
+        self.regathers = 0                    # frames whose first gather was too small (finish() repaired them)
+        self.min_capacity = int(min_capacity)
         if self.exchanging:
             npx = view[0] * view[1]
-            if halo == "exchange":
-                layers, nbytes = backend.halo_info()
-                n = nbytes // 4
-                self.send = torch.empty((2, n), dtype=torch.float32, device=self.dev)
-                self.gath = torch.empty((world, 2, n), dtype=torch.float32, device=self.dev)
-            if composite == "dense":
-                self.part = torch.empty(npx * 6, dtype=torch.float32, device=self.dev)          # 24 B / pixel
-                self.parts = torch.empty((world, npx * 6), dtype=torch.float32, device=self.dev) if rank == 0 else None
-            else:
-                self.cap = npx                                                                   # a slab cannot hit more rays than there are pixels
-                self.hitbuf = torch.zeros(8 + npx * 8, dtype=torch.float32, device=self.dev)     # 32 B header + 32 B records
-                self.hitparts = torch.zeros((world, 8 + npx * 8), dtype=torch.float32, device=self.dev) if rank == 0 else None
-                self.counts = torch.zeros((world, 2), dtype=torch.int32, device=self.dev)
+            self.npx = npx
+            with self._on_stream():
+                if halo == "exchange":
+                    layers, nbytes = backend.halo_info()
+                    n = nbytes // 4
+                    self.send = torch.empty((2, n), dtype=torch.float32, device=self.dev)
+                    self.gath = torch.empty((world, 2, n), dtype=torch.float32, device=self.dev)
+                if composite == "dense":
+                    self.part = torch.empty(npx * 6, dtype=torch.float32, device=self.dev)          # 24 B / pixel
+                    self.parts = torch.empty((world, npx * 6), dtype=torch.float32, device=self.dev) if rank == 0 else None
+                else:
+                    self.hitbuf = torch.zeros(8 + npx * 8, dtype=torch.float32, device=self.dev)     # 32 B header + 32 B records; a slab cannot hit more rays than there are pixels
+                    self.hitparts = torch.zeros((world, 8 + npx * 8), dtype=torch.float32, device=self.dev) if rank == 0 else None
+                    self.counts = torch.zeros((world, 2), dtype=torch.int32, device=self.dev)        # per rank: [records written, rays hit]
+                    ring = self.LAG + 1
+                    self.counts_host = [torch.zeros((world, 2), dtype=torch.int32, pin_memory=(self.dev.type == "cuda")) for _ in range(ring)]
+                    self.counts_evt = [None] * ring
+            if self.stream is not None:
+                self.stream.synchronize()
+
+    # ------------------------------------------------------------------ plumbing
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def _all_gather(self, out, inp):
         if self.stage_cpu:
@@ -79,7 +116,7 @@ class SlabDriver:
             dist.all_gather_into_tensor(o, inp.reshape(-1).cpu(), group=self.group)
             out.view(-1).copy_(o)
         else:
-            dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
+            dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1), group=self.group)
 
     def _gather0(self, out_rows, inp):
         """gather `inp` (1-D) of every rank into out_rows[r] (1-D views of equal length) on rank 0"""
@@ -100,7 +137,45 @@ class SlabDriver:
         above = self.gath[self.rank + 1, 0].data_ptr() if self.rank < self.world - 1 else 0
         b.halo_unpack_dev(below, above)
 
+    # ------------------------------------------------------------------ compact composite: sizes without a host sync
+    def _counts_of(self, f):
+        """the all-gathered [written, hit] counts of frame f on the host (waits for their pinned copy: for f <= now - LAG it arrived long ago)"""
+        slot = f % (self.LAG + 1)
+        if self.counts_evt[slot] is not None:
+            self.counts_evt[slot].synchronize()
+        return self.counts_host[slot]
+
+    def _capacity(self, f):
+        """records gathered per rank for frame f: 1.5 x the largest per-rank hit count of frame f - LAG (the same number on every rank)"""
+        if f < self.LAG:
+            return self.npx                                # no history yet: a slab cannot hit more rays than there are pixels
+        m = int(self._counts_of(f - self.LAG)[:, 1].max())
+        cap = max(self.min_capacity, ((m * 3) // 2 + 1024 + 1023) // 1024 * 1024)
+        return min(cap, self.npx)
+
+    def _exchange_hits(self, cap, record_counts_of=None):
+        b = self.b
+        b.export_hits_dev(self.hitbuf.data_ptr(), cap)
+        if record_counts_of is not None:
+            self._all_gather(self.counts, self.hitbuf[:2].view(torch.int32))
+            slot = record_counts_of % (self.LAG + 1)
+            self.counts_host[slot].copy_(self.counts, non_blocking=True)
+            if self.stream is not None:
+                ev = self.counts_evt[slot] or torch.cuda.Event()
+                ev.record(self.stream)
+                self.counts_evt[slot] = ev
+        n = 8 + cap * 8
+        self._gather0([self.hitparts[r, :n] for r in range(self.world)] if self.rank == 0 else None, self.hitbuf[:n])
+        if self.rank == 0:
+            b.composite_hits_dev(self.hitparts.data_ptr(), self.world, self.hitparts.stride(0) * 4)
+            b.fillColors()
+
+    # ------------------------------------------------------------------ per frame
     def frame(self, mv, proj):
+        with self._on_stream():
+            self._frame(mv, proj)
+
+    def _frame(self, mv, proj):
         b = self.b
         b.clearOccupiedBricks()
         if self.preprocess:
@@ -122,14 +197,27 @@ class SlabDriver:
                 b.composite_dev(self.parts.data_ptr(), self.world)
                 b.fillColors()
             return
-        b.export_hits_dev(self.hitbuf.data_ptr(), self.cap)
-        self._all_gather(self.counts, self.hitbuf[:2].view(torch.int32))
-        m = int(self.counts[:, 0].max().item())                        # the one host synchronisation of the exchange
-        n = 8 + m * 8
-        self._gather0([self.hitparts[r, :n] for r in range(self.world)] if self.rank == 0 else None, self.hitbuf[:n])
-        if self.rank == 0:
-            b.composite_hits_dev(self.hitparts.data_ptr(), self.world, self.hitparts.stride(0) * 4)
-            b.fillColors()
+        f = self.frame_no
+        cap = self._capacity(f)
+        self._exchange_hits(cap, record_counts_of=f)
+        self.last = (f, cap)
+        self.frame_no = f + 1
+
+    def finish(self):
+        """Completes the latest frame: call before reading its result (and at the end of a timed region).  A COLLECTIVE when
+        the compact gather of that frame turned out too small -- every rank sees the same counts and re-gathers together."""
+        if self.exchanging and self.composite == "compact" and self.last is not None:
+            f, cap = self.last
+            self.last = None
+            m = int(self._counts_of(f)[:, 1].max())
+            if m > cap:
+                self.regathers += 1
+                with self._on_stream():
+                    self._exchange_hits(min(self.npx, m))
+        if self.stream is not None:
+            self.stream.synchronize()
+        else:
+            self.b.sync() if hasattr(self.b, "sync") else None
 
 
 def frame_slabs_on_one_device(backends, mv, proj, device, halo="exchange", composite="dense"):
@@ -148,6 +236,7 @@ def frame_slabs_on_one_device(backends, mv, proj, device, halo="exchange", compo
             b.halo_pack_dev(faces[k, 0].data_ptr(), faces[k, 1].data_ptr())
         b.sync()
     parts = torch.zeros((world, npx * 6 if composite == "dense" else 8 + npx * 8), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()                      # the contexts run on their own streams: the buffers must exist before they write them
     for k, b in enumerate(backends):
         if halo == "exchange":
             below = faces[k - 1, 1].data_ptr() if k > 0 else 0

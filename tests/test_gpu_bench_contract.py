@@ -30,6 +30,33 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 and r["achieved"] > 0 and (r["traffic"] is None or r["traffic"] > 0)
+    # algorithmic bytes are those of the units the launch processes (active tiles), not the dense volume: a fraction of the peak
+    assert 0.0 < r["frac"] < 1.0 and r["algorithmic_bytes"] < 200e6 and abs(r["achieved"] - r["algorithmic_bytes"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    # the dense configuration's two kernels ride along in the same line
+    c1 = d["roofline_c1"]
+    for k, dense in (("integrate", 4 * 256 ** 3 + 4 * 16 * 128 ** 3 + 4 * 16 * 640 * 480), ("march", 4 * 256 ** 3 + 24 * 1280 * 720)):
+        assert c1[k]["algorithmic_bytes"] == dense and 0.0 < c1[k]["frac"] < 1.0 and c1[k]["avg_launch_ms"] > 0
+    # value is the moving-scene rate (two resident frames alternating); the static best case is reported beside it
+    assert "alternating" in d["config"]["scene"] and d["static"]["value"] > 0 and d["long_run"]["steps"] >= 1000
+    assert d["pcie_overlapped"]["frames_per_s"] > d["pcie_inclusive_frames_per_s"] * 0.9
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
     assert d["value"] > 100 * c["value"]                                        # the GPU line is not the oracle's
+
+
+@pytest.mark.timeout(1500)
+def test_bench_with_two_ranks_runs_the_slab_partition_by_default():
+    """`--gpus 2` without further flags = ONE volume in two Z-slabs, strong scaling, and the run itself checks the composite against
+    an unpartitioned context before timing.  Two processes on the one GPU of the box, gloo standing in for RCCL (RCCL refuses two
+    ranks on one device): everything else is the driver's command."""
+    env = dict(os.environ, RR_BENCH_BACKEND="gloo", RR_BENCH_DEVICE="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--long-steps", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1400, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "Z-slabs" in d["config"]["parallelism"]
+    assert "bit-identical" in d["slab_check"] and d["regathers"] == 0
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"] and d["value"] > 30.0

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 KW = dict(res=(64, 64, 64), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(160, 90))
 
 
-def _worker(rank, world, port, q, halo, composite):
+def _worker(rank, world, port, q, halo, composite, tiny_capacity=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
@@ -25,12 +25,16 @@ def _worker(rank, world, port, q, halo, composite):
         scene = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
         mv, pr = rr.scene.default_view(*KW["view"])
         hip = rr.ReconIntegrationHip(scene, slab=mgpu.slab_range(KW["res"][2], rank, world), recompute_halo=(halo == "recompute"), **KW)
-        hip.set_stream(torch.cuda.current_stream().cuda_stream)
-        drv = mgpu.SlabDriver(hip, rank, world, "cuda:0", view=KW["view"], halo=halo, composite=composite)
-        for _ in range(2):                       # two frames: buffers are reused
+        drv = mgpu.SlabDriver(hip, rank, world, "cuda:0", view=KW["view"], halo=halo, composite=composite)      # (creates and hands over its own torch stream)
+        if tiny_capacity:
+            drv._capacity = lambda f: 64             # every gather is too small: finish() has to repair each frame it is asked about
+        for _ in range(5):                           # past the LAG frames that gather the full capacity; buffers are reused
             drv.frame(mv, pr)
+        drv.finish()
         torch.cuda.synchronize()
         ok = True
+        if tiny_capacity:
+            ok &= drv.regathers == 1
         if rank == 0:
             whole = rr.ReconIntegrationHip(scene, **KW)
             whole.clearOccupiedBricks(); whole.markBricks(); whole.updateOccupiedBricks()
@@ -47,15 +51,15 @@ def _worker(rank, world, port, q, halo, composite):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("halo,composite", [("exchange", "dense"), ("recompute", "compact")])
-def test_two_rank_slab_driver_matches_single_context(halo, composite):
+@pytest.mark.parametrize("halo,composite,tiny", [("exchange", "dense", False), ("recompute", "compact", False), ("recompute", "compact", True)])
+def test_two_rank_slab_driver_matches_single_context(halo, composite, tiny):
     import torch                     # first import on a fresh box takes minutes: pay it here, not in both children at once
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, halo, composite)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, halo, composite, tiny)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -76,10 +80,10 @@ def _rccl_alone(port, q, halo, composite):
         scene = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
         mv, pr = rr.scene.default_view(*KW["view"])
         hip = rr.ReconIntegrationHip(scene, slab=mgpu.slab_range(KW["res"][2], 0, 1), recompute_halo=(halo == "recompute"), **KW)
-        hip.set_stream(torch.cuda.current_stream().cuda_stream)
         drv = mgpu.SlabDriver(hip, 0, 1, "cuda:0", view=KW["view"], halo=halo, composite=composite, exchange_when_alone=True)
-        for _ in range(3):
+        for _ in range(5):
             drv.frame(mv, pr)
+        drv.finish()
         dist.barrier()
         t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")                          # bench.py's max-over-ranks reduction
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -26,6 +26,8 @@ class FakeSlab:
         self.vol = np.full((self.lo + own + self.hi, TILE_LAYER), np.nan, np.float32)
         self.calls = []
         self.result = None
+        self.exports = []
+        self.extra_hits = 0
 
     # per-frame operator surface (no-ops except integrate/draw)
     def clearOccupiedBricks(self): self.calls.append("clear")
@@ -75,6 +77,43 @@ class FakeSlab:
                            colour=np.where(any_hit, buf[best, np.arange(npx) * 4], 0.0))
         self.calls.append("composite")
 
+    # compact exchange (tsdf_export_hits_dev / tsdf_composite_hits_dev): 32-byte header {written, hit, overflow} + 32-byte records
+    def export_hits_dev(self, ptr, cap):
+        npx = VIEW[0] * VIEW[1]
+        ns = self.partial[npx * 5:]
+        pix = np.nonzero(ns > 0)[0]
+        if self.extra_hits:                                # frames with many more hits than the history predicts
+            pix = np.concatenate([pix, np.repeat(pix[:1], self.extra_hits)])
+        n = min(pix.size, cap)
+        buf = np.zeros(8 + cap * 8, np.float32)
+        hdr = buf[:8].view(np.uint32)
+        hdr[0], hdr[1], hdr[2] = n, pix.size, int(pix.size > cap)
+        rec = buf[8:].reshape(cap, 8)
+        rec[:n, 0] = pix[:n].astype(np.uint32).view(np.float32)
+        rec[:n, 1] = ns[pix[:n]]
+        rec[:n, 2] = self.partial[npx * 4:npx * 5][pix[:n]]
+        rec[:n, 4:] = self.partial[:npx * 4].reshape(npx, 4)[pix[:n]]
+        ctypes.memmove(ptr, buf.ctypes.data, buf.nbytes)
+        self.exports.append((cap, int(pix.size)))
+
+    def composite_hits_dev(self, ptr, n, stride_bytes):
+        npx = VIEW[0] * VIEW[1]
+        best = np.full(npx, np.inf)
+        rank_of = np.full(npx, -1)
+        colour = np.zeros(npx)
+        for r in range(n):
+            base = ctypes.cast(ptr + r * stride_bytes, ctypes.POINTER(ctypes.c_float))
+            hdr = np.ctypeslib.as_array(base, shape=(8,)).view(np.uint32)
+            cnt = int(hdr[0])
+            rec = np.ctypeslib.as_array(base, shape=(8 + cnt * 8,))[8:].reshape(cnt, 8)
+            for k in range(cnt):
+                p = int(rec[k, 0:1].view(np.uint32)[0])
+                if rec[k, 1] < best[p]:
+                    best[p], rank_of[p], colour[p] = rec[k, 1], r, rec[k, 4]
+        self.result = dict(rank_of_pixel=rank_of, ns=best, colour=colour)
+        self.calls.append("composite")
+
+    def sync(self): pass
     def fillColors(self): self.calls.append("fill")
     def drawF(self, mv, proj): self.calls.append("drawF")
 
@@ -143,3 +182,81 @@ def test_slab_range_partitions_tile_layers():
         sizes = [(hi - lo + 7) // 8 for lo, hi in r]
         assert max(sizes) - min(sizes) <= 1
     assert mgpu.slab_range(512, 3, 8) == (192, 256)
+
+
+def _compact_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mgpu = import_module("rgbd-recon_amd.multigpu")
+        fake = FakeSlab(rank, world)
+        drv = mgpu.SlabDriver(fake, rank, world, "cpu", view=VIEW, halo="recompute", composite="compact", min_capacity=4)
+        npx = VIEW[0] * VIEW[1]
+        p = np.arange(npx)
+        hits = p % 3 != 2
+
+        def check():
+            r = fake.result
+            return bool((r["rank_of_pixel"][hits] == (p % world)[hits]).all()) and bool((r["rank_of_pixel"][~hits] == -1).all()) and \
+                bool(np.allclose(r["ns"][hits], ((p + 1) * 0.0027)[hits])) and bool((r["colour"][hits] == (p % world + 1)[hits]).all())
+
+        ok = True
+        for f in range(6):
+            drv.frame(None, None)
+        drv.finish()
+        # frames 0, 1 (no history) gather the full capacity; from frame LAG on: max(min_capacity, 1.5 x hits of frame f - LAG + 1024 rounded), capped at npx
+        caps = [c for c, _ in fake.exports]
+        ok &= caps[:2] == [npx, npx] and all(c == npx for c in caps)          # the 1024-record margin exceeds this 32-pixel view: full size, never a regather
+        ok &= drv.regathers == 0
+        if rank == 0:
+            ok &= check()
+        # a capacity rule that under-sizes every gather (what a frame with many more hits than two frames ago looks like): the
+        # result is only right once finish() has re-gathered -- a collective decision taken from the all-gathered counts
+        drv._capacity = lambda f: 2
+        n0 = len(fake.exports)
+        for f in range(3):
+            drv.frame(None, None)
+        if rank == 0:
+            ok &= not check()                                                 # two records per rank are not the frame
+        drv.finish()
+        ok &= drv.regathers == 1 and len(fake.exports) == n0 + 4              # three frames + ONE re-export, with the exact size
+        ok &= fake.exports[-1][0] == max(int(((p % world == r) & hits).sum()) + int(((p % world != r) & hits & (p % 5 == 0)).sum()) for r in range(world))
+        if rank == 0:
+            ok &= check()
+        drv.finish()                                                          # idempotent
+        ok &= drv.regathers == 1
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_compact_composite_sizes_its_gather_without_a_host_sync_and_repairs_overflow():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compact_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
+def test_capacity_rule():
+    """1.5 x the largest per-rank hit count of LAG frames ago + 1024, rounded up to 1024, at least min_capacity, at most every pixel"""
+    mgpu = import_module("rgbd-recon_amd.multigpu")
+
+    class D(mgpu.SlabDriver):
+        def __init__(self, counts, npx, min_capacity):
+            self.npx, self.min_capacity, self._c = npx, min_capacity, counts
+
+        def _counts_of(self, f):
+            return torch.tensor(self._c[f], dtype=torch.int32)
+
+    d = D({0: [[10, 10], [7000, 9000]], 1: [[0, 0], [0, 0]], 5: [[1, 900000], [1, 5]]}, 921600, 4096)
+    assert d._capacity(0) == 921600 and d._capacity(1) == 921600              # no history
+    assert d._capacity(2) == 15360                                            # 1.5 * 9000 + 1024 = 14524 -> the next multiple of 1024
+    assert d._capacity(3) == 4096                                             # nothing hit two frames ago: the floor
+    assert d._capacity(7) == 921600                                           # capped at one record per pixel
