@@ -65,7 +65,8 @@ struct tsdf_ctx {
   // the stream's per-tile LUT box against the integrate kernel's LDS budget: 0 = does not fit (global-memory kernel), 1 = the box fits
   // (direct 8-tap form), 2 = the separable passes' rows and planes fit as well (the fastest form)
   int lds_ok[TSDF_MAX_STREAMS]{};
-  int k1_form_cap = 2;           // RR_K1_FORM=1 forces the direct form, 0 the global-memory kernel
+  int k1_form_cap = 3;           // RR_K1_FORM: 3 = wave-per-stream separable form (default where it fits), 2 = separable, 1 = direct 8-tap form, 0 = global-memory kernel
+  int ws_box[TSDF_MAX_STREAMS]{}, ws_row[TSDF_MAX_STREAMS]{};   // per stream: LDS float4 of the wave-per-stream form for the worst tile box
   FrameImages frame{};           // the CURRENT frame slot's images (what mark / integrate / draw read)
   // Two frame slots (the reference's double PBO + texture arrays, NetKinectArray.cpp:225-236): while the path computes on slot
   // `cur_slot`, tsdf_upload_frame_async fills the other one on a copy stream; tsdf_select_frame_slot makes it current.
@@ -642,6 +643,8 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
     auto idx1 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k + 1, 0), n - 1); };
     for (int t = 0; t * 8 < c->res[a]; ++t) worst[a] = std::max(worst[a], idx1(std::min(t * 8 + 7, c->res[a] - 1)) - idx0(t * 8) + 1);
   }
+  c->ws_box[i] = std::max(worst[0] * worst[1] * worst[2], worst[2] * 64);
+  c->ws_row[i] = worst[1] * worst[2] * 8;
   c->lds_ok[i] = worst[0] * worst[1] * worst[2] > integrate_box_cap() ? 0 : ((worst[1] * worst[2] * 8 <= integrate_row_cap() && worst[2] * 64 <= integrate_box_cap()) ? 2 : 1);
   c->have_calib[i] = true;
   return TSDF_OK;
@@ -969,6 +972,10 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   timer_begin(c, "2integrate");
   int lds = 2;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = std::min(lds, c->lds_ok[i]);
+  // the wave-per-stream form needs the separable form's preconditions and 4 x (box + rows) float4 of dynamic LDS within 64 KiB
+  int ws_box = 0, ws_row = 0;
+  for (uint32_t i = 0; i < c->cfg.num_streams; ++i) { ws_box = std::max(ws_box, c->ws_box[i]); ws_row = std::max(ws_row, c->ws_row[i]); }
+  if (lds == 2 && (size_t)4 * (ws_box + ws_row) * 16 <= 60 * 1024) lds = 3;
   lds = std::min(lds, c->k1_form_cap);
   if (c->use_bricks) {
     // this frame's list / count, the previous integrate()'s (trusted unless something else may have written the volume)
@@ -992,9 +999,9 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     pc.zero = c->d_counters[c->counters_cur ^ 1]; pc.zero_words = (uint32_t)c->counter_words;
     c->spare_clean = true;
   }
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc, ws_box, ws_row);
   timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 2);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 2, nullptr, ws_box, ws_row);
   timer_end(c, "k_integrate_tiles");
   if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
   else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them

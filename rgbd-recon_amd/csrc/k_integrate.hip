@@ -393,8 +393,153 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
   }
 }
 
+
+// Wave-per-stream form (round 2).  The separable form above walks the streams one after another and separates its phases with
+// workgroup barriers: a tile is a chain of ~4 barriers and two dependent round trips (LUT box, image gather) PER STREAM, ~21 us for
+// a 4-stream tile at c2, and the launch lasts (tiles / resident workgroups) x that chain.  Here the four waves of the workgroup take
+// one stream each: wave w evaluates the filter set-up, copies the texel box and runs the X and Y passes of stream (chunk + w)
+// entirely by itself -- LDS traffic of one wave is processed in order, so these phases need no workgroup barrier, and the four
+// streams' box loads are in flight together.  One barrier later every thread reads the y-lerped planes of all four streams, issues
+// the four image gathers of a voxel together and applies the fusion rule in stream order.  Two barriers per tile and chunk of four
+// streams instead of ~17, one LUT round trip and two image round trips instead of four each.  Operands and operation order per
+// voxel are those of the separable form: bit-identical.
+// Dynamic LDS: per wave box_cap + row_cap float4 (the context's worst tile box: box_cap = max(dx dy dz, 64 dz), row_cap = 8 dy dz).
+constexpr int kWsWaves = 4;
+struct WsCaps { int box, row; };
+#ifndef RR_K1WS_BOUNDS
+#define RR_K1WS_BOUNDS 4
+#endif
+template <bool kList>
+__global__ __launch_bounds__(256, RR_K1WS_BOUNDS) void k_integrate_tiles_ws(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check, WsCaps C) {
+  extern __shared__ float4 s_dyn[];
+  __shared__ int s_i0a[kWsWaves][3][8], s_i1a[kWsWaves][3][8];
+  __shared__ float s_wa[kWsWaves][3][8];
+  const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
+  const float limit = V.limit;
+  const int n_work = kList ? (int)*S.count : S.n;
+  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  float4* const s_box = s_dyn + wv * (C.box + C.row);          // this wave's stream: texel box, later its y-lerped planes
+  float4* const s_row = s_box + C.box;                         // ... and its x-lerped rows
+  if (kList && blockIdx.x == 0 && tid == 0) *S.next_count = 0u;                    // the previous list was consumed by the classify launch
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int tile = work_tile<kList>(S, w);
+    int t3[3];
+    tile_coords(V, tile, t3[0], t3[1], t3[2]);
+    if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
+    float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
+    constexpr int kVox = 2;                                             // voxels per thread: local z = lz and lz + 4, same x and y
+    const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
+    const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
+    bool drawn[kVox];
+    float tsd[kVox], wsum[kVox];
+#pragma unroll
+    for (int h = 0; h < kVox; ++h) {
+      const int z = t3[2] * 8 + lz + 4 * h;
+      drawn[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      if (drawn[h] && per_voxel_check) drawn[h] = voxel_drawn(B, x, y, z);
+      tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
+      wsum[h] = 0.0f;
+    }
+    for (int cb = 0; cb < T.n; cb += kWsWaves) {
+      __syncthreads();                                                  // the previous chunk's / tile's readers of the planes are done
+      const int i = cb + wv;                                            // this wave's stream
+      int mx = 0, my = 0, mz = 0, dx = 1, dy = 1, dz = 1;
+      if (i < T.n) {
+        const StreamLut& L = T.s[i];
+        if (ln < 24) {                                                  // phase A: GL LINEAR set-up of the tile's 8 coordinates per axis
+          const int a = ln >> 3, k = ln & 7;
+          const int coord = min(t3[a] * 8 + k, V.res[a] - 1);           // padding voxels reuse the last real coordinate
+          const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], L.inv_res[a]);
+          s_i0a[wv][a][k] = ax.i0; s_i1a[wv][a][k] = ax.i1; s_wa[wv][a][k] = ax.a;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int (*s_i0)[8] = s_i0a[wv];
+        const int (*s_i1)[8] = s_i1a[wv];
+        const float (*s_w)[8] = s_wa[wv];
+        mx = s_i0[0][0]; my = s_i0[1][0]; mz = s_i0[2][0];
+        dx = s_i1[0][7] - mx + 1; dy = s_i1[1][7] - my + 1; dz = s_i1[2][7] - mz + 1;
+        {                                                               // phase B: the stream's texel box, independent 16-byte loads
+          const int n = min(__mul24(__mul24(dx, dy), dz), C.box);
+          const float rdx = __builtin_amdgcn_rcpf((float)dx), rdy = __builtin_amdgcn_rcpf((float)dy);   // division-free e -> (bx, by, bz), see above
+          for (int e = ln; e < n; e += 64) {
+            const int row = (int)(((float)e + 0.5f) * rdx);
+            const int bz = (int)(((float)row + 0.5f) * rdy);
+            const int bx = e - __mul24(row, dx), by = row - __mul24(bz, dy);
+            s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n1 = min(__mul24(__mul24(dy, dz), 8), C.row);         // pass X
+        for (int e = ln; e < n1; e += 64) {
+          const int k = e & 7, rb = __mul24(e >> 3, dx);
+          const float3 r = lerp3(s_box[rb + (s_i0[0][k] - mx)], s_box[rb + (s_i1[0][k] - mx)], s_w[0][k]);
+          s_row[e] = make_float4(r.x, r.y, r.z, 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n2 = min(dz << 6, C.box);                             // pass Y: the y-lerped planes overwrite the box
+        for (int e = ln; e < n2; e += 64) {
+          const int k = e & 7, j = (e >> 3) & 7, zb = __mul24(e >> 6, dy);
+          const float3 r = lerp3(s_row[((zb + (s_i0[1][j] - my)) << 3) + k], s_row[((zb + (s_i1[1][j] - my)) << 3) + k], s_w[1][j]);
+          s_box[e] = make_float4(r.x, r.y, r.z, 0.0f);
+        }
+      }
+      __syncthreads();
+      bool any_drawn = false;
+#pragma unroll
+      for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
+      if (__ballot(any_drawn) != 0ull) {                                // phase Z, all streams of the chunk
+        const int nc = min(kWsWaves, T.n - cb);
+#pragma unroll
+        for (int h = 0; h < kVox; ++h) {
+          const int kz = lz + 4 * h;
+          float3 pc[kWsWaves];
+          Dqs q[kWsWaves];
+#pragma unroll
+          for (int c = 0; c < kWsWaves; ++c)
+            if (c < nc) {                                               // texture(cv_xyz_inv[i], position).xyz, :31
+              const float4* pl = s_dyn + c * (C.box + C.row);
+              const int mzc = s_i0a[c][2][0];
+              pc[c] = lerp3(pl[(((s_i0a[c][2][kz] - mzc) << 3) + ly) * 8 + lx], pl[(((s_i1a[c][2][kz] - mzc) << 3) + ly) * 8 + lx], s_wa[c][2][kz]);
+            }
+#pragma unroll
+          for (int c = 0; c < kWsWaves; ++c)
+            if (c < nc && drawn[h]) q[c] = dqs_fetch(F, cb + c, pc[c].x, pc[c].y);
+          if (drawn[h]) {
+            float weighted_tsd = tsd[h], total_weight = wsum[h];        // tsdf_integration.vs:30-55, in stream order
+#pragma unroll
+            for (int c = 0; c < kWsWaves; ++c)
+              if (c < nc) {
+                bool skip = false;
+                if (dqs_silhouette(q[c]) < 1.0f) {
+                  if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
+                }
+                if (!skip) {
+                  const float sdist = pc[c].z - dqs_depth(q[c]);
+                  if (sdist <= -limit) {
+                    weighted_tsd = -limit;
+                  } else if (sdist >= limit) {
+                  } else {
+                    const float weight = dqs_quality(q[c]);
+                    weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
+                    total_weight += weight;
+                  }
+                }
+              }
+            tsd[h] = weighted_tsd; wsum[h] = total_weight;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < kVox; ++h) out[tid + 256 * h] = drawn[h] ? tsd[h] : -limit;   // clearImage(-limit), :249-250
+    if (tid == 0) S.cls[tile] = kTileMixed;
+  }
+}
+
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc) {
+                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, int ws_box, int ws_row) {
+  const WsCaps wc{ws_box, ws_row};
+  const size_t ws_lds = (size_t)kWsWaves * (size_t)(ws_box + ws_row) * sizeof(float4);
   // phase 1: tile classification + stale-tile clear; phase 2: the integrate kernel; 0: both (the split lets the caller time the kernel alone)
   if (use_bricks) {
     if (phase != 2) {
@@ -408,12 +553,14 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     }
     if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
-    if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_ws<true>), grid, dim3(256), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, wc);
+    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
   } else {
     if (phase == 1) return;
-    if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+    if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_ws<false>), dim3(S.n), dim3(256), ws_lds, st, T, F, V, B, S, 0, wc);
+    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
   }

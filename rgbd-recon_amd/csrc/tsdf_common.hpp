@@ -180,7 +180,7 @@ void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels
 // ... and so does the zeroing of the spare brick-counter buffer (`zero`, in 16-byte units of zero_words / 4)
 struct PeelClear { uint4* peels; const uint8_t* touched_prev; int w, h, ntx, n_tiles; uint32_t* zero; uint32_t zero_words; };   // null pointers: nothing to do
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr);
+                      int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr, int ws_box = 0, int ws_row = 0);
 int integrate_box_cap();
 int integrate_row_cap();
 void launch_mark_all_mixed(hipStream_t st, const TileState& S);

@@ -63,10 +63,10 @@ def test_lds_box_near_its_capacity(rr, res, inv_res):
         assert (np.abs(a) < 0.08).sum() > 500
 
 
-@pytest.mark.parametrize("form", ["2", "1", "0"])
+@pytest.mark.parametrize("form", ["3", "2", "1", "0"])
 def test_all_three_integrate_kernels_give_the_same_volume(rr, small_scene, form, monkeypatch):
-    """RR_K1_FORM caps the kernel choice when a context is created: 2 = separable LDS passes, 1 = direct 8-tap LDS form,
-    0 = every tap from global memory.  The choice is normally made from the LUT box size; each must be bit-identical."""
+    """RR_K1_FORM caps the kernel choice when a context is created: 3 = separable passes with one wave per stream (the default
+    where its LDS fits), 2 = separable LDS passes stream by stream, 1 = direct 8-tap LDS form, 0 = every tap from global memory.  The choice is normally made from the LUT box size; each must be bit-identical."""
     monkeypatch.setenv("RR_K1_FORM", form)
     hip, orc = rr.ReconIntegrationHip(small_scene, **KW), OracleRecon(small_scene, **KW)
     for use_bricks in (True, False):
@@ -90,7 +90,7 @@ def test_nan_and_out_of_range_lut_coordinates_sample_like_the_oracle(rr):
         inv[i, idx, :3] = np.array(vals, np.float32)
     sc["cv_xyz_inv"] = inv
     mv, pr = rr.scene.default_view(*KW["view"])
-    for form in ("2", "1", "0"):
+    for form in ("3", "2", "1", "0"):
         os.environ["RR_K1_FORM"] = form
         try:
             hip, orc = rr.ReconIntegrationHip(sc, **KW), OracleRecon(sc, **KW)

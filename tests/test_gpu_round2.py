@@ -43,6 +43,22 @@ def assert_frame_equal(a, b, what):
     return int((ad < 1).sum())
 
 
+def frame_vs_oracle(hip, orc, mv, pr, what, peels=True):
+    """the frame of both sides stage by stage: brick update + integrate + draw() -> raymarch target, then fillColors() -> framebuffer
+    (the oracle's literal two-atlas fillColors() swaps its atlases, so its raymarch target is read before the hole filling)"""
+    for o in (hip, orc):
+        o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks(); o.integrate(); o.draw(mv, pr)
+    (aa, ad, an, ap), (ba, bd, bn, bp) = hip.view_images(), orc.view_images()
+    assert not peels or same(ap, bp).all(), f"{what}: depth peels"
+    assert same(an, bn).all(), f"{what}: sample counts"
+    assert same(ad, bd).all() and same(aa, ba).all(), f"{what}: raymarch depth / colour"
+    for o in (hip, orc):
+        o.fillColors()
+    (ac, adp), (bc, bdp) = hip.framebuffer(), orc.framebuffer()
+    assert same(adp, bdp).all() and same(ac, bc).all(), f"{what}: framebuffer"
+    return int((ad < 1).sum())
+
+
 def big(rr, n_streams, res):
     scene = rr.scene.make_scene(n_streams=n_streams, width=640, height=480, lut_res=128, inv_res=128)
     ext = scene["bbox_max"] - scene["bbox_min"]
@@ -64,12 +80,10 @@ def slabs_frame(rr, scene, kw, mv, pr, n, halo, composite, **extra):
 def test_config3_512cubed_8_streams_whole_equals_oracle_and_8_slabs_equal_whole(rr):
     scene, kw, mv, pr = big(rr, 8, (512, 512, 512))
     hip, orc = rr.ReconIntegrationHip(scene, **kw), OracleRecon(scene, **kw)
-    for o in (hip, orc):
-        o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks(); o.integrate(); o.drawF(mv, pr)
+    assert frame_vs_oracle(hip, orc, mv, pr, "c3 whole vs oracle") > 20000
     np.testing.assert_array_equal(hip.bricks()[0], orc.counters())
     whole_tsdf = hip.tsdf()
     assert same(whole_tsdf, orc.tsdf()).all()
-    assert assert_frame_equal(hip, orc, "c3 whole vs oracle") > 20000
     del orc
     for halo, composite in (("recompute", "compact"), ("exchange", "dense")):
         slabs = slabs_frame(rr, scene, kw, mv, pr, 8, halo, composite)
@@ -87,10 +101,8 @@ def test_config3_512cubed_8_streams_whole_equals_oracle_and_8_slabs_equal_whole(
 def test_config4_1024cubed_8_streams_dense_and_sparse_equal_oracle_and_8_slabs_equal_whole(rr):
     scene, kw, mv, pr = big(rr, 8, (1024, 1024, 1024))
     hip, orc = rr.ReconIntegrationHip(scene, **kw), OracleRecon(scene, **kw)
-    ratios = []
-    for o in (hip, orc):
-        o.clearOccupiedBricks(); o.markBricks(); ratios.append(o.updateOccupiedBricks()); o.integrate(); o.drawF(mv, pr)
-    assert ratios[0] == ratios[1] and 0.0005 < ratios[0] < 0.05
+    assert frame_vs_oracle(hip, orc, mv, pr, "c4 dense vs oracle") > 20000
+    assert 0.0005 < hip.occupiedRatio() < 0.05
     np.testing.assert_array_equal(hip.bricks()[0], orc.counters())
     a, b = hip.tsdf(), orc.tsdf()                                           # 2^30 voxels each: inside the occupied bricks' voxel lists the
     assert a.shape == (1024, 1024, 1024)                                    # fused values, the clear value everywhere else (:249-258)
@@ -98,7 +110,6 @@ def test_config4_1024cubed_8_streams_dense_and_sparse_equal_oracle_and_8_slabs_e
         assert same(a[z:z + 128], b[z:z + 128]).all(), f"planes {z}.."
     assert (a != np.float32(-0.01)).mean() > 1e-4
     del b
-    assert assert_frame_equal(hip, orc, "c4 dense vs oracle") > 20000
     del orc
     # the same volume in a sparse tile pool (BASELINE.json configs[4] "sparse-brick allocation")
     sp = rr.ReconIntegrationHip(scene, sparse_pool_tiles=1 << 17, **kw)
@@ -143,18 +154,19 @@ def test_nan_voxels_and_nan_hit_positions_in_every_march_instantiation(rr, small
             hips["sparse"] = rr.ReconIntegrationHip(sc, sparse_pool_tiles=4096, **KW)
         for o in [orc] + list(hips.values()):
             o.setUseBricks(use_bricks); o.setSpaceSkip(skip)
-            run_frame(o, mv, pr)
-        t = orc.tsdf()
+        for name, h in hips.items():
+            assert frame_vs_oracle(h, orc, mv, pr, f"{name}, bricks={use_bricks}", peels=skip) > 300
+            t = orc.tsdf()
+            assert_same(h.tsdf(), t, f"tsdf ({name}, bricks={use_bricks})")
         assert np.isnan(t).sum() > 500                                       # the NaN shell exists
+        orc.draw(mv, pr)
         (oc, od, on, _) = orc.view_images()
         assert np.isnan(oc[od < 1]).any()                                    # ... and rays were shaded at NaN positions
-        for name, h in hips.items():
-            assert_same(h.tsdf(), t, f"tsdf ({name}, bricks={use_bricks})")
-            assert assert_frame_equal(h, orc, f"{name}, bricks={use_bricks}") > 300
         if use_bricks:
+            run_frame(hips["whole"], mv, pr)
             for halo, composite in (("recompute", "compact"), ("exchange", "dense")):
                 slabs = slabs_frame(rr, sc, KW, mv, pr, 4, halo, composite)
-                assert_frame_equal(slabs[0], orc, f"4 slabs ({halo})")
+                assert_frame_equal(slabs[0], hips["whole"], f"4 slabs ({halo})")
 
 
 # ------------------------------------------------------------------------------------------------ halo wider than one step
@@ -263,8 +275,13 @@ def test_occupied_sliver_bricks_over_an_incremental_sequence(rr):
         cnt[sliver[f::3]] = 1000                                             # a different set of sliver bricks "occupied" each frame
         for o in (hip, orc):
             o.set_counters(cnt)
-            o.updateOccupiedBricks(); o.integrate(); o.drawF(mv, pr)
+            o.updateOccupiedBricks(); o.integrate(); o.draw(mv, pr)
         a = hip.tsdf()
         assert_same(a, orc.tsdf(), f"frame {f} tsdf")
         assert (a[:, 60:70, :] != np.float32(-0.04)).sum() > 1000            # the sphere's surface band lies in the overlapping bricks below
-        assert_frame_equal(hip, orc, f"frame {f}")
+        (aa, ad, an, ap), (ba, bd, bn, bp) = hip.view_images(), orc.view_images()
+        assert same(ap, bp).all() and same(an, bn).all() and same(ad, bd).all() and same(aa, ba).all(), f"frame {f} raymarch"
+        for o in (hip, orc):
+            o.fillColors()
+        (ac, adp), (bc, bdp) = hip.framebuffer(), orc.framebuffer()
+        assert same(adp, bdp).all() and same(ac, bc).all(), f"frame {f} framebuffer"
