@@ -65,7 +65,7 @@ struct tsdf_ctx {
   // the stream's per-tile LUT box against the integrate kernel's LDS budget: 0 = does not fit (global-memory kernel), 1 = the box fits
   // (direct 8-tap form), 2 = the separable passes' rows and planes fit as well (the fastest form)
   int lds_ok[TSDF_MAX_STREAMS]{};
-  int k1_form_cap = 3;           // RR_K1_FORM: 3 = wave-per-stream separable form (default where it fits), 2 = separable, 1 = direct 8-tap form, 0 = global-memory kernel
+  int k1_form_cap = 2;           // RR_K1_FORM: 2 = separable form (default), 1 = direct 8-tap form, 0 = global-memory kernel, 3 = wave-per-stream separable form (measured slower: DESIGN.md section 4)
   int ws_box[TSDF_MAX_STREAMS]{}, ws_row[TSDF_MAX_STREAMS]{};   // per stream: LDS float4 of the wave-per-stream form for the worst tile box
   FrameImages frame{};           // the CURRENT frame slot's images (what mark / integrate / draw read)
   // Two frame slots (the reference's double PBO + texture arrays, NetKinectArray.cpp:225-236): while the path computes on slot

@@ -91,7 +91,7 @@ def test_config3_512cubed_8_streams_whole_equals_oracle_and_8_slabs_equal_whole(
         if halo == "recompute":
             for k, s in enumerate(slabs):                                   # every rank's owned planes are the whole volume's
                 z0, z1 = k * 64, (k + 1) * 64
-                assert (s.tsdf()[z0:z1] == whole_tsdf[z0:z1]).all(), f"slab {k} volume"
+                assert same(s.tsdf()[z0:z1], whole_tsdf[z0:z1]).all(), f"slab {k} volume"
         for s in slabs:
             s.close()
 
