@@ -157,12 +157,16 @@ __global__ __launch_bounds__(256) void k_classify_lists(Volume V, Bricks B, Tile
     return;
   }
   const uint32_t n_prev = *S.prev_count;                                           // ---- part B
-  const uint32_t nthreads = kStaleBlocks * blockDim.x;
-  for (uint32_t base = (blockIdx.x - kScatterBlocks) * blockDim.x; base < n_prev; base += nthreads) {   // block-uniform: the ballots below need whole waves
-    const uint32_t i = base + threadIdx.x;
+  // kGroup list entries per wave and round: lanes < kGroup test one tile each, then the whole wave resets the stale ones (2 x 1 KiB
+  // stores per tile).  A moving scene makes EVERY previous tile stale; with 64 entries per wave only n_prev / 64 waves had work and
+  // each reset 64 tiles one after another (25 us at c2); 8 per wave spread the same resets over 8 x as many waves.
+  constexpr uint32_t kGroup = 8;
+  const uint32_t n_waves = kStaleBlocks * (blockDim.x >> 6), wave = (blockIdx.x - kScatterBlocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  for (uint32_t base = wave * kGroup; base < n_prev; base += n_waves * kGroup) {   // wave-uniform: the ballot below needs the whole wave
+    const uint32_t i = base + (uint32_t)lane;
     bool stale = false;
     int tile = 0;
-    if (i < n_prev) {
+    if (lane < (int)kGroup && i < n_prev) {
       tile = (int)S.prev_list[i];
       int t[3];
       tile_coords(V, tile, t[0], t[1], t[2]);
