@@ -224,6 +224,21 @@ int32_t tsdf_set_min_voxels_per_brick(tsdf_ctx* ctx, uint32_t n);
 int32_t tsdf_set_brick_size(tsdf_ctx* ctx, const float size[3]);
 int32_t tsdf_set_shade_mode(tsdf_ctx* ctx, int32_t mode);      /* UBO 1 g_shade_mode, shading.glsl:14-21 */
 int32_t tsdf_resize(tsdf_ctx* ctx, uint32_t width, uint32_t height);
+/* Side-by-side stereo (source/kinect_client.cpp:637-664): each eye is drawn into its own glViewport(x, y, w, h) and the operator
+ * is told the same numbers with Reconstruction::setViewportOffset (reconstruction.hpp:23, recon_integration.cpp:527), which
+ * tsdf_raymarch.fs subtracts from gl_FragCoord again (:70, :388-389).  tsdf_set_viewport_offset is that setter;
+ * tsdf_set_viewport_origin is the glViewport origin the reference reads implicitly through gl_FragCoord (default 0, 0).
+ * The context's framebuffer is the viewport's w x h pixels.  Equal origin and offset reproduce the mono frame bit for bit;
+ * unequal ones shift the depth-peel lookup and the unprojection exactly as the shader's arithmetic does. */
+int32_t tsdf_set_viewport_offset(tsdf_ctx* ctx, float x, float y);
+int32_t tsdf_set_viewport_origin(tsdf_ctx* ctx, int32_t x, int32_t y);
+/* Anaglyph stereo (kinect_client.cpp:616-633): Reconstruction::setColorMaskMode (reconstruction.hpp:22) -- 0 all channels, 1 red
+ * only, 2 green + blue only: glColorMask around the raymarch (fill_holes off, recon_integration.cpp:212-216,235-237) or around
+ * the colorfill pass (:321-333).  tsdf_set_framebuffer_clear(0): the client cleared only the depth buffer before this draw
+ * (glClear(GL_DEPTH_BUFFER_BIT), :627), so masked channels and background pixels keep the previous draw's colour; 1 (default): the
+ * colour buffer was cleared too (:609-610, :620). */
+int32_t tsdf_set_color_mask_mode(tsdf_ctx* ctx, uint32_t mode);
+int32_t tsdf_set_framebuffer_clear(tsdf_ctx* ctx, int32_t clear_color);
 
 /* ---- getters ----------------------------------------------------------------------------------- */
 int32_t tsdf_get_resolution(const tsdf_ctx* ctx, uint32_t res[3], uint32_t res_bricks[3], float brick_size[3]);

@@ -89,6 +89,7 @@ class OracleRecon:
         self.upload_frame(scene)
         self.flags = dict(use_bricks=1, skip_space=1, fill_holes=1, min_voxels=10, shade_mode=0)
         self._apply_flags()
+        self.stereo = dict(org=(0, 0), off=(0.0, 0.0), mask=0, clear=1)
 
     def __del__(self):
         if getattr(self, "_c", None):
@@ -111,6 +112,16 @@ class OracleRecon:
     def setMinVoxelsPerBrick(self, n): self.flags["min_voxels"] = int(n); self._apply_flags()
     def setShadeMode(self, m): self.flags["shade_mode"] = int(m); self._apply_flags()
     def setTsdfLimit(self, v): self._L.orc_set_limit(self._c, C.c_float(v))
+
+    # stereo modes of the client (kinect_client.cpp:616-669)
+    def _apply_stereo(self):
+        s = self.stereo
+        self._L.orc_set_stereo(self._c, int(s["org"][0]), int(s["org"][1]), C.c_float(s["off"][0]), C.c_float(s["off"][1]), int(s["mask"]), int(s["clear"]))
+
+    def setViewportOffset(self, x, y): self.stereo["off"] = (float(x), float(y)); self._apply_stereo()
+    def setViewportOrigin(self, x, y): self.stereo["org"] = (int(x), int(y)); self._apply_stereo()
+    def setColorMaskMode(self, m): self.stereo["mask"] = int(m); self._apply_stereo()
+    def setFramebufferClear(self, clear_color): self.stereo["clear"] = int(bool(clear_color)); self._apply_stereo()
     def clearOccupiedBricks(self): self._L.orc_clear_occupied(self._c)
     def markBricks(self): self._L.orc_mark_bricks(self._c)
     def updateOccupiedBricks(self): return self._L.orc_update_occupied(self._c)

@@ -204,7 +204,20 @@ struct orc_ctx {
   float min_length = 0.0125f;                 // KinectCalibrationFile::min_length default (KinectCalibrationFile.cpp:96) -> Reconstruction::m_min_length
   const float* normals = nullptr;             // [N][H][W][3] kinect_normals (NetKinectArray "normal" array) for the point back-end
   int shade_mode = 0;
+  // stereo modes (source/kinect_client.cpp:616-669): glViewport origin + viewport_offset uniform (side by side,
+  // tsdf_raymarch.fs:70,388-389); m_color_mask_mode (reconstruction.cpp:51-53) + whether the client cleared the colour buffer
+  int vp_org[2] = {0, 0};
+  float vp_off[2] = {0.0f, 0.0f};
+  uint32_t color_mask_mode = 0;
+  bool keep_color = false;
 };
+
+// glColorMask(GL_TRUE, GL_FALSE, GL_FALSE, GL_FALSE) / (GL_FALSE, GL_TRUE, GL_TRUE, GL_FALSE), recon_integration.cpp:212-216,321-326
+static inline void masked_store(const orc_ctx* c, float* dst, const float* src) {
+  if (c->color_mask_mode == 1) { dst[0] = src[0]; return; }
+  if (c->color_mask_mode == 2) { dst[1] = src[1]; dst[2] = src[2]; return; }
+  memcpy(dst, src, 16);
+}
 
 static void set_view(orc_ctx* c, uint32_t w, uint32_t h) {
   // ViewLod::setResolution, view_lod.cpp:24-50
@@ -308,6 +321,10 @@ void orc_set_flags(orc_ctx* c, int use_bricks, int skip_space, int fill_holes, u
   c->use_bricks = use_bricks; c->skip_space = skip_space; c->fill_holes = fill_holes; c->min_voxels = min_voxels; c->shade_mode = shade_mode;
 }
 void orc_set_limit(orc_ctx* c, float limit) { c->limit = limit; }
+void orc_set_stereo(orc_ctx* c, int org_x, int org_y, float off_x, float off_y, uint32_t color_mask_mode, int clear_color) {
+  c->vp_org[0] = org_x; c->vp_org[1] = org_y; c->vp_off[0] = off_x; c->vp_off[1] = off_y;
+  c->color_mask_mode = color_mask_mode; c->keep_color = clear_color == 0;
+}
 
 // ---------------------------------------------------------------- bricks (inc_bricks.glsl)
 void orc_clear_occupied(orc_ctx* c) { std::fill(c->counters.begin(), c->counters.end(), 0u); }   // recon_integration.cpp:271-277
@@ -627,21 +644,28 @@ void orc_draw(orc_ctx* c, const float* mv16, const float* proj16) {
     for (size_t i = 0; i < ad.size(); ++i) { ac[4 * i] = 0; ac[4 * i + 1] = 1; ac[4 * i + 2] = 0; ac[4 * i + 3] = 0; ad[i] = 1.0f; }
     tgt_c = ac.data(); tgt_d = ad.data(); stride = c->aw;
   } else {
-    for (size_t i = 0; i < c->fb_d.size(); ++i) { c->fb_c[4 * i] = 0; c->fb_c[4 * i + 1] = 0; c->fb_c[4 * i + 2] = 0; c->fb_c[4 * i + 3] = 0; c->fb_d[i] = 1.0f; }
+    // the client's glClear before the draw: colour + depth (kinect_client.cpp:609-610,620), or depth alone before the anaglyph's second eye (:627)
+    for (size_t i = 0; i < c->fb_d.size(); ++i) { if (!c->keep_color) { c->fb_c[4 * i] = 0; c->fb_c[4 * i + 1] = 0; c->fb_c[4 * i + 2] = 0; c->fb_c[4 * i + 3] = 0; } c->fb_d[i] = 1.0f; }
     tgt_c = c->fb_c.data(); tgt_d = c->fb_d.data(); stride = w;
   }
   const float limit = c->limit, sd = limit * 0.5f;                       // sampleDistance :34
+  // rasterised into the window viewport (its origin is part of gl_FragCoord) or, with hole filling, into the pyramid's level-0
+  // viewport at (0, 0) (ViewLod::enable, view_lod.cpp:68)
+  const int org[2] = {c->fill_holes ? 0 : c->vp_org[0], c->fill_holes ? 0 : c->vp_org[1]};
 #pragma omp parallel for schedule(dynamic, 2)
   for (long py = 0; py < (long)h; ++py)
     for (uint32_t px = 0; px < w; ++px) {
       const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
       vec3 step = normalize(pixel_dir_vol(V, fx, fy)) * sd;              // :64
       uint32_t max_n = 0; vec3 pos = {0, 0, 0};
-      if (skip) {                                                        // getStartPos :384-393
-        const float* dm = &c->peels[((size_t)py * w + px) * 4];
+      if (skip) {                                                        // getStartPos(ivec2(gl_FragCoord.xy - viewport_offset)) :70, :384-393
+        const float qx = ((float)((long)px + org[0]) + 0.5f) - c->vp_off[0], qy = ((float)(py + org[1]) + 0.5f) - c->vp_off[1];   // gl_FragCoord - viewport_offset
+        const int cx = (int)qx, cy = (int)qy;                            // ivec2(): truncation
+        static const float zero4[4] = {0, 0, 0, 0};                     // texelFetch out of range -> 0 (Appendix A)
+        const float* dm = (cx >= 0 && cy >= 0 && cx < (int)w && cy < (int)h) ? &c->peels[((size_t)cy * w + cx) * 4] : zero4;
         float r = dm[0], g = dm[1], b = dm[2];
         r = (r >= b) ? 0.0f : r;
-        vec3 pf = screen_to_vol(V, fx, fy, r), pb = screen_to_vol(V, fx, fy, -g);
+        vec3 pf = screen_to_vol(V, qx, qy, r), pb = screen_to_vol(V, qx, qy, -g);
         if (r >= 1.0f) pb = pf;
         pos = pf;
         max_n = (uint32_t)ceilf(length(pf - pb) / sd);                   // :73
@@ -670,7 +694,10 @@ void orc_draw(orc_ctx* c, const float* mv16, const float* proj16) {
         prev = density;
         pos = pos + step;
       }
-      c->nsamples[(size_t)py * w + px] = (float)n * 0.0027f;             // :395-398
+      {                                                                  // :395-398: imageStore at ivec2(gl_FragCoord.xy) = viewport origin + pixel
+        const long sx = (long)px + org[0], sy = py + org[1];
+        if (sx >= 0 && sy >= 0 && sx < (long)w && sy < (long)h) c->nsamples[(size_t)sy * w + sx] = (float)n * 0.0027f;
+      }
       if (!hit) continue;                                                // discard
       // submitFragment :116-134
       vec3 gn = get_gradient(c, pos, sd);
@@ -686,7 +713,10 @@ void orc_draw(orc_ctx* c, const float* mv16, const float* proj16) {
       // GL depth test LESS against the cleared 1.0 and the [0,1] depth clamp
       fd = clampf(fd, 0.0f, 1.0f);
       if (!(fd < tgt_d[o])) continue;
-      tgt_c[4 * o] = out.x; tgt_c[4 * o + 1] = out.y; tgt_c[4 * o + 2] = out.z; tgt_c[4 * o + 3] = out.w; tgt_d[o] = fd;
+      const float o4[4] = {out.x, out.y, out.z, out.w};
+      if (c->fill_holes) memcpy(&tgt_c[4 * o], o4, 16);                  // into the pyramid: no mask (:212-216 only without hole filling)
+      else masked_store(c, &tgt_c[4 * o], o4);
+      tgt_d[o] = fd;
     }
 }
 
@@ -787,12 +817,12 @@ static void colorfill(orc_ctx* c, const std::vector<float>& sc, const std::vecto
       float c0[4], d0;
       fetch(sc, sdp, aw, h, (int)((float)(int)OFF(0, 0) + (float)(int)RES(0, 0) * tcx), (int)((float)(int)OFF(0, 1) + (float)(int)RES(0, 1) * tcy), c0, &d0);   // :54
       size_t o = (size_t)py * w + px;
-      if (d0 < c->fb_d[o]) { memcpy(&c->fb_c[4 * o], out, 16); c->fb_d[o] = d0; }      // GL_LESS
+      if (d0 < c->fb_d[o]) { masked_store(c, &c->fb_c[4 * o], out); c->fb_d[o] = d0; }  // GL_LESS, glColorMask :321-326
     }
 }
 void orc_fill_colors(orc_ctx* c) {
-  // the caller cleared the default framebuffer (kinect_client.cpp:602-612)
-  for (size_t i = 0; i < c->fb_d.size(); ++i) { c->fb_c[4 * i] = c->fb_c[4 * i + 1] = c->fb_c[4 * i + 2] = c->fb_c[4 * i + 3] = 0; c->fb_d[i] = 1.0f; }
+  // the caller cleared the default framebuffer (kinect_client.cpp:602-612) -- or only its depth (:627)
+  for (size_t i = 0; i < c->fb_d.size(); ++i) { if (!c->keep_color) { c->fb_c[4 * i] = c->fb_c[4 * i + 1] = c->fb_c[4 * i + 2] = c->fb_c[4 * i + 3] = 0; } c->fb_d[i] = 1.0f; }
   auto *Tc = c->target_is_A ? &c->atlasA_c : &c->atlasB_c, *Td = c->target_is_A ? &c->atlasA_d : &c->atlasB_d;   // m_view_inpaint
   auto *Sc = c->target_is_A ? &c->atlasB_c : &c->atlasA_c, *Sd = c->target_is_A ? &c->atlasB_d : &c->atlasA_d;   // m_view_inpaint2
   const int num_lods = (int)(c->lod_res.size() / 2);

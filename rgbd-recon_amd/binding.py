@@ -374,6 +374,11 @@ class ReconIntegrationHip:
     def setColorFilling(self, a): self._ck(self._L.tsdf_set_color_filling(self._c, int(a)))
     def setMinVoxelsPerBrick(self, n): self._ck(self._L.tsdf_set_min_voxels_per_brick(self._c, int(n)))
     def setShadeMode(self, m): self._ck(self._L.tsdf_set_shade_mode(self._c, int(m)))
+    # stereo modes of the client (kinect_client.cpp:616-669): Reconstruction::setViewportOffset / setColorMaskMode + the GL state around them
+    def setViewportOffset(self, x, y): self._ck(self._L.tsdf_set_viewport_offset(self._c, C.c_float(x), C.c_float(y)))
+    def setViewportOrigin(self, x, y): self._ck(self._L.tsdf_set_viewport_origin(self._c, int(x), int(y)))
+    def setColorMaskMode(self, m): self._ck(self._L.tsdf_set_color_mask_mode(self._c, int(m)))
+    def setFramebufferClear(self, clear_color): self._ck(self._L.tsdf_set_framebuffer_clear(self._c, int(bool(clear_color))))
 
     def setBrickSize(self, size):
         s = (C.c_float * 3)(*([size] * 3 if np.isscalar(size) else list(size)))

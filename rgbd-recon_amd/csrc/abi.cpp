@@ -105,6 +105,10 @@ struct tsdf_ctx {
   // flags (recon_integration.cpp:54-57)
   bool fill_holes = true, use_bricks = true, skip_space = true;
   int shade_mode = 0;
+  // stereo modes of the client (source/kinect_client.cpp:616-669): viewport origin + viewport_offset uniform (side by side),
+  // colour mask + "colour buffer not cleared before this draw" (anaglyph)
+  int vp_org[2]{}; float vp_off[2]{};
+  uint32_t color_mask_mode = 0; bool keep_color = false;
   bool timers_on = false;
   std::string timer_filter;      // ",name,name," or empty = all
   std::map<std::string, Timer> timers;
@@ -379,6 +383,10 @@ bool make_view_params(const tsdf_ctx* c, const float* mv16, const float* pr16, V
   P->w = c->vw; P->h = c->vh;
   P->shade_mode = c->shade_mode;
   P->skip = (c->skip_space && c->use_bricks) ? 1 : 0;                                     // :154, :510-513
+  // with hole filling the raymarch is rasterised into the pyramid's level-0 viewport (0, 0, w, h) (ViewLod::enable, view_lod.cpp:68):
+  // gl_FragCoord then carries no window origin, while the shader still subtracts viewport_offset ("currently not working",
+  // recon_integration.cpp:528-530; the client switches hole filling off for side-by-side stereo, kinect_client.cpp:645-647)
+  for (int a = 0; a < 2; ++a) { P->vp_org[a] = c->fill_holes ? 0 : c->vp_org[a]; P->vp_off[a] = c->vp_off[a]; }
   return true;
 }
 
@@ -402,9 +410,14 @@ void use_frame_slot(tsdf_ctx* c, int k) {
 
 int halo_layers_for(float limit, int res_z) { return (int)ceilf((limit * (float)res_z + 2.0f) / 8.0f); }
 
+// draw() without hole filling writes the default framebuffer through glColorMask (recon_integration.cpp:212-216): with a mask, or
+// with a colour buffer the client did not clear, the march renders into the (otherwise unused) atlas and a merge pass follows
+bool masked_direct(const tsdf_ctx* c) { return !c->fill_holes && (c->color_mask_mode != 0 || c->keep_color); }
+
 RayTarget ray_target(tsdf_ctx* c) {
   RayTarget R{};
-  if (c->fill_holes) { R.color = c->atlas.color; R.depth = c->atlas.depth; R.stride = c->atlas.aw; R.clear[0] = 0; R.clear[1] = 1; R.clear[2] = 0; R.clear[3] = 0; }
+  if (masked_direct(c)) { R.color = c->atlas.color; R.depth = c->atlas.depth; R.stride = c->atlas.aw; R.clear[0] = R.clear[1] = R.clear[2] = R.clear[3] = 0; }
+  else if (c->fill_holes) { R.color = c->atlas.color; R.depth = c->atlas.depth; R.stride = c->atlas.aw; R.clear[0] = 0; R.clear[1] = 1; R.clear[2] = 0; R.clear[3] = 0; }
   else { R.color = c->d_fb_c; R.depth = c->d_fb_d; R.stride = c->vw; R.clear[0] = R.clear[1] = R.clear[2] = R.clear[3] = 0; }
   R.nsamples = c->d_nsamples;
   R.peels = c->d_peels;
@@ -1019,7 +1032,10 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   if (!make_view_params(c, mv, pr, &P)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "singular modelview / projection matrix");
   if (outer_timer) timer_begin(c, "3recon");
   const bool partial = !(c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
-  const bool use_tiles = P.skip && !partial && c->use_tile_history;
+  const bool shifted = P.vp_org[0] != 0 || P.vp_org[1] != 0 || P.vp_off[0] != 0.0f || P.vp_off[1] != 0.0f;
+  if (shifted && partial) FAIL(c, TSDF_ERR_STATE, "a viewport origin / offset is not available on a slab context (the composite indexes pixels)");
+  if (shifted) HIP_TRY(c, hipMemsetAsync(c->d_nsamples, 0, (size_t)c->vw * c->vh * sizeof(float), c->stream));   // clearImage of tex_num_samples, :207-208: the stores land at origin + pixel
+  const bool use_tiles = P.skip && !partial && c->use_tile_history && !shifted && !masked_direct(c);
   if (P.skip) {
     timer_begin(c, "brickdraw");
     if (use_tiles && !c->tile_history) {
@@ -1045,6 +1061,7 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   timer_end(c, "k_march");
   launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu);
   c->hit_parity ^= 1;
+  if (masked_direct(c)) launch_resolve_masked(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
   timer_end(c, "draw");
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -1132,7 +1149,7 @@ int32_t tsdf_fill_colors(tsdf_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   timer_begin(c, "holefill");
   launch_inpaint_pyramid(c->stream, c->atlas);
-  launch_colorfill(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d);
+  launch_colorfill(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
   timer_end(c, "holefill");
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -1167,6 +1184,25 @@ int32_t tsdf_set_shade_mode(tsdf_ctx* c, int32_t m) {
   c->shade_mode = m;
   return TSDF_OK;
 }
+// Reconstruction::setViewportOffset -> uniform viewport_offset (recon_integration.cpp:527); the GL viewport origin is GL state the
+// reference reads implicitly through gl_FragCoord (glViewport(x, y, ..), kinect_client.cpp:650,658)
+int32_t tsdf_set_viewport_offset(tsdf_ctx* c, float x, float y) { CHECK_CTX(c); c->vp_off[0] = x; c->vp_off[1] = y; c->tile_history = false; return TSDF_OK; }
+int32_t tsdf_set_viewport_origin(tsdf_ctx* c, int32_t x, int32_t y) {
+  CHECK_CTX(c);
+  if (x < -(1 << 20) || x > (1 << 20) || y < -(1 << 20) || y > (1 << 20)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "viewport origin out of range");
+  c->vp_org[0] = x; c->vp_org[1] = y; c->tile_history = false;
+  return TSDF_OK;
+}
+// Reconstruction::setColorMaskMode (reconstruction.cpp:51-53; used recon_integration.cpp:212-216,321-333) and whether the client
+// cleared the colour buffer before this draw (glClear(GL_COLOR_BUFFER_BIT | GL_DEPTH_BUFFER_BIT), kinect_client.cpp:609-610,620) or
+// only the depth buffer (the anaglyph's second eye, :627)
+int32_t tsdf_set_color_mask_mode(tsdf_ctx* c, uint32_t mode) {
+  CHECK_CTX(c);
+  if (mode > 2) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "colour mask mode must be 0 (all), 1 (red) or 2 (green + blue)");
+  c->color_mask_mode = mode; c->tile_history = false;
+  return TSDF_OK;
+}
+int32_t tsdf_set_framebuffer_clear(tsdf_ctx* c, int32_t clear_color) { CHECK_CTX(c); c->keep_color = clear_color == 0; c->tile_history = false; return TSDF_OK; }
 int32_t tsdf_set_brick_size(tsdf_ctx* c, const float size[3]) {
   CHECK_CTX(c);
   if (!size) return TSDF_ERR_INVALID_ARGUMENT;

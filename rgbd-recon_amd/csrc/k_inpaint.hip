@@ -160,7 +160,15 @@ __device__ __forceinline__ Texel fetch_atlas(const Atlas& A, int x, int y) {
 }
 
 // tsdf_colorfill.fs:30-55 with depth func LESS against the cleared framebuffer (:313)
-__global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4* __restrict__ fb_c, float* __restrict__ fb_d) {
+// glColorMask of the anaglyph modes on the write into the "default framebuffer" (recon_integration.cpp:212-216,321-333): masked
+// channels keep what the colour buffer held -- the cleared 0 (glClear, kinect_client.cpp:609-610,620) or, when the client cleared
+// only the depth buffer before this draw (:627), the previous draw's colour
+__device__ __forceinline__ float4 masked_write(float4 out, float4 base, int mask) {
+  if (mask == 1) return make_float4(out.x, base.y, base.z, base.w);          // GL_TRUE, GL_FALSE, GL_FALSE, GL_FALSE
+  if (mask == 2) return make_float4(base.x, out.y, out.z, base.w);           // GL_FALSE, GL_TRUE, GL_TRUE, GL_FALSE
+  return out;
+}
+__global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4* __restrict__ fb_c, float* __restrict__ fb_d, int mask, int keep) {
   const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (px >= w || py >= h) return;
   const float tcx = (float)px / (float)A.res[0][0], tcy = (float)py / (float)A.res[0][1];             // :32
@@ -168,8 +176,9 @@ __global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4
   // depth comes from level 0 alone (:54) and the fragment only lands if it beats the cleared depth (GL_LESS, :313):
   // background pixels need none of the colour work
   const float d0 = fetch_atlas(A, (int)((float)A.off[0][0] + (float)A.res[0][0] * tcx), (int)((float)A.off[0][1] + (float)A.res[0][1] * tcy)).d;
+  const float4 base = keep ? fb_c[o] : make_float4(0, 0, 0, 0);
   if (!(d0 < 1.0f)) {
-    fb_c[o] = make_float4(0, 0, 0, 0);
+    fb_c[o] = base;
     fb_d[o] = 1.0f;
     return;
   }
@@ -200,12 +209,27 @@ __global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4
     out = make_float4((c1.x * w1 + c2.x * w2) / (w1 + w2), (c1.y * w1 + c2.y * w2) / (w1 + w2),
                       (c1.z * w1 + c2.z * w2) / (w1 + w2), (c1.w * w1 + c2.w * w2) / (w1 + w2));
   }
-  fb_c[o] = out;
+  fb_c[o] = masked_write(out, base, mask);
   fb_d[o] = d0;
 }
-void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth) {
+void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask, int keep_color) {
   dim3 grid((w + 15) / 16, (h + 15) / 16);
-  hipLaunchKernelGGL(k_colorfill, grid, dim3(256), 0, st, A, w, h, fb_color, fb_depth);
+  hipLaunchKernelGGL(k_colorfill, grid, dim3(256), 0, st, A, w, h, fb_color, fb_depth, mask, keep_color);
+}
+// draw() without hole filling but with a colour mask / an uncleared colour buffer: fragments (depth < 1 in the march target) write
+// their unmasked channels, everything else keeps the colour buffer; the depth buffer was cleared before the draw
+__global__ __launch_bounds__(256) void k_resolve_masked(Atlas A, int w, int h, float4* __restrict__ fb_c, float* __restrict__ fb_d, int mask, int keep) {
+  const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (px >= w || py >= h) return;
+  const size_t o = (size_t)py * w + px, a = (size_t)py * A.aw + px;
+  const float d = A.depth[a];
+  const float4 base = keep ? fb_c[o] : make_float4(0, 0, 0, 0);
+  fb_c[o] = d < 1.0f ? masked_write(A.color[a], base, mask) : base;
+  fb_d[o] = d < 1.0f ? d : 1.0f;
+}
+void launch_resolve_masked(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask, int keep_color) {
+  dim3 grid((w + 15) / 16, (h + 15) / 16);
+  hipLaunchKernelGGL(k_resolve_masked, grid, dim3(256), 0, st, A, w, h, fb_color, fb_depth, mask, keep_color);
 }
 
 __global__ __launch_bounds__(256) void k_clear_image(float4* __restrict__ c, float* __restrict__ d, size_t n, float4 cv, float dv) {

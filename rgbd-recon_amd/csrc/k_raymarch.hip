@@ -272,13 +272,19 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   float3 pos = make_float3(0, 0, 0);
   bool covered = inside;
   if (inside) {
-    if (P.skip) {                                                       // getStartPos(), :384-393
-      const uint4 dmb = ((const uint4*)R.peels)[(size_t)py * P.w + px];
+    if (P.skip) {                                                       // getStartPos(ivec2(gl_FragCoord.xy - viewport_offset)), :70, :384-393
+      // gl_FragCoord = viewport origin + pixel + 0.5 (window coordinates); the shader subtracts its viewport_offset uniform again.
+      // origin == offset (what the client sets, kinect_client.cpp:650-662) gives back the pixel centre exactly; anything else
+      // shifts the peel lookup and the unprojection the way the reference's arithmetic does (out-of-range texelFetch -> 0).
+      const float qx = ((float)(px + P.vp_org[0]) + 0.5f) - P.vp_off[0], qy = ((float)(py + P.vp_org[1]) + 0.5f) - P.vp_off[1];
+      const int cx = (int)qx, cy = (int)qy;
+      uint4 dmb = make_uint4(0u, 0u, 0u, 0u);
+      if (cx >= 0 && cy >= 0 && cx < P.w && cy < P.h) dmb = ((const uint4*)R.peels)[(size_t)cy * P.w + cx];
       const float dm_r = __uint_as_float(dmb.x), dm_g = -__uint_as_float(dmb.y), dm_b = __uint_as_float(dmb.z);   // g = min(-z) = -max z
       float r = dm_r;
       r = (r >= dm_b) ? 0.0f : r;
-      const float3 pf = screen_to_vol(P, fx, fy, r);
-      float3 pb = screen_to_vol(P, fx, fy, -dm_g);
+      const float3 pf = screen_to_vol(P, qx, qy, r);
+      float3 pb = screen_to_vol(P, qx, qy, -dm_g);
       if (r >= 1.0f) pb = pf;
       pos = pf;
       const float3 dd = make_float3(pf.x - pb.x, pf.y - pb.y, pf.z - pb.z);
@@ -399,8 +405,9 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
       R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
       R.depth[oi] = 1.0f;
     }
-    const float ns = (float)n * 0.0027f;                                // writeNumSamples(), :395-398
-    R.nsamples[(size_t)py * P.w + px] = covered ? ((partial && !hit) ? -ns : ns) : 0.0f;
+    const float ns = (float)n * 0.0027f;                                // writeNumSamples(), :395-398: imageStore at ivec2(gl_FragCoord.xy)
+    const int sx = px + P.vp_org[0], sy = py + P.vp_org[1];
+    if (sx >= 0 && sy >= 0 && sx < P.w && sy < P.h) R.nsamples[(size_t)sy * P.w + sx] = covered ? ((partial && !hit) ? -ns : ns) : 0.0f;
   }
 }
 
@@ -496,7 +503,8 @@ __device__ __forceinline__ void march_long(const ViewParams& P, const Volume& V,
         R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
         R.depth[oi] = 1.0f;
       }
-      R.nsamples[(size_t)py * P.w + px] = (float)n * 0.0027f;           // writeNumSamples(), :395-398
+      const int sx = px + P.vp_org[0], sy = py + P.vp_org[1];           // writeNumSamples(), :395-398
+      if (sx >= 0 && sy >= 0 && sx < P.w && sy < P.h) R.nsamples[(size_t)sy * P.w + sx] = (float)n * 0.0027f;
     }
   }
 }

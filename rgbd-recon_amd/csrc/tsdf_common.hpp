@@ -98,6 +98,10 @@ struct ViewParams {
   int w, h;
   int shade_mode;
   int skip;
+  // side-by-side stereo (kinect_client.cpp:637-664): the GL viewport's origin (gl_FragCoord = origin + pixel + 0.5) and the shader's
+  // viewport_offset uniform (tsdf_raymarch.fs:70,388-389; setViewportOffset, recon_integration.cpp:527)
+  int vp_org[2];
+  float vp_off[2];
 };
 
 // ViewLod atlas (view_lod.cpp:24-61)
@@ -199,7 +203,11 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
 // hit_counters: 4 words [hit, hit', long, long'], the primed ones re-armed for the next frame by k_shade
 void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod);
 void launch_inpaint_pyramid(hipStream_t st, const Atlas& A);
-void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth);
+// mask: Reconstruction::m_color_mask_mode (0 all channels, 1 red only, 2 green + blue only: glColorMask, recon_integration.cpp:321-333);
+// keep_color: the colour buffer was NOT cleared before this draw (the anaglyph's second eye, kinect_client.cpp:627)
+void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask = 0, int keep_color = 0);
+// fill_holes off with a colour mask / an uncleared colour buffer: the march renders into the atlas' level-0 region and this merges it
+void launch_resolve_masked(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask, int keep_color);
 void launch_clear_image(hipStream_t st, float4* color, float* depth, size_t n, float4 c, float d);
 void launch_export_partial(hipStream_t st, const RayTarget& R, int w, int h, void* dst);
 void launch_composite(hipStream_t st, const void* gathered, int n, const RayTarget& R, int w, int h);

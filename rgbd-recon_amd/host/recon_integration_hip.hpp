@@ -94,8 +94,11 @@ class ReconIntegrationHip {
   void drawF() { check(tsdf_draw_f(m_ctx, m_mv, m_proj)); }
   void reload() {}                                               // shader hot reload: nothing to reload
   void resize(std::size_t width, std::size_t height) { check(tsdf_resize(m_ctx, (uint32_t)width, (uint32_t)height)); }
-  void setColorMaskMode(unsigned mode) { m_color_mask_mode = mode; }   // anaglyph masks apply when the caller blits the result
-  void setViewportOffset(float x, float y) { m_viewport_offset[0] = x; m_viewport_offset[1] = y; }
+  void setColorMaskMode(unsigned mode) { check(tsdf_set_color_mask_mode(m_ctx, mode)); }       // reconstruction.cpp:51-53 -> glColorMask :212-216,321-333
+  void setViewportOffset(float x, float y) { check(tsdf_set_viewport_offset(m_ctx, x, y)); }   // recon_integration.cpp:527 -> tsdf_raymarch.fs:70,388-389
+  // GL state the reference reads implicitly: glViewport's origin (gl_FragCoord) and whether glClear included the colour buffer
+  void setViewportOrigin(int x, int y) { check(tsdf_set_viewport_origin(m_ctx, x, y)); }
+  void setFramebufferClear(bool clear_color) { check(tsdf_set_framebuffer_clear(m_ctx, clear_color ? 1 : 0)); }
 
   // ---- kinect::ReconIntegration (recon_integration.hpp:42-58)
   void integrate() { check(tsdf_integrate(m_ctx)); }
@@ -141,8 +144,6 @@ class ReconIntegrationHip {
   tsdf_ctx* m_ctx = nullptr;
   float m_mv[16], m_proj[16];
   float m_brick_size;
-  float m_viewport_offset[2] = {0.0f, 0.0f};
-  unsigned m_color_mask_mode = 0;
   bool m_draw_bricks = false;
 };
 

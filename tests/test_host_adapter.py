@@ -44,6 +44,26 @@ def test_python_mirror_has_the_reference_method_names(rr):
         assert callable(getattr(rr.ReconIntegrationHip, name)), name
 
 
+def test_python_mirror_has_the_stereo_setters(rr):
+    for name in ["setViewportOffset", "setColorMaskMode", "setViewportOrigin", "setFramebufferClear"]:
+        assert callable(getattr(rr.ReconIntegrationHip, name)), name
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree only exists in the build container")
+def test_gl_adapter_derives_from_the_reference_base_class_and_fits_g_recons():
+    """host/recon_integration_hip_gl.hpp compiled against the reference's OWN reconstruction.hpp / calibration_files.hpp / gloost
+    (where they lie; nothing is copied, nothing is linked): a std::shared_ptr<ReconIntegrationHipGL> goes into
+    std::vector<std::shared_ptr<kinect::Reconstruction>> g_recons and is driven through the base-class calls of draw3d()."""
+    inc = [os.path.join(REF, "framework", "reconstruction"), os.path.join(REF, "framework", "calibration"), os.path.join(REF, "external"),
+           os.path.join(REF, "external", "gloost"), os.path.join(REF, "external", "glm-0.9.5.3"), HOST]
+    p = subprocess.run(["g++", "-std=c++11", "-Wall", "-fsyntax-only"] + ["-I" + d for d in inc] + [os.path.join(ROOT, "tests", "cpp", "adapter_in_reference_tree.cpp")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+
+
 def test_harness_builds_and_fails_loudly_without_a_device():
     import torch
     exe = build_harness()
