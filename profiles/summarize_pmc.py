@@ -7,8 +7,12 @@ The optional fourth pass (SQ_INSTS_VALU) adds `valu_insts` = VALU wave-instructi
 `roofline.valu_issue_frac` = valu_insts x 2 issue cycles (SIMD-32: 32 lanes/cycle, MI355X_MICROARCH.md) / (1024 SIMDs x 2.4 GHz x launch time): the share of the launch the
 SIMDs spend issuing vector instructions (the largest single share of the integrate kernel).
 
-Corrections: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950 -> x2 (an upper bound for gathers);
-WRITE_SIZE is taken as is (calibration on this path: the dense c1 integrate writes 256^3 x 4 B = 67.1 MB and the counter
+Corrections (calibrated on known byte counts with tools/gather_calib.hip, profiles/r02_fetch_calibration_summary.txt):
+FETCH_SIZE reports 1/2 of a wide coalesced 16-B-per-lane stream (512 MiB read -> 256 MiB counted), but counts scattered
+accesses at their full 64-B sector: 4.00 x the useful bytes for random 16-B taps (128 MiB and 1 GiB tables alike), 1.96 x for
+2x2x2 texel neighbourhoods.  The integrate / march / shade kernels are gather kernels (LUT boxes of 3-6 texels per row, scattered
+image and voxel taps), so `hbm_bytes` = FETCH_SIZE x 1 + WRITE_SIZE; `hbm_bytes_if_streaming` = FETCH_SIZE x 2 + WRITE_SIZE is
+kept as the upper bound that round 1 reported.  WRITE_SIZE is taken as is (calibration on this path: the dense c1 integrate writes 256^3 x 4 B = 67.1 MB and the counter
 reads 67.1 MB; a 512 MiB fill reads 524288 KiB)."""
 import collections
 import csv
@@ -34,9 +38,9 @@ def main():
     v = per_kernel(sys.argv[4], "SQ_INSTS_VALU") if len(sys.argv) > 4 else {}
     out = {}
     for name, parts in GROUPS.items():
-        fb = sum(v for k, v in f.items() if any(p in k for p in parts)) * 1024 * 2
+        fb = sum(v for k, v in f.items() if any(p in k for p in parts)) * 1024
         wb = sum(v for k, v in w.items() if any(p in k for p in parts)) * 1024
-        out[name] = {"fetch_bytes_corrected": fb, "write_bytes_corrected": wb, "hbm_bytes": fb + wb}
+        out[name] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb, "hbm_bytes_if_streaming": 2 * fb + wb}
         if v:
             out[name]["valu_insts"] = sum(x for k, x in v.items() if any(p in k for p in parts))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
