@@ -7,6 +7,8 @@
 // proportional to the occupied bricks' screen footprint, not to rays x grid cells.  The raymarch then runs
 // one ray per pixel (the reference shades the front and the back cube face with identical results,
 // SURVEY.md Appendix C.3).
+#include <cstdlib>
+
 #include "sampling.hpp"
 #include "shading_dev.hpp"
 
@@ -411,6 +413,175 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   }
 }
 
+// Dense march through LDS-staged voxel boxes (round 2; whole-volume dense storage, no depth limits: configs[1]).
+// k_march gathers every tap of every sample from global memory: 8 scattered dword loads per lane and sample, each touching a
+// handful of cache lines -- the texture-address path, not the vector ALUs (43 % issue) and not HBM (5 %), sets its 205 us at c1.
+// But the 64 rays of a wave (one 8x8-pixel tile) are nearly parallel and step in lockstep: over S steps their taps stay inside one
+// small axis-aligned box of voxels, and at 256^3 a voxel is tapped by ~4 rays x several steps.  Per batch of S steps a wave
+//   1. takes the integer range of tap indices each lane will touch (from its first and last sample position of the batch) and
+//      reduces min / max over the wave: the box [B0, B1] per axis (x origin aligned down to 4 voxels);
+//   2. copies the box into its own LDS region with aligned 16-byte loads along x -- indices clamped on the way in, so a box cell IS
+//      the GL CLAMP_TO_EDGE texel of its coordinate and the lanes need no clamps of their own;
+//   3. marches its S samples with all eight taps from LDS.
+// Positions are the reference's chain of `pos += step` additions and the trilinear filter is tsdf_fetch's (same operands, x -> y
+// -> z): bit-identical.  The first / last positions only SIZE the box; a tap that falls outside it after all (rounding of the
+// addition chain against pos + k * step, a NaN) is detected per sample and fetched from global memory instead, so exactness never
+// rests on the box estimate.  S adapts (16, 8, 4, 2, 1) until the box fits kBoxFloats.
+#ifndef RR_BOX_FLOATS
+#define RR_BOX_FLOATS 2560
+#endif
+#ifndef RR_BOX_STEPS
+#define RR_BOX_STEPS 16
+#endif
+constexpr int kBoxFloats = RR_BOX_FLOATS;     // per wave: 10 KiB -> 40 KiB per workgroup
+constexpr int kBoxSteps = RR_BOX_STEPS;
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+  return v;
+}
+__global__ __launch_bounds__(256, 2) void k_march_box(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
+  __shared__ float4 s_all[4][kBoxFloats / 4];
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  float* const s_box = (float*)s_all[wv];
+  const float limit = V.limit, sd = limit * 0.5f;
+  const int px = blockIdx.x * 16 + (wv & 1) * 8 + (ln & 7);
+  const int py = blockIdx.y * 16 + (wv >> 1) * 8 + (ln >> 3);
+  const bool inside = px < P.w && py < P.h;
+  const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+  const float3 dn = normalize3(pixel_dir_vol(P, fx, fy));
+  const float3 step = make_float3(dn.x * sd, dn.y * sd, dn.z * sd);     // :64
+  uint32_t max_n = 0;
+  float3 pos = make_float3(0, 0, 0);
+  bool covered = inside;
+  if (inside) {                                                         // intersectBox(), :363-374
+    const float3 o = make_float3(P.cam_vol[0], P.cam_vol[1], P.cam_vol[2]);
+    const float3 inv = make_float3(1.0f / step.x, 1.0f / step.y, 1.0f / step.z);
+    const float3 tbot = make_float3(inv.x * (0.0f - o.x), inv.y * (0.0f - o.y), inv.z * (0.0f - o.z));
+    const float3 ttop = make_float3(inv.x * (1.0f - o.x), inv.y * (1.0f - o.y), inv.z * (1.0f - o.z));
+    const float3 tmn = make_float3(fminf(ttop.x, tbot.x), fminf(ttop.y, tbot.y), fminf(ttop.z, tbot.z));
+    const float3 tmx = make_float3(fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z));
+    const float t0 = fmaxf(fmaxf(tmn.x, tmn.y), fmaxf(tmn.x, tmn.z));
+    const float t1 = fminf(fminf(tmx.x, tmx.y), fminf(tmx.x, tmx.z));
+    if (!(t0 <= t1) || t1 < 0.0f) covered = false;                      // no fragment: pixel not under the cube
+    else {
+      const float t_near = t0 < 0.0f ? 0.0f : t0;
+      pos = make_float3(o.x + step.x * t_near, o.y + step.y * t_near, o.z + step.z * t_near);
+      max_n = (uint32_t)ceilf(fabsf(t1 - t_near));
+    }
+  }
+  const float nx = (float)V.res[0], ny = (float)V.res[1], nz = (float)V.res[2];
+  float prev = -limit;
+  uint32_t n = 0;
+  bool hit = false;
+  float3 hit_pos = pos;
+  float hit_d = 0.0f;
+  int S = kBoxSteps;
+  while (__ballot(!hit && n < max_n) != 0ull) {                         // wave-uniform: the reductions and the box copy need every lane
+    const bool live = !hit && n < max_n;
+    // ---- 1. the box of this batch
+    int bx0 = 0, by0 = 0, bz0 = 0, ex = 0, ey = 0, ez = 0;
+    bool fits = false;
+    for (;;) {
+      const uint32_t rem = max_n - n;
+      const float last = (float)((live ? min((uint32_t)S, rem) : 1u) - 1u);
+      const float ax = pos.x * nx - 0.5f, ay = pos.y * ny - 0.5f, az = pos.z * nz - 0.5f;
+      const float bx = (pos.x + step.x * last) * nx - 0.5f, by = (pos.y + step.y * last) * ny - 0.5f, bz = (pos.z + step.z * last) * nz - 0.5f;
+      // lowest / highest tap index per axis; dead lanes and non-finite positions contribute nothing (they take the global path)
+      const bool ok = live && fabsf(ax) < 1.0e6f && fabsf(ay) < 1.0e6f && fabsf(az) < 1.0e6f && fabsf(bx) < 1.0e6f && fabsf(by) < 1.0e6f && fabsf(bz) < 1.0e6f;
+      const int big = 0x3fffffff;
+      const int lx = ok ? (int)floorf(fminf(ax, bx)) : big, ly = ok ? (int)floorf(fminf(ay, by)) : big, lz = ok ? (int)floorf(fminf(az, bz)) : big;
+      const int hx = ok ? (int)floorf(fmaxf(ax, bx)) + 1 : -big, hy = ok ? (int)floorf(fmaxf(ay, by)) + 1 : -big, hz = ok ? (int)floorf(fmaxf(az, bz)) + 1 : -big;
+      const int mlx = wave_min_i32(lx), mly = wave_min_i32(ly), mlz = wave_min_i32(lz);
+      const int mhx = -wave_min_i32(-hx), mhy = -wave_min_i32(-hy), mhz = -wave_min_i32(-hz);
+      if (mlx == big) { fits = false; break; }                          // no lane has a finite position: global path
+      bx0 = mlx & ~3; by0 = mly; bz0 = mlz;
+      ex = ((mhx - bx0 + 1) + 3) & ~3; ey = mhy - by0 + 1; ez = mhz - bz0 + 1;
+      fits = ex > 0 && ey > 0 && ez > 0 && ex <= 1024 && ey <= 1024 && ez <= 1024 && __mul24(__mul24(ex, ey), ez) <= kBoxFloats;
+      if (fits || S == 1) break;
+      S >>= 1;
+    }
+    // ---- 2. global -> LDS, clamped on the way in
+    if (fits) {
+      const int q = ex >> 2, rows = __mul24(ey, ez), items = __mul24(rows, q);
+      const float rq = __builtin_amdgcn_rcpf((float)q), rey = __builtin_amdgcn_rcpf((float)ey);
+      const float* __restrict__ d = V.data;
+      for (int it = ln; it < items; it += 64) {
+        const int row = (int)(((float)it + 0.5f) * rq);                  // it / q   (exact for it < 2^20, see k_integrate_tiles_lds)
+        const int qi = it - __mul24(row, q);
+        const int rz = (int)(((float)row + 0.5f) * rey);                 // row / ey
+        const int ry = row - __mul24(rz, ey);
+        const int gy = min(max(by0 + ry, 0), V.res[1] - 1), gz = min(max(bz0 + rz, 0), V.res[2] - 1);
+        const uint32_t oyz = vol_off_y(V, gy) + vol_off_z(V, gz);
+        const int gx = bx0 + (qi << 2);
+        float4 v;
+        if (gx >= 0 && gx + 3 < V.res[0]) v = *(const float4*)(d + oyz + vol_off_x(gx));          // four voxels of one tile row: 16-byte aligned
+        else {
+          const int c0 = min(max(gx, 0), V.res[0] - 1), c1 = min(max(gx + 1, 0), V.res[0] - 1), c2 = min(max(gx + 2, 0), V.res[0] - 1), c3 = min(max(gx + 3, 0), V.res[0] - 1);
+          v = make_float4(d[oyz + vol_off_x(c0)], d[oyz + vol_off_x(c1)], d[oyz + vol_off_x(c2)], d[oyz + vol_off_x(c3)]);
+        }
+        *(float4*)(s_box + (__mul24(row, ex) + (qi << 2))) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3. S samples (no box at any S -- a tile whose rays entered the cube through different faces: eight samples straight from
+    // global memory, then the box is tried again)
+    const int pl = __mul24(ex, ey);
+    const int s_run = fits ? S : 8;
+    float3 p = pos;
+    for (int k = 0; k < s_run; ++k) {
+      if (!hit && n < max_n) {
+        n += 1;
+        const float fxv = p.x * nx - 0.5f, fyv = p.y * ny - 0.5f, fzv = p.z * nz - 0.5f;      // axis_linear: f = u * n - 0.5
+        const float flx = floorf(fxv), fly = floorf(fyv), flz = floorf(fzv);
+        const float wx = fxv - flx, wy = fyv - fly, wz = fzv - flz;
+        const int ix = (int)flx - bx0, iy = (int)fly - by0, iz = (int)flz - bz0;
+        float dv;
+        if (fits && (unsigned)ix < (unsigned)(ex - 1) && (unsigned)iy < (unsigned)(ey - 1) && (unsigned)iz < (unsigned)(ez - 1)) {
+          const float* b = s_box + (__mul24(iz, pl) + __mul24(iy, ex) + ix);
+          const float c00 = lerpf(b[0], b[1], wx), c10 = lerpf(b[ex], b[ex + 1], wx);
+          const float c01 = lerpf(b[pl], b[pl + 1], wx), c11 = lerpf(b[pl + ex], b[pl + ex + 1], wx);
+          dv = lerpf(lerpf(c00, c10, wy), lerpf(c01, c11, wy), wz);
+        } else dv = tex3d_tsdf<false, true>(V, p.x, p.y, p.z);            // outside the box estimate / no box: the global path, same result
+        if (dv > 0.0f) { hit = true; hit_pos = p; hit_d = dv; }
+        else { prev = dv; p = make_float3(p.x + step.x, p.y + step.y, p.z + step.z); }
+      }
+    }
+    pos = p;
+    __builtin_amdgcn_wave_barrier();                                      // the next batch overwrites the box
+    if (fits && S < kBoxSteps && (n & 63u) == 0u) S <<= 1;                // try a longer batch again now and then (wave-uniform only if n is: see below)
+    S = __builtin_amdgcn_readfirstlane(S);
+  }
+  float3 out_pos = pos;
+  if (hit) {                                                            // approximate ray-cell intersection, :99-101
+    const float kk = prev / (hit_d - prev);
+    out_pos = make_float3((hit_pos.x - step.x) - step.x * kk, (hit_pos.y - step.y) - step.y * kk, (hit_pos.z - step.z) - step.z * kk);
+  }
+  const unsigned long long hm = __ballot(hit);
+  if (hm) {
+    const int leader = __ffsll((long long)hm) - 1;
+    uint32_t base = 0;
+    if (ln == leader) base = atomicAdd(hit_count, (uint32_t)__popcll(hm));
+    base = __shfl(base, leader);
+    if (hit) {
+      Hit h;
+      h.x = out_pos.x; h.y = out_pos.y; h.z = out_pos.z; h.pix = (uint32_t)(py * P.w + px);
+      hits[base + (uint32_t)__popcll(hm & ((1ull << ln) - 1ull))] = h;
+    }
+  }
+  if (inside) {
+    if (!hit) {                                                         // discard: the target keeps its clear value
+      const size_t oi = (size_t)py * R.stride + px;
+      R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
+      R.depth[oi] = 1.0f;
+    }
+    const float ns = (float)n * 0.0027f;                                // writeNumSamples(), :395-398
+    const int sx = px + P.vp_org[0], sy = py + P.vp_org[1];
+    if (sx >= 0 && sy >= 0 && sx < P.w && sy < P.h) R.nsamples[(size_t)sy * P.w + sx] = covered ? ns : 0.0f;
+  }
+}
+
 // Second pass of the march: kLanes lanes per long ray, kLongBatch consecutive samples per lane (kLanes * kLongBatch samples of a
 // ray per round trip, 64 / kLanes rays per wave; shapes measured in DESIGN.md section 4).  Lane j starts 8j samples further along the ray; it gets there by performing the reference's own
 // chain of `pos += step` additions, so positions, densities, the first positive sample and the sample count are exactly
@@ -568,6 +739,10 @@ __global__ __launch_bounds__(256, RR_SHADE_BOUNDS) void k_shade_and_long(ViewPar
   if (blockIdx.x < kLongBlocks) march_long<kSparse>(P, V, R, longs, long_count, kLongBlocks, &T, &F);
   else shade_list<kSparse>(P, T, F, V, R, hits, hit_count, next_count, kLongBlocks);
 }
+static bool box_march_enabled() {                     // RR_MARCH_BOX=0: the global-gather march (A/B and test hook)
+  static const bool on = [] { const char* e = getenv("RR_MARCH_BOX"); return !e || atoi(e) != 0; }();
+  return on;
+}
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
                      void* hit_list, uint32_t* hit_counters, int parity, int phase, void* long_list, uint32_t cap) {
   // phase 2: k_march alone; phase 3: k_shade alone; 0: everything (the split lets the caller time the march kernel alone)
@@ -581,6 +756,7 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
 #define RR_LAUNCH_MARCH(PART, SP, B) hipLaunchKernelGGL((k_march<PART, SP, B>), grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity, ll, hit_counters + 2 + parity, cap1)
     if (partial) { if (sparse) RR_LAUNCH_MARCH(true, true, kBatchDense); else RR_LAUNCH_MARCH(true, false, kBatchDense); }
     else if (two_pass) { if (sparse) RR_LAUNCH_MARCH(false, true, kBatchSkip); else RR_LAUNCH_MARCH(false, false, kBatchSkip); }
+    else if (!sparse && !P.skip && box_march_enabled()) hipLaunchKernelGGL(k_march_box, grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
     else { if (sparse) RR_LAUNCH_MARCH(false, true, kBatchDense); else RR_LAUNCH_MARCH(false, false, kBatchDense); }
 #undef RR_LAUNCH_MARCH
   }
