@@ -196,6 +196,14 @@ __global__ __launch_bounds__(256) void k_classify_lists(Volume V, Bricks B, Tile
   }
 }
 
+// What the tile's 2 KiB hold after this integrate: kTileMinus iff EVERY stored voxel is the clear value (exactly), else kTileMixed.
+// The dense march leaps over whole runs of kTileMinus tiles (k_march_box, k_raymarch.hip); for the culled path an exact class only
+// means that such a tile needs no reset when it stops being active.  One __syncthreads_and per tile.
+__device__ __forceinline__ void store_tile_class(const TileState& S, int tile, bool mine_all_clear) {
+  const int all = __syncthreads_and(mine_all_clear ? 1 : 0);
+  if (threadIdx.x == 0) S.cls[tile] = all ? kTileMinus : kTileMixed;
+}
+
 // Shared tile loop: which tile does work item w map to
 template <bool kList>
 __device__ __forceinline__ int work_tile(const TileState& S, int w) {
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
       if (drawn) v[half] = integrate_voxel(T, F, limit, ((float)x + 0.5f) * sx, ((float)y + 0.5f) * sy, ((float)z + 0.5f) * sz);
       out[l] = v[half];
     }
-    if (threadIdx.x == 0) S.cls[tile] = kTileMixed;
+    store_tile_class(S, tile, v[0] == -limit && v[1] == -limit);
   }
 }
 
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
       wsum[h] = 0.0f;
     }
-    __syncthreads();                                                    // the previous tile's readers of s_* are done
+    // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)
     for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
       const int i = t / 24, a = (t % 24) >> 3, k = t & 7;
       const int coord = min(t3[a] * 8 + k, V.res[a] - 1);               // padding voxels reuse the last real coordinate
@@ -392,8 +400,8 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       }
     }
 #pragma unroll
-    for (int h = 0; h < kVox; ++h) out[tid + 256 * h] = drawn[h] ? tsd[h] : -limit;   // clearImage(-limit), :249-250
-    if (tid == 0) S.cls[tile] = kTileMixed;
+    for (int h = 0; h < kVox; ++h) { tsd[h] = drawn[h] ? tsd[h] : -limit; out[tid + 256 * h] = tsd[h]; }   // clearImage(-limit), :249-250
+    store_tile_class(S, tile, tsd[0] == -limit && tsd[1] == -limit);
   }
 }
 
@@ -535,8 +543,8 @@ __global__ __launch_bounds__(256, RR_K1WS_BOUNDS) void k_integrate_tiles_ws(Stre
       }
     }
 #pragma unroll
-    for (int h = 0; h < kVox; ++h) out[tid + 256 * h] = drawn[h] ? tsd[h] : -limit;   // clearImage(-limit), :249-250
-    if (tid == 0) S.cls[tile] = kTileMixed;
+    for (int h = 0; h < kVox; ++h) { tsd[h] = drawn[h] ? tsd[h] : -limit; out[tid + 256 * h] = tsd[h]; }   // clearImage(-limit), :249-250
+    store_tile_class(S, tile, tsd[0] == -limit && tsd[1] == -limit);
   }
 }
 

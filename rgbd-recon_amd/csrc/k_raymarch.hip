@@ -433,14 +433,44 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
 #ifndef RR_BOX_STEPS
 #define RR_BOX_STEPS 16
 #endif
+#ifndef RR_BOX_SUB
+#define RR_BOX_SUB 4
+#endif
+#ifndef RR_BOX_BOUNDS
+#define RR_BOX_BOUNDS 2
+#endif
 constexpr int kBoxFloats = RR_BOX_FLOATS;     // per wave: 10 KiB -> 40 KiB per workgroup
 constexpr int kBoxSteps = RR_BOX_STEPS;
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
-  return v;
+#ifndef RR_BOX_LEAP
+#define RR_BOX_LEAP 32
+#endif
+constexpr int kLeap = RR_BOX_LEAP;            // samples per leap over all-clear tiles
+#ifdef RR_BOX_STATS      // instrumented build (tools/build_variant.sh): [batches, batches with a box, sum of S, samples from LDS, samples from global, box floats, retries, samples in all-clear boxes]
+__device__ unsigned long long g_box_stats[8];
+extern "C" int32_t tsdf_debug_box_stats(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_box_stats), sizeof(g_box_stats)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_box_stats), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
 }
-__global__ __launch_bounds__(256, 2) void k_march_box(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
+#define RR_STAT(i, v) do { if (ln == 0) atomicAdd(&g_box_stats[i], (unsigned long long)(v)); } while (0)
+#define RR_STAT_LANE(i, v) atomicAdd(&g_box_stats[i], (unsigned long long)(v))
+#else
+#define RR_STAT(i, v) do { } while (0)
+#define RR_STAT_LANE(i, v) do { } while (0)
+#endif
+// min over the 64 lanes, returned wave-uniform.  DPP row shifts + row broadcasts (the classic GCN wave reduction): eight VALU
+// instructions and one v_readlane, no LDS round trips (six ds_bpermute per value cost the first version of this kernel ~0.3 us of
+// exposed latency per batch).  Lanes without a source in a row shift keep their own value (old operand = self).
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xe, false));   // row_shr:4 (banks 1-3)
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xc, false));   // row_shr:8 (banks 2-3): lane 15 of each row holds the row's min
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's min
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
   __shared__ float4 s_all[4][kBoxFloats / 4];
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
   float* const s_box = (float*)s_all[wv];
@@ -477,11 +507,60 @@ __global__ __launch_bounds__(256, 2) void k_march_box(ViewParams P, Volume V, Ra
   float3 hit_pos = pos;
   float hit_d = 0.0f;
   int S = kBoxSteps;
+  bool try_leap = true;                                                 // wave-uniform: the last thing seen was empty space
+  const uint8_t* __restrict__ cls = V.cls;
+  const float ml = -limit;
   while (__ballot(!hit && n < max_n) != 0ull) {                         // wave-uniform: the reductions and the box copy need every lane
     const bool live = !hit && n < max_n;
+    // ---- 0. leap: integrate() leaves an exact class per 8^3 storage tile (kTileMinus = every voxel is -limit).  If all tiles the
+    // wave's next kLeap samples can tap are of that class, those samples are -limit without looking at a single voxel: count, add.
+    // One byte per tile and lane instead of a box of voxels; tried while the wave is in empty space, dropped at the first failure and
+    // taken up again when a sampled box turns out all clear.
+    if (try_leap) {
+      const uint32_t rem = max_n - n;
+      const float last = (float)((live ? min((uint32_t)kLeap, rem) : 1u) - 1u);
+      const float ax = pos.x * nx - 0.5f, ay = pos.y * ny - 0.5f, az = pos.z * nz - 0.5f;
+      const float bx = (pos.x + step.x * last) * nx - 0.5f, by = (pos.y + step.y * last) * ny - 0.5f, bz = (pos.z + step.z * last) * nz - 0.5f;
+      const bool ok = live && fabsf(ax) < 1.0e6f && fabsf(ay) < 1.0e6f && fabsf(az) < 1.0e6f && fabsf(bx) < 1.0e6f && fabsf(by) < 1.0e6f && fabsf(bz) < 1.0e6f;
+      constexpr float kSlackL = 0.05f;                                   // as kSlack below, for up to kLeap additions
+      const int big = 0x3fffffff;
+      // tile coordinates of the clamped tap range (CLAMP_TO_EDGE: taps outside the volume read its border voxels)
+      const int rx = V.res[0] - 1, ry = V.res[1] - 1, rz = V.res[2] - 1;
+      const int lx = ok ? min(max((int)floorf(fminf(ax, bx) - kSlackL), 0), rx) >> 3 : big, ly = ok ? min(max((int)floorf(fminf(ay, by) - kSlackL), 0), ry) >> 3 : big;
+      const int lz = ok ? min(max((int)floorf(fminf(az, bz) - kSlackL), 0), rz) >> 3 : big;
+      const int hx = ok ? min(max((int)floorf(fmaxf(ax, bx) + kSlackL) + 1, 0), rx) >> 3 : -big, hy = ok ? min(max((int)floorf(fmaxf(ay, by) + kSlackL) + 1, 0), ry) >> 3 : -big;
+      const int hz = ok ? min(max((int)floorf(fmaxf(az, bz) + kSlackL) + 1, 0), rz) >> 3 : -big;
+      const bool odd_l = __ballot(live && !ok) != 0ull;
+      const int tx0 = wave_min_i32(lx), ty0 = wave_min_i32(ly), tz0 = wave_min_i32(lz);
+      const int tx1 = -wave_min_i32(-hx), ty1 = -wave_min_i32(-hy), tz1 = -wave_min_i32(-hz);
+      const int cx = tx1 - tx0 + 1, cy = ty1 - ty0 + 1, cz = tz1 - tz0 + 1;
+      bool leap = !odd_l && tx0 != big && cx > 0 && cy > 0 && cz > 0 && cx <= 64 && cy <= 64 && cz <= 64 && __mul24(__mul24(cx, cy), cz) <= 4 * 64;
+      if (leap) {
+        const int cnt = __mul24(__mul24(cx, cy), cz);
+        const float rcx = __builtin_amdgcn_rcpf((float)cx), rcy = __builtin_amdgcn_rcpf((float)cy);
+        bool clear = true;
+        for (int it = ln; it < cnt; it += 64) {
+          const int row = (int)(((float)it + 0.5f) * rcx);               // it / cx
+          const int kx = it - __mul24(row, cx);
+          const int kz = (int)(((float)row + 0.5f) * rcy);               // row / cy
+          const int ky = row - __mul24(kz, cy);
+          clear &= cls[(uint32_t)__mul24(__mul24(tz0 + kz - V.tz0, V.nty) + (ty0 + ky), V.ntx) + (uint32_t)(tx0 + kx)] == kTileMinus;
+        }
+        leap = __ballot(!clear) == 0ull;
+      }
+      if (leap) {
+        float3 e = pos;
+        for (int k = 0; k < kLeap; ++k) e = make_float3(e.x + step.x, e.y + step.y, e.z + step.z);   // the reference's chain of additions
+        if (live) { n += min((uint32_t)kLeap, max_n - n); prev = ml; }
+        pos = e;
+        RR_STAT(7, kLeap);
+        continue;
+      }
+      try_leap = false;
+    }
     // ---- 1. the box of this batch
     int bx0 = 0, by0 = 0, bz0 = 0, ex = 0, ey = 0, ez = 0;
-    bool fits = false;
+    bool fits = false, odd = false;                                      // odd: some live lane has a non-finite position
     for (;;) {
       const uint32_t rem = max_n - n;
       const float last = (float)((live ? min((uint32_t)S, rem) : 1u) - 1u);
@@ -490,8 +569,13 @@ __global__ __launch_bounds__(256, 2) void k_march_box(ViewParams P, Volume V, Ra
       // lowest / highest tap index per axis; dead lanes and non-finite positions contribute nothing (they take the global path)
       const bool ok = live && fabsf(ax) < 1.0e6f && fabsf(ay) < 1.0e6f && fabsf(az) < 1.0e6f && fabsf(bx) < 1.0e6f && fabsf(by) < 1.0e6f && fabsf(bz) < 1.0e6f;
       const int big = 0x3fffffff;
-      const int lx = ok ? (int)floorf(fminf(ax, bx)) : big, ly = ok ? (int)floorf(fminf(ay, by)) : big, lz = ok ? (int)floorf(fminf(az, bz)) : big;
-      const int hx = ok ? (int)floorf(fmaxf(ax, bx)) + 1 : -big, hy = ok ? (int)floorf(fmaxf(ay, by)) + 1 : -big, hz = ok ? (int)floorf(fmaxf(az, bz)) + 1 : -big;
+      // kSlack voxels of margin: the samples are reached by S - 1 rounded additions, the estimate by one multiply-add; the two differ
+      // by at most ~S ulps of a coordinate near 1, i.e. < 16 * 6e-8 * 4096 = 4e-3 voxels at the largest volume -- with the margin every
+      // sample of a finite ray provably taps inside the box (the per-sample test of the sampling path below stays as a second line)
+      constexpr float kSlack = 0.01f;
+      const int lx = ok ? (int)floorf(fminf(ax, bx) - kSlack) : big, ly = ok ? (int)floorf(fminf(ay, by) - kSlack) : big, lz = ok ? (int)floorf(fminf(az, bz) - kSlack) : big;
+      const int hx = ok ? (int)floorf(fmaxf(ax, bx) + kSlack) + 1 : -big, hy = ok ? (int)floorf(fmaxf(ay, by) + kSlack) + 1 : -big, hz = ok ? (int)floorf(fmaxf(az, bz) + kSlack) + 1 : -big;
+      odd = __ballot(live && !ok) != 0ull;
       const int mlx = wave_min_i32(lx), mly = wave_min_i32(ly), mlz = wave_min_i32(lz);
       const int mhx = -wave_min_i32(-hx), mhy = -wave_min_i32(-hy), mhz = -wave_min_i32(-hz);
       if (mlx == big) { fits = false; break; }                          // no lane has a finite position: global path
@@ -500,8 +584,15 @@ __global__ __launch_bounds__(256, 2) void k_march_box(ViewParams P, Volume V, Ra
       fits = ex > 0 && ey > 0 && ez > 0 && ex <= 1024 && ey <= 1024 && ez <= 1024 && __mul24(__mul24(ex, ey), ez) <= kBoxFloats;
       if (fits || S == 1) break;
       S >>= 1;
+      RR_STAT(6, 1);
     }
-    // ---- 2. global -> LDS, clamped on the way in
+    RR_STAT(0, 1); RR_STAT(1, fits ? 1 : 0); RR_STAT(2, fits ? S : 0); RR_STAT(5, fits ? __mul24(__mul24(ex, ey), ez) : 0);
+    // ---- 2. global -> LDS, clamped on the way in.  While it passes through the registers every voxel is compared with the clear
+    // value: a box that holds nothing but -limit (free space in front of the surfaces, most of the volume) makes every sample inside
+    // it exactly -limit -- lerp(a, a, t) = a + (a - a) * t = a in fp32 -- so step 3 only has to count and to perform the position
+    // additions.  (The per-sample tile-class lookups of round 1 lost to their own instruction cost; here the test costs four compares
+    // per 16-byte load and is shared by all samples of the batch.)
+    bool all_clear = true;
     if (fits) {
       const int q = ex >> 2, rows = __mul24(ey, ez), items = __mul24(rows, q);
       const float rq = __builtin_amdgcn_rcpf((float)q), rey = __builtin_amdgcn_rcpf((float)ey);
@@ -521,32 +612,87 @@ __global__ __launch_bounds__(256, 2) void k_march_box(ViewParams P, Volume V, Ra
           v = make_float4(d[oyz + vol_off_x(c0)], d[oyz + vol_off_x(c1)], d[oyz + vol_off_x(c2)], d[oyz + vol_off_x(c3)]);
         }
         *(float4*)(s_box + (__mul24(row, ex) + (qi << 2))) = v;
+        all_clear &= (v.x == ml) & (v.y == ml) & (v.z == ml) & (v.w == ml);
       }
     }
+    const bool empty = fits && __ballot(!all_clear) == 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- 3. S samples (no box at any S -- a tile whose rays entered the cube through different faces: eight samples straight from
-    // global memory, then the box is tried again)
+    // ---- 3. S samples, kSub at a time: positions never depend on the densities, so the taps of kSub consecutive samples are read
+    // together (their LDS latencies overlap) and then examined in order -- the same trick as k_march's batched fetches.
+    // (No box at any S -- a tile whose rays entered the cube through different faces: eight samples straight from global memory,
+    // then the box is tried again.)
     const int pl = __mul24(ex, ey);
     const int s_run = fits ? S : 8;
+    constexpr int kSub = RR_BOX_SUB;
     float3 p = pos;
-    for (int k = 0; k < s_run; ++k) {
-      if (!hit && n < max_n) {
-        n += 1;
-        const float fxv = p.x * nx - 0.5f, fyv = p.y * ny - 0.5f, fzv = p.z * nz - 0.5f;      // axis_linear: f = u * n - 0.5
+    if (empty && !odd) {
+      // every sample of the batch is -limit: no hit, prev_density = -limit, the counter advances by the samples this ray still had;
+      // the positions still go through the reference's chain of additions
+      for (int k = 0; k < s_run; ++k) p = make_float3(p.x + step.x, p.y + step.y, p.z + step.z);
+      if (live) { n += min((uint32_t)s_run, max_n - n); prev = ml; }
+      pos = p;
+      RR_STAT(7, s_run);
+      __builtin_amdgcn_wave_barrier();
+      try_leap = true;                                                    // back in empty space
+      continue;
+    }
+    for (int k0 = 0; k0 < s_run; k0 += kSub) {
+      float3 q[kSub];
+      float dv[kSub];
+      q[0] = p;
+#pragma unroll
+      for (int j = 1; j < kSub; ++j) q[j] = make_float3(q[j - 1].x + step.x, q[j - 1].y + step.y, q[j - 1].z + step.z);
+      float wx[kSub], wy[kSub], wz[kSub];
+      int cell[kSub];
+      bool want[kSub];
+      bool stray = false;                                                 // a wanted sample whose taps leave the box estimate
+#pragma unroll
+      for (int j = 0; j < kSub; ++j) {
+        want[j] = !hit && n + (uint32_t)j < max_n && k0 + j < s_run;
+        const float fxv = q[j].x * nx - 0.5f, fyv = q[j].y * ny - 0.5f, fzv = q[j].z * nz - 0.5f;    // axis_linear: f = u * n - 0.5
         const float flx = floorf(fxv), fly = floorf(fyv), flz = floorf(fzv);
-        const float wx = fxv - flx, wy = fyv - fly, wz = fzv - flz;
+        wx[j] = fxv - flx; wy[j] = fyv - fly; wz[j] = fzv - flz;
         const int ix = (int)flx - bx0, iy = (int)fly - by0, iz = (int)flz - bz0;
-        float dv;
-        if (fits && (unsigned)ix < (unsigned)(ex - 1) && (unsigned)iy < (unsigned)(ey - 1) && (unsigned)iz < (unsigned)(ez - 1)) {
-          const float* b = s_box + (__mul24(iz, pl) + __mul24(iy, ex) + ix);
-          const float c00 = lerpf(b[0], b[1], wx), c10 = lerpf(b[ex], b[ex + 1], wx);
-          const float c01 = lerpf(b[pl], b[pl + 1], wx), c11 = lerpf(b[pl + ex], b[pl + ex + 1], wx);
-          dv = lerpf(lerpf(c00, c10, wy), lerpf(c01, c11, wy), wz);
-        } else dv = tex3d_tsdf<false, true>(V, p.x, p.y, p.z);            // outside the box estimate / no box: the global path, same result
-        if (dv > 0.0f) { hit = true; hit_pos = p; hit_d = dv; }
-        else { prev = dv; p = make_float3(p.x + step.x, p.y + step.y, p.z + step.z); }
+        const bool in_box = (unsigned)ix < (unsigned)(ex - 1) && (unsigned)iy < (unsigned)(ey - 1) && (unsigned)iz < (unsigned)(ez - 1);
+        stray |= want[j] && !in_box;
+        cell[j] = (want[j] && in_box) ? __mul24(iz, pl) + __mul24(iy, ex) + ix : 0;
       }
+      if (fits && __ballot(stray) == 0ull) {
+        // the common case, free of divergence: every lane reads eight taps per sample (idle lanes read cell 0), all reads of the
+        // sub-batch are issued before the first lerp
+        float t[kSub][8];
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) {
+          const float* b = s_box + cell[j];
+          t[j][0] = b[0]; t[j][1] = b[1]; t[j][2] = b[ex]; t[j][3] = b[ex + 1];
+          t[j][4] = b[pl]; t[j][5] = b[pl + 1]; t[j][6] = b[pl + ex]; t[j][7] = b[pl + ex + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) {
+          const float c00 = lerpf(t[j][0], t[j][1], wx[j]), c10 = lerpf(t[j][2], t[j][3], wx[j]);
+          const float c01 = lerpf(t[j][4], t[j][5], wx[j]), c11 = lerpf(t[j][6], t[j][7], wx[j]);
+          dv[j] = lerpf(lerpf(c00, c10, wy[j]), lerpf(c01, c11, wy[j]), wz[j]);
+        }
+        RR_STAT(3, kSub);
+      } else {
+        // no box, or some lane's taps fall outside the estimate (rounding of the addition chain, a NaN): the whole sub-batch from
+        // global memory -- the same operands, the same result
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) dv[j] = want[j] ? tex3d_tsdf<false, true>(V, q[j].x, q[j].y, q[j].z) : 0.0f;
+        RR_STAT(4, kSub);
+      }
+#pragma unroll
+      for (int j = 0; j < kSub; ++j) {
+        if (!hit && n < max_n && k0 + j < s_run) {
+          n += 1;
+          if (dv[j] > 0.0f) { hit = true; hit_pos = q[j]; hit_d = dv[j]; }
+          else prev = dv[j];
+        }
+      }
+      p = make_float3(q[kSub - 1].x + step.x, q[kSub - 1].y + step.y, q[kSub - 1].z + step.z);
+#pragma unroll
+      for (int j = kSub - 1; j >= 1; --j) if (s_run - k0 == j) p = q[j];     // a last, shorter sub-batch: the chain stops after j additions
     }
     pos = p;
     __builtin_amdgcn_wave_barrier();                                      // the next batch overwrites the box
