@@ -1,17 +1,17 @@
 #!/bin/bash
 # tools/profile_round.sh TAG : on the GPU box -- kernel-trace stats + FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (separate runs) of
-# bench.py for c2 and c1.  The --pmc passes are reduced to one row per (kernel, counter) by tools/pmc_aggregate.py (the raw CSVs hold one
-# row per launch, megabytes per pass).
+# bench.py for c2 and c1, then the plain bench lines.  The --pmc passes are reduced to one row per (kernel, counter) by
+# tools/pmc_aggregate.py (the raw CSVs hold one row per launch, megabytes per pass).
 set -e
 TAG=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 for c in c2 c1; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/$c -o stats -- python3 $R/bench.py --config $c --no-cpu-baseline --steps 100 > $R/gpurun_out/$TAG/bench_stats_$c.json 2> $R/gpurun_out/$TAG/stats_$c.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/$c -o stats -- python3 $R/bench.py --config $c --no-cpu-baseline --no-c1 --long-steps 0 --steps 100 > $R/gpurun_out/$TAG/bench_stats_$c.json 2> $R/gpurun_out/$TAG/stats_$c.err
   echo "stats $c done"
   for pmc in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-    rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_$c -o $pmc -- python3 $R/bench.py --config $c --no-cpu-baseline --no-timers --steps 20 --warmup 3 > /dev/null 2> $R/gpurun_out/$TAG/${pmc}_$c.err
+    rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_$c -o $pmc -- python3 $R/bench.py --config $c --no-cpu-baseline --no-timers --no-c1 --long-steps 0 --steps 20 --warmup 3 > /dev/null 2> $R/gpurun_out/$TAG/${pmc}_$c.err
     f=$(find /tmp/pmc_$c -name "${pmc}_counter_collection.csv" | head -n 1)
     python3 $R/tools/pmc_aggregate.py $f $R/gpurun_out/$TAG/pmc_${pmc}_$c.csv
     echo "$pmc $c done"
@@ -20,6 +20,11 @@ for c in c2 c1; do
 done
 cd $R
 python3 bench.py > gpurun_out/$TAG/bench_c2.json 2> gpurun_out/$TAG/bench_c2.err
-python3 bench.py --config c1 > gpurun_out/$TAG/bench_c1.json 2> gpurun_out/$TAG/bench_c1.err
-python3 bench.py --preprocess --no-cpu-baseline > gpurun_out/$TAG/bench_c2_pre.json 2> gpurun_out/$TAG/bench_c2_pre.err
-ls -R gpurun_out/$TAG
+echo "bench c2 done"
+python3 bench.py --config c1 --no-cpu-baseline > gpurun_out/$TAG/bench_c1.json 2> gpurun_out/$TAG/bench_c1.err
+python3 bench.py --config c3 --no-cpu-baseline --no-c1 > gpurun_out/$TAG/bench_c3.json 2> gpurun_out/$TAG/bench_c3.err
+python3 bench.py --config c4 --no-cpu-baseline --no-c1 > gpurun_out/$TAG/bench_c4.json 2> gpurun_out/$TAG/bench_c4.err
+echo "bench c1 c3 c4 done"
+RR_BENCH_EXCHANGE_ALONE=1 python3 bench.py --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_exchange_alone.json 2> gpurun_out/$TAG/bench_c2_exchange_alone.err
+python3 bench.py --frames-in-flight 3 --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_3_frames_in_flight.json 2> gpurun_out/$TAG/bench_c2_3fif.err
+echo "all done"
