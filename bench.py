@@ -187,6 +187,9 @@ def main():
     # collectives of a world of one, composite -- so that the cost of the collective path itself can be read on a 1-GPU box
     alone = world == 1 and os.environ.get("RR_BENCH_EXCHANGE_ALONE") == "1"
     if alone:
+        # a whole-volume context shades its long rays in place (k_shade_and_long), outside the hit list the compact exchange ships:
+        # the one-rank rehearsal marches in a single pass like a slab context does (read when the context is created)
+        os.environ["RR_MARCH_CAP"] = "0"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     if world > 1:
