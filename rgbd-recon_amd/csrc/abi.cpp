@@ -548,6 +548,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   CHECK_CTX(c);
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);          // (a null handle is the NULL stream: tsdf_adopt_null_stream)
+  if (c->copy_stream) hipStreamSynchronize(c->copy_stream);   // an asynchronous upload may still be writing a frame slot
   release_view(c); release_bricks(c);
   hipFree(c->tiles.stamp); hipFree(c->d_cls_all); hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts);
   hipFree(c->vol.data); hipFree(c->vol.slot); 
@@ -689,11 +690,11 @@ static int32_t ensure_async_upload(tsdf_ctx* c) {
   if (c->copy_stream) return TSDF_OK;
   const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h, nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
   const size_t bytes = np * 16 + nc * 3;
-  for (int k = 0; k < 2; ++k) {
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_stage[k], bytes, hipHostMallocDefault));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->stage_done[k], hipEventDisableTiming));
+  for (int k = 0; k < 2; ++k) {                                            // (re-entered after a failed first attempt: keep what exists)
+    if (!c->h_stage[k]) HIP_TRY(c, hipHostMalloc((void**)&c->h_stage[k], bytes, hipHostMallocDefault));
+    if (!c->stage_done[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_done[k], hipEventDisableTiming));
   }
-  HIP_TRY(c, hipMalloc((void**)&c->d_astage, bytes));
+  if (!c->d_astage) HIP_TRY(c, hipMalloc((void**)&c->d_astage, bytes));
   if (int32_t rc = alloc_frame_slot(c, 0)) return rc;
   if (int32_t rc = alloc_frame_slot(c, 1)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));                             // the new slot's colour memset
