@@ -98,6 +98,7 @@ struct tsdf_ctx {
   uint32_t* d_tri_z = nullptr; float4* d_tri_acc = nullptr; float min_length = 0.0125f;   // triangle-grid back-end; KinectCalibrationFile.cpp:96 default
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
   bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)
+  bool march_box = true;          // RR_MARCH_BOX=0: the dense march gathers from global memory as in round 1 (A/B and test hook, read at creation)
   void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
   unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
   float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
@@ -205,6 +206,7 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   HIP_TRY(c, hipMalloc(&c->d_hit_counters, 4 * sizeof(uint32_t)));
   HIP_TRY(c, hipMemsetAsync(c->d_hit_counters, 0, 4 * sizeof(uint32_t), c->stream));
   if (const char* e = getenv("RR_MARCH_CAP")) c->march_cap = (uint32_t)atoi(e);
+  if (const char* e = getenv("RR_MARCH_BOX")) c->march_box = atoi(e) != 0;
   if (const char* e = getenv("RR_K1_FORM")) c->k1_form_cap = atoi(e);     // A/B and test hook, read when the context is created
   if (const char* e = getenv("RR_IMAGE_TILES")) c->use_tile_history = atoi(e) != 0;
   c->hit_parity = 0;
@@ -1058,9 +1060,9 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   } else c->tile_history = false;
   timer_begin(c, "draw");
   timer_begin(c, "k_march");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu);
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
   timer_end(c, "k_march");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu);
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
   c->hit_parity ^= 1;
   if (masked_direct(c)) launch_resolve_masked(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
   timer_end(c, "draw");

@@ -877,7 +877,13 @@ __global__ __launch_bounds__(256, RR_SHADE_BOUNDS) void k_shade(ViewParams P, St
 // ONE launch for the two independent jobs that follow the first march pass: blocks [0, kLongBlocks) finish the long rays
 // (and shade their own hits on the spot), the rest shade the first pass's hit list.  Saves a dependent launch (~5 us of
 // ramp) and overlaps two latency-bound kernels: 15 + 19 us -> ~21 us.
-constexpr uint32_t kLongBlocks = 512;
+#ifndef RR_LONG_BLOCKS
+#define RR_LONG_BLOCKS 512
+#endif
+#ifndef RR_SHADE_BLOCKS
+#define RR_SHADE_BLOCKS 1024
+#endif
+constexpr uint32_t kLongBlocks = RR_LONG_BLOCKS, kShadeBlocks = RR_SHADE_BLOCKS;
 template <bool kSparse>
 __global__ __launch_bounds__(256, RR_SHADE_BOUNDS) void k_shade_and_long(ViewParams P, StreamTable T, FrameImages F, Volume V, RayTarget R, const Hit* __restrict__ hits,
                                                         const uint32_t* __restrict__ hit_count, uint32_t* __restrict__ next_count,
@@ -885,12 +891,8 @@ __global__ __launch_bounds__(256, RR_SHADE_BOUNDS) void k_shade_and_long(ViewPar
   if (blockIdx.x < kLongBlocks) march_long<kSparse>(P, V, R, longs, long_count, kLongBlocks, &T, &F);
   else shade_list<kSparse>(P, T, F, V, R, hits, hit_count, next_count, kLongBlocks);
 }
-static bool box_march_enabled() {                     // RR_MARCH_BOX=0: the global-gather march (A/B and test hook)
-  static const bool on = [] { const char* e = getenv("RR_MARCH_BOX"); return !e || atoi(e) != 0; }();
-  return on;
-}
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
-                     void* hit_list, uint32_t* hit_counters, int parity, int phase, void* long_list, uint32_t cap) {
+                     void* hit_list, uint32_t* hit_counters, int parity, int phase, void* long_list, uint32_t cap, int box_march) {
   // phase 2: k_march alone; phase 3: k_shade alone; 0: everything (the split lets the caller time the march kernel alone)
   dim3 grid((P.w + 15) / 16, (P.h + 15) / 16);
   // counters: [hit parity 0, hit parity 1, long parity 0, long parity 1]
@@ -902,15 +904,15 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
 #define RR_LAUNCH_MARCH(PART, SP, B) hipLaunchKernelGGL((k_march<PART, SP, B>), grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity, ll, hit_counters + 2 + parity, cap1)
     if (partial) { if (sparse) RR_LAUNCH_MARCH(true, true, kBatchDense); else RR_LAUNCH_MARCH(true, false, kBatchDense); }
     else if (two_pass) { if (sparse) RR_LAUNCH_MARCH(false, true, kBatchSkip); else RR_LAUNCH_MARCH(false, false, kBatchSkip); }
-    else if (!sparse && !P.skip && box_march_enabled()) hipLaunchKernelGGL(k_march_box, grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+    else if (!sparse && !P.skip && box_march) hipLaunchKernelGGL(k_march_box, grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
     else { if (sparse) RR_LAUNCH_MARCH(false, true, kBatchDense); else RR_LAUNCH_MARCH(false, false, kBatchDense); }
 #undef RR_LAUNCH_MARCH
   }
   if (phase == 2) return;
   if (two_pass) {
-    if (sparse) hipLaunchKernelGGL(k_shade_and_long<true>, dim3(kLongBlocks + 1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1),
+    if (sparse) hipLaunchKernelGGL(k_shade_and_long<true>, dim3(kLongBlocks + kShadeBlocks), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1),
                                    (const LongRay*)long_list, hit_counters + 2 + parity);
-    else hipLaunchKernelGGL(k_shade_and_long<false>, dim3(kLongBlocks + 1024), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1),
+    else hipLaunchKernelGGL(k_shade_and_long<false>, dim3(kLongBlocks + kShadeBlocks), dim3(256), 0, st, P, T, F, V, R, (const Hit*)hit_list, hit_counters + parity, hit_counters + (parity ^ 1),
                             (const LongRay*)long_list, hit_counters + 2 + parity);
     return;
   }

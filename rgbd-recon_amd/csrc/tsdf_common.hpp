@@ -198,7 +198,8 @@ struct RayTarget {
   const uint8_t* touched_cur; uint8_t* touched_prev; int rewrite_all;   // 8x8-pixel tile history (k_raymarch.hip); null = none
 };
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
-                     void* hit_list, uint32_t* hit_counters, int parity, int phase = 0, void* long_list = nullptr, uint32_t cap = 0xffffffffu);
+                     void* hit_list, uint32_t* hit_counters, int parity, int phase = 0, void* long_list = nullptr, uint32_t cap = 0xffffffffu,
+                     int box_march = 1);   // dense whole-volume march without depth limits: 1 = through LDS voxel boxes with tile-class leaps (k_march_box), 0 = gather march
 // hit_list: 16 B per view pixel; long_list: 32 B per view pixel (rays handed to the wave-per-ray pass after `cap` samples);
 // hit_counters: 4 words [hit, hit', long, long'], the primed ones re-armed for the next frame by k_shade
 void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod);

@@ -285,3 +285,65 @@ def test_occupied_sliver_bricks_over_an_incremental_sequence(rr):
             o.fillColors()
         (ac, adp), (bc, bdp) = hip.framebuffer(), orc.framebuffer()
         assert same(adp, bdp).all() and same(ac, bc).all(), f"frame {f} framebuffer"
+
+
+# ------------------------------------------------------------------------------------------------ dense march through LDS boxes
+def _dense(o):
+    o.setUseBricks(False); o.setSpaceSkip(False); o.setColorFilling(False)
+
+
+@pytest.mark.parametrize("res", [(64, 64, 64), (40, 56, 72), (37, 61, 50)])
+def test_box_march_equals_gather_march_and_oracle(rr, small_scene, res, monkeypatch):
+    """k_march_box (voxel boxes in LDS, all-clear boxes, tile-class leaps) against the round-1 gather march (RR_MARCH_BOX=0) and the
+    oracle: eyes far away, grazing, INSIDE the volume (rays of one 8x8 tile diverge: boxes that do not fit, the global path) and on
+    an axis; volumes that are not multiples of the 8-voxel tile; a view that is not a multiple of the 8x8 ray tile."""
+    kw = dict(res=res, brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(173, 99))
+    pr = rr.scene.gl_flat(rr.scene.perspective(50.0, 173 / 99.0, 0.1, 200.0))
+    box = rr.ReconIntegrationHip(small_scene, **kw)
+    monkeypatch.setenv("RR_MARCH_BOX", "0")
+    gather = rr.ReconIntegrationHip(small_scene, **kw)
+    monkeypatch.delenv("RR_MARCH_BOX")
+    orc = OracleRecon(small_scene, **kw)
+    for o in (box, gather, orc):
+        _dense(o)
+        o.integrate()
+    for eye, at in (((0.0, 1.1, 3.0), (0.0, 1.1, 0.0)), ((2.6, 2.0, 2.2), (0.0, 1.0, 0.0)), ((0.2, 1.0, 0.3), (0.0, 1.1, -1.0)),
+                    ((0.05, 1.1, 0.05), (0.9, 1.3, 0.7)), ((0.0, 5.0, 0.001), (0.0, 0.0, 0.0)), ((-3.5, 1.1, 0.0), (0.0, 1.1, 0.0))):
+        mv = rr.scene.gl_flat(rr.scene.look_at(eye, at))
+        for o in (box, gather, orc):
+            o.draw(mv, pr)
+        (ba, bd, bn, _), (ga, gd, gn, _), (oa, od, on, _) = box.view_images(), gather.view_images(), orc.view_images()
+        assert same(bn, gn).all() and same(bd, gd).all() and same(ba, ga).all(), f"box vs gather, eye {eye}"
+        assert same(bn, on).all() and same(bd, od).all() and same(ba, oa).all(), f"box vs oracle, eye {eye}"
+        assert (bn > 0).sum() > 500
+
+
+def test_box_march_on_uploaded_volumes(rr, small_scene):
+    """tsdf_upload_volume leaves every tile class 'mixed' (no leaps) -- and the classes must come back exact with the next integrate.
+    Random densities, exact -limit regions, NaN and infinite voxels."""
+    kw = dict(res=(48, 40, 56), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(160, 90))
+    mv, pr = rr.scene.default_view(160, 90)
+    hip, orc = rr.ReconIntegrationHip(small_scene, **kw), OracleRecon(small_scene, **kw)
+    for o in (hip, orc):
+        _dense(o)
+    rng = np.random.default_rng(3)
+    lim = np.float32(0.04)
+    for case in range(4):
+        v = np.full((56, 40, 48), -lim, np.float32)
+        if case == 0:
+            v[20:40, 10:30, 12:36] = rng.uniform(-0.04, 0.04, (20, 20, 24)).astype(np.float32)
+        elif case == 1:
+            v[:] = rng.uniform(-0.04, 0.001, v.shape).astype(np.float32)
+        elif case == 2:
+            v[24:32] = np.nan; v[40:44, :, :] = np.float32(0.02); v[10, 10, 10] = np.inf
+        else:
+            v[:] = -lim                                                        # nothing to hit: every ray runs its full length
+        for o in (hip, orc):
+            o.set_tsdf(v)
+            o.draw(mv, pr)
+        (ha, hd, hn, _), (oa, od, on, _) = hip.view_images(), orc.view_images()
+        assert same(hn, on).all() and same(hd, od).all() and same(ha, oa).all(), f"uploaded volume case {case}"
+    for o in (hip, orc):                                                       # back to integrated volumes: classes exact again, leaps on
+        o.integrate(); o.draw(mv, pr)
+    (ha, hd, hn, _), (oa, od, on, _) = hip.view_images(), orc.view_images()
+    assert same(hn, on).all() and same(hd, od).all() and same(ha, oa).all() and (hd < 1).sum() > 300
