@@ -216,8 +216,8 @@ class SlabDriver:
                     self._exchange_hits(min(self.npx, m))
         if self.stream is not None:
             self.stream.synchronize()
-        else:
-            self.b.sync() if hasattr(self.b, "sync") else None
+        elif hasattr(self.b, "sync"):
+            self.b.sync()
 
 
 def frame_slabs_on_one_device(backends, mv, proj, device, halo="exchange", composite="dense"):
