@@ -411,6 +411,25 @@ def main():
     if slabs_mode:
         out["slab_check"] = slab_check
         out["regathers"] = drv.regathers
+    # N > 1, an extra key, never `value`: what the same N GPUs deliver as N independent single-GPU frame streams (every frame rebuilds
+    # the volume from scratch, so frames are independent units: no exchange at all, weak scaling by construction)
+    if world > 1:
+        rep = make_ctx()
+        rdrv = mg.SlabDriver(rep, 0, 1, f"cuda:{local}", view=VIEW)
+        for i in range(50):
+            step(rdrv, i)
+        rdrv.finish()
+        barrier()
+        tr0 = time.perf_counter()
+        for i in range(args.steps):
+            step(rdrv, i)
+        rdrv.finish()
+        barrier()
+        dtr = max_over_ranks(time.perf_counter() - tr0)
+        out["frame_replicas"] = {"value": world * args.steps / dtr, "unit": "frames/s", "scaling": "weak",
+                                 "note": f"{world} unpartitioned contexts, one per GPU, each fusing its own frames: no data-path collective. Reported beside `value` "
+                                         "(the Z-slab partition of ONE volume), never as it"}
+        rep.close()
 
     # ---- roofline of the dominant kernel: ALGORITHMIC bytes of the units the launch really processes / its measured time
     def roofline(kname, alg, ms, cfgname, note):

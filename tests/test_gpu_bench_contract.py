@@ -59,4 +59,5 @@ def test_bench_with_two_ranks_runs_the_slab_partition_by_default():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "Z-slabs" in d["config"]["parallelism"]
     assert "bit-identical" in d["slab_check"] and d["regathers"] == 0
+    assert d["frame_replicas"]["scaling"] == "weak" and d["frame_replicas"]["value"] > 0     # an extra key beside the slab value, never instead of it
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"] and d["value"] > 30.0
