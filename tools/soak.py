@@ -1,6 +1,8 @@
-"""Long-run determinism soak: two different c2 frames (scene, view) alternating N times; the TSDF and the framebuffer must hash identically every CHECK frames
-(the per-frame state -- alternating tile lists, re-armed device counters, image-space dirty tiles, double-buffered brick
-counters -- is self-cleaning; a race or a stale counter would show as a drifting hash).   python tools/soak.py [N] [CHECK]"""
+"""Long-run determinism soak: two DIFFERENT frames (objects moved, so every tile churns; another view) alternating N times in one
+context; TSDF + framebuffer must hash identically to the first frame of their kind every CHECK frames (the per-frame state --
+alternating tile lists, re-armed device counters, image-space dirty tiles, double-buffered brick counters, exact tile classes, frame
+slots -- is self-cleaning; a race or a stale counter would show as a drifting hash).
+    python tools/soak.py [N] [CHECK] [c2|c1]"""
 import hashlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,13 +12,18 @@ rr = import_module("rgbd-recon_amd")
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 CHECK = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+CFG = sys.argv[3] if len(sys.argv) > 3 else "c2"
 VIEW = (1280, 720)
-scene = rr.scene.make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128)
+res = 512 if CFG == "c2" else 256
+mk = dict(n_streams=4, width=640, height=480, lut_res=128, inv_res=128)
+scene = rr.scene.make_scene(**mk)
+scene_b = rr.scene.make_scene(sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2), **mk)      # bench.py's frame B
 ext = scene["bbox_max"] - scene["bbox_min"]
-hip = rr.ReconIntegrationHip(scene, res=(512, 512, 512), brick_size=[float(ext[a]) / 512 * 8 for a in range(3)], limit=0.01, view=VIEW)
-hip.setUseBricks(True); hip.setSpaceSkip(True); hip.setColorFilling(True)
+hip = rr.ReconIntegrationHip(scene, res=(res,) * 3, brick_size=[float(ext[a]) / res * 8 for a in range(3)], limit=0.01, view=VIEW)
+dense = CFG != "c2"
+hip.setUseBricks(not dense); hip.setSpaceSkip(not dense); hip.setColorFilling(not dense)
+hip.select_frame_slot(1); hip.upload_frame(scene_b); hip.select_frame_slot(0)
 mv, pr = rr.scene.default_view(*VIEW)
-scene_b = rr.scene.make_scene(n_streams=4, width=640, height=480, lut_res=128, inv_res=128, seed=77)     # another object, another view
 mv_b = rr.scene.gl_flat(rr.scene.look_at((1.6, 1.4, 2.4), (0.0, 1.1, 0.0)))
 
 
@@ -29,11 +36,11 @@ ref = {}
 t0 = time.perf_counter()
 for f in range(1, N + 1):
     which = f & 1
-    hip.upload_frame(scene if which else scene_b)
+    hip.select_frame_slot(0 if which else 1)
     hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv if which else mv_b, pr)
     if f <= 2 or f % CHECK in (0, 1):
         h = digest()
         ref.setdefault(which, h)
         print(f"frame {f} ({'A' if which else 'B'}): {h[:16]} {'ok' if h == ref[which] else 'DIFFERENT'}  ({time.perf_counter() - t0:.1f} s)", flush=True)
         assert h == ref[which], f"frame {f} differs from the first frame of its kind"
-print("soak ok:", N, "frames")
+print("soak ok:", N, "frames", CFG)
