@@ -70,7 +70,7 @@ struct tsdf_ctx {
   FrameImages frame{};           // the CURRENT frame slot's images (what mark / integrate / draw read)
   // Two frame slots (the reference's double PBO + texture arrays, NetKinectArray.cpp:225-236): while the path computes on slot
   // `cur_slot`, tsdf_upload_frame_async fills the other one on a copy stream; tsdf_select_frame_slot makes it current.
-  struct FrameSlot { float4* dqs = nullptr; float* depth = nullptr; uchar4* color = nullptr; bool have = false;
+  struct FrameSlot { float4* dqs = nullptr; float* depth = nullptr; uchar4* color = nullptr; float4* ranges = nullptr; bool have = false;
                      hipEvent_t ready = nullptr; bool pending = false;      // recorded on the copy stream after the slot's upload + pack
                      hipEvent_t released = nullptr; bool in_use = false; }; // recorded on the compute stream when the slot stopped being current
   FrameSlot slots[2];
@@ -98,6 +98,8 @@ struct tsdf_ctx {
   uint32_t* d_tri_z = nullptr; float4* d_tri_acc = nullptr; float min_length = 0.0125f;   // triangle-grid back-end; KinectCalibrationFile.cpp:96 default
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
   bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)
+  float4* d_tile_bounds = nullptr; bool tile_bounds_valid = false;   // static per (stored tile, stream) LUT-box bounds, built on the first dense integrate after a calibration
+  bool use_ranges = true;         // RR_K1_RANGES=0: the dense integrate evaluates every voxel of every stream (A/B and test hook, read at creation)
   bool march_box = true;          // RR_MARCH_BOX=0: the dense march gathers from global memory as in round 1 (A/B and test hook, read at creation)
   void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
   unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
@@ -400,6 +402,7 @@ int32_t alloc_frame_slot(tsdf_ctx* c, int k) {
   HIP_TRY(c, hipMalloc((void**)&S.dqs, np * sizeof(float4)));
   HIP_TRY(c, hipMalloc((void**)&S.depth, np * sizeof(float)));
   HIP_TRY(c, hipMalloc((void**)&S.color, nc * sizeof(uchar4)));
+  HIP_TRY(c, hipMalloc((void**)&S.ranges, (size_t)c->cfg.num_streams * ((c->cfg.depth_w + 7) / 8) * ((c->cfg.depth_h + 7) / 8) * sizeof(float4)));
   HIP_TRY(c, hipMemsetAsync(S.color, 0, nc * sizeof(uchar4), c->stream));
   HIP_TRY(c, hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&S.released, hipEventDisableTiming));
@@ -408,6 +411,7 @@ int32_t alloc_frame_slot(tsdf_ctx* c, int k) {
 void use_frame_slot(tsdf_ctx* c, int k) {
   c->cur_slot = k;
   c->frame.dqs = c->slots[k].dqs; c->frame.depth = c->slots[k].depth; c->frame.color = c->slots[k].color;
+  c->frame.ranges = c->use_ranges ? c->slots[k].ranges : nullptr; c->frame.rcw = ((int)c->cfg.depth_w + 7) / 8; c->frame.rch = ((int)c->cfg.depth_h + 7) / 8;
 }
 
 int halo_layers_for(float limit, int res_z) { return (int)ceilf((limit * (float)res_z + 2.0f) / 8.0f); }
@@ -456,6 +460,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(TSDF_ERR_HIP); }
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   c->stream = c->own_stream;
+  if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
   // setVoxelSize(), :340-347
   for (int a = 0; a < 3; ++a) {
     const float ext = cfg->bbox_max[a] - cfg->bbox_min[a];
@@ -554,9 +559,9 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   release_view(c); release_bricks(c);
   hipFree(c->tiles.stamp); hipFree(c->d_cls_all); hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts);
   hipFree(c->vol.data); hipFree(c->vol.slot); 
-  for (auto& sl : c->slots) { hipFree(sl.dqs); hipFree(sl.depth); hipFree(sl.color); if (sl.ready) hipEventDestroy(sl.ready); if (sl.released) hipEventDestroy(sl.released); }
+  for (auto& sl : c->slots) { hipFree(sl.dqs); hipFree(sl.depth); hipFree(sl.color); hipFree(sl.ranges); if (sl.ready) hipEventDestroy(sl.ready); if (sl.released) hipEventDestroy(sl.released); }
   for (int k = 0; k < 2; ++k) { if (c->h_stage[k]) hipHostFree(c->h_stage[k]); if (c->stage_done[k]) hipEventDestroy(c->stage_done[k]); }
-  hipFree(c->d_astage);
+  hipFree(c->d_astage); hipFree(c->d_tile_bounds);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal);
   hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
@@ -663,6 +668,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
   c->ws_row[i] = worst[1] * worst[2] * 8;
   c->lds_ok[i] = worst[0] * worst[1] * worst[2] > integrate_box_cap() ? 0 : ((worst[1] * worst[2] * 8 <= integrate_row_cap() && worst[2] * 64 <= integrate_box_cap()) ? 2 : 1);
   c->have_calib[i] = true;
+  c->tile_bounds_valid = false;                                          // the tiles' LUT-box bounds belong to the old volumes
   return TSDF_OK;
 }
 
@@ -676,6 +682,7 @@ int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quali
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_q, quality, np * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_s, silhouette, np * 4, hipMemcpyHostToDevice, c->stream));
   launch_pack_frame(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, (float*)c->frame.depth, np);
+  launch_frame_ranges(c->stream, F.dqs, (int)c->cfg.num_streams, F.w, F.h, c->slots[c->cur_slot].ranges);
   if (colour) {
     HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
     launch_pack_color(c->stream, c->d_stage_col, (uchar4*)F.color, nc);
@@ -736,6 +743,7 @@ int32_t tsdf_upload_frame_async(tsdf_ctx* c, const float* depth_rg, const float*
   HIP_TRY(c, hipEventRecord(c->stage_done[k], c->copy_stream));
   c->stage_busy[k] = true; c->stage_k ^= 1;
   launch_pack_frame(c->copy_stream, (const float*)c->d_astage, (const float*)(c->d_astage + np * 8), (const float*)(c->d_astage + np * 12), S.dqs, S.depth, np);
+  launch_frame_ranges(c->copy_stream, S.dqs, (int)c->cfg.num_streams, c->frame.w, c->frame.h, S.ranges);
   if (with_colour) launch_pack_color(c->copy_stream, c->d_astage + np * 16, S.color, nc);
   HIP_TRY(c, hipEventRecord(S.ready, c->copy_stream));
   S.pending = true; S.have = true;
@@ -905,6 +913,7 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
   B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
   timer_begin(c, "1preprocess");
   launch_preprocess(c->stream, P, B, c->luts, c->frame, c->br);
+  launch_frame_ranges(c->stream, c->frame.dqs, (int)c->cfg.num_streams, c->frame.w, c->frame.h, c->slots[c->cur_slot].ranges);
   timer_end(c, "1preprocess");
   HIP_TRY(c, hipGetLastError());
   c->slots[c->cur_slot].have = true;
@@ -1017,7 +1026,14 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   }
   launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc, ws_box, ws_row);
   timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 2, nullptr, ws_box, ws_row);
+  // dense launches: the static half of the uniform-pair shortcut (k_integrate.hip), built once per calibration
+  const float4* bounds = nullptr;
+  if (!c->use_bricks && lds == 2 && c->frame.ranges) {
+    if (!c->d_tile_bounds) HIP_TRY(c, hipMalloc((void**)&c->d_tile_bounds, (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 2 * sizeof(float4)));
+    if (!c->tile_bounds_valid) { launch_tile_bounds(c->stream, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
+    bounds = c->d_tile_bounds;
+  }
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 2, nullptr, ws_box, ws_row, bounds);
   timer_end(c, "k_integrate_tiles");
   if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
   else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them

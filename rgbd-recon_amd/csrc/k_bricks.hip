@@ -15,6 +15,33 @@ __global__ __launch_bounds__(256) void k_pack_frame(const float2* __restrict__ d
     depth[i] = d;
   }
 }
+// Per 8x8-pixel cell of the packed {depth, quality, silhouette} image: {min depth, max depth, min silhouette, max silhouette}.  One wave per
+// cell (a lane per pixel), four cells per workgroup.  A NaN anywhere in a cell poisons its range to (-inf, +inf): the consumer's tests
+// then fail and it falls back to the per-voxel evaluation.
+__global__ __launch_bounds__(256) void k_frame_ranges(const float4* __restrict__ dqs, int n_streams, int w, int h, int rcw, int rch, float4* __restrict__ ranges) {
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+  if (cell >= n_streams * rcw * rch) return;
+  const int i = cell / (rcw * rch), r = cell % (rcw * rch), cy = r / rcw, cx = r % rcw;
+  const int px = cx * 8 + (ln & 7), py = cy * 8 + (ln >> 3);
+  float d0 = __builtin_inff(), d1 = -__builtin_inff(), s0 = __builtin_inff(), s1 = -__builtin_inff();
+  bool nan = false;
+  if (px < w && py < h) {
+    const float4 t = dqs[((size_t)i * h + py) * w + px];
+    d0 = d1 = t.x; s0 = s1 = t.z;
+    nan = (t.x != t.x) || (t.z != t.z);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    d0 = fminf(d0, __shfl_xor(d0, m)); d1 = fmaxf(d1, __shfl_xor(d1, m));
+    s0 = fminf(s0, __shfl_xor(s0, m)); s1 = fmaxf(s1, __shfl_xor(s1, m));
+  }
+  if (__ballot(nan) != 0ull) { d0 = s0 = -__builtin_inff(); d1 = s1 = __builtin_inff(); }
+  if (ln == 0) ranges[cell] = make_float4(d0, d1, s0, s1);
+}
+void launch_frame_ranges(hipStream_t st, const float4* dqs, int n_streams, int w, int h, float4* ranges) {
+  const int rcw = (w + 7) / 8, rch = (h + 7) / 8, cells = n_streams * rcw * rch;
+  hipLaunchKernelGGL(k_frame_ranges, dim3((cells + 3) / 4), dim3(256), 0, st, dqs, n_streams, w, h, rcw, rch, ranges);
+}
 __global__ __launch_bounds__(256) void k_pack_color(const uint8_t* __restrict__ rgb, uchar4* __restrict__ rgba, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     rgba[i] = make_uchar4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 255);

@@ -265,6 +265,99 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 // and with all of that in place the separable passes once more: 0.0542 / 0.2518 (the x pass alone: 0.0556 / 0.253).  Neither the
 // vector pipe (60 %) nor the LDS pipe (65 %) is saturated; the passes cut the traffic of both.  (Sharing the x/y-lerped LUT
 // planes between z-neighbour voxels of a thread on top of the direct form: 0.064 / 0.321.)
+// ---- uniform (tile, stream) pairs (round 2, dense launches).  Most of a dense volume is free space: for most tiles and streams EVERY
+// voxel takes the same branch of the fusion rule -- the tile projects onto background pixels (silhouette 0 and no depth: "carve if
+// untouched"), or lies wholly in front of the measured surface (-limit), or wholly behind it (nothing) -- and the per-voxel image
+// gather only confirms it.  That can be PROVEN per tile and stream from bounds, without touching a voxel:
+//   * the trilinear filter returns a convex combination of the texels of the tile's LUT box, so (u, v, z) of every voxel lies within the
+//     per-component min / max over the box (plus a rounding slack: three nested fp32 lerps are within a few ulps of the exact value);
+//   * the image taps of all voxels then lie in one pixel rectangle, and k_frame_ranges (k_bricks.hip) holds min / max of depth and
+//     silhouette per 8x8-pixel cell: a silhouette range of exactly {0} (or {1}) makes every bilinear silhouette exactly 0 (or 1), and a
+//     depth range bounds sdist = z - depth for every voxel, nearest texel included.
+// Outcome per pair: kPairFull (evaluate as before), kPairCarve (tsd >= limit ? -limit : tsd), kPairNeg (tsd = -limit), kPairNop.  Any
+// NaN / non-finite value, an oversized rectangle or a mixed range fails the tests (comparisons with NaN are false) -> kPairFull.
+// Each wave of the workgroup derives the class by itself from the box in LDS (same data, same instructions: the same answer), so the
+// shortcut costs no workgroup barrier.
+constexpr int kPairFull = 0, kPairCarve = 1, kPairNeg = 2, kPairNop = 3;
+__device__ __forceinline__ float wave_min_f32(float v) {          // DPP row shifts + row broadcasts, result wave-uniform (see k_raymarch.hip)
+#define RR_DPP_MIN(ctrl, rm, bm) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rm, bm, false)))
+  RR_DPP_MIN(0x111, 0xf, 0xf); RR_DPP_MIN(0x112, 0xf, 0xf); RR_DPP_MIN(0x114, 0xf, 0xe); RR_DPP_MIN(0x118, 0xf, 0xc);
+  RR_DPP_MIN(0x142, 0xa, 0xf); RR_DPP_MIN(0x143, 0xc, 0xf);
+#undef RR_DPP_MIN
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
+// Per (tile, stream) the (u, v, z) range over the tile's LUT texel box -- static: it depends on the calibration volume and the voxel
+// grid only -- is computed once (k_tile_bounds, below) as two float4 {u0, u1, v0, v1}, {z0, z1, -, -}; NaN marks a box with a
+// non-finite or far-away texel.  The class of (tile, stream i) for THIS frame, by one wave (the result is wave-uniform):
+__device__ __forceinline__ int classify_pair(const FrameImages& F, int i, float4 b0, float4 b1, float limit) {
+  const int ln = threadIdx.x & 63;
+  const float inf = __builtin_inff();
+  const float u0 = b0.x, u1 = b0.y, v0 = b0.z, v1 = b0.w, z0 = b1.x, z1 = b1.y;
+  if (!(u0 <= u1)) return kPairFull;                                   // NaN: the box holds something non-finite
+  // slack of the three nested lerps (each within ~3 ulps of a value bounded by the box): 1e-5 relative is two orders above it
+  const float su = 1.0e-5f * (1.0f + fmaxf(fabsf(u0), fabsf(u1))), sv = 1.0e-5f * (1.0f + fmaxf(fabsf(v0), fabsf(v1)));
+  // the texel rectangle of the bilinear footprints (axis_linear: f = u * n - 0.5, taps floor(f) and floor(f) + 1, clamped)
+  const float wf = (float)F.w, hf = (float)F.h;
+  const int x0 = (int)__builtin_amdgcn_fmed3f(floorf((u0 - su) * wf - 0.5f), 0.0f, wf - 1.0f), x1 = (int)__builtin_amdgcn_fmed3f(floorf((u1 + su) * wf - 0.5f) + 1.0f, 0.0f, wf - 1.0f);
+  const int y0 = (int)__builtin_amdgcn_fmed3f(floorf((v0 - sv) * hf - 0.5f), 0.0f, hf - 1.0f), y1 = (int)__builtin_amdgcn_fmed3f(floorf((v1 + sv) * hf - 0.5f) + 1.0f, 0.0f, hf - 1.0f);
+  const int cx0 = x0 >> 3, cy0 = y0 >> 3, cw = (x1 >> 3) - cx0 + 1, chh = (y1 >> 3) - cy0 + 1;
+  if (cw < 1 || chh < 1 || __mul24(cw, chh) > 64) return kPairFull;
+  float d0 = inf, d1 = -inf, s0 = inf, s1 = -inf;
+  if (ln < __mul24(cw, chh)) {
+    const int ry = (int)(((float)ln + 0.5f) * __builtin_amdgcn_rcpf((float)cw));          // ln / cw
+    const float4 r = F.ranges[(size_t)__mul24(__mul24(i, F.rch) + cy0 + ry, F.rcw) + (cx0 + ln - __mul24(ry, cw))];
+    d0 = r.x; d1 = r.y; s0 = r.z; s1 = r.w;
+  }
+  d0 = wave_min_f32(d0); d1 = wave_max_f32(d1); s0 = wave_min_f32(s0); s1 = wave_max_f32(s1);
+  const float sz = 1.0e-5f * (1.0f + fmaxf(fabsf(z0), fabsf(z1)) + fmaxf(fabsf(d0), fabsf(d1)));   // lerp slack of z + the rounding of z - depth
+  const bool all_le = (z1 + sz) - d0 <= -limit - sz;                   // sdist <= -limit for every voxel (false for NaN / infinite ranges)
+  const bool all_ge = (z0 - sz) - d1 >= limit + sz;                    // sdist >= limit for every voxel
+  const bool sil0 = s0 == 0.0f && s1 == 0.0f, sil1 = s0 == 1.0f && s1 == 1.0f;
+  if (sil0 && all_ge) return kPairCarve;                               // silhouette < 1: tsd >= limit -> -limit; otherwise sdist >= limit: nothing
+  if ((sil0 || sil1) && all_le) return kPairNeg;                       // carved by the silhouette rule or by sdist <= -limit: -limit either way
+  if (sil1 && all_ge) return kPairNop;                                 // behind the surface: nothing
+  return kPairFull;
+}
+// the static half: one wave per (stored tile, stream) reduces min / max of (u, v, z) over the tile's LUT texel box
+__global__ __launch_bounds__(256) void k_tile_bounds(StreamTable T, Volume V, float4* __restrict__ bounds, int n_tiles) {
+  const int ln = threadIdx.x & 63;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (long long)n_tiles * T.n) return;
+  const int tile = (int)(item / T.n), i = (int)(item % T.n);
+  const int t3[3] = {tile % V.ntx, (tile / V.ntx) % V.nty, V.tz0 + tile / (V.ntx * V.nty)};
+  const StreamLut& L = T.s[i];
+  int m[3], d[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {                                         // the same index arithmetic as phase A of the integrate kernels
+    const float step = 1.0f / (float)V.res[a];
+    const Axis lo = axis_linear(((float)min(t3[a] * 8, V.res[a] - 1) + 0.5f) * step, L.inv_res[a]);
+    const Axis hi = axis_linear(((float)min(t3[a] * 8 + 7, V.res[a] - 1) + 0.5f) * step, L.inv_res[a]);
+    m[a] = lo.i0; d[a] = hi.i1 - lo.i0 + 1;
+  }
+  const float inf = __builtin_inff();
+  float u0 = inf, u1 = -inf, v0 = inf, v1 = -inf, z0 = inf, z1 = -inf;
+  bool bad = false;
+  const int n = d[0] * d[1] * d[2];
+  for (int e = ln; e < n; e += 64) {
+    const int bx = e % d[0], by = (e / d[0]) % d[1], bz = e / (d[0] * d[1]);
+    const float4 t = L.inv[(uint32_t)__mul24(__mul24(m[2] + bz, L.inv_res[1]) + (m[1] + by), L.inv_res[0]) + (uint32_t)(m[0] + bx)];
+    bad |= !(fabsf(t.x) < 1.0e4f && fabsf(t.y) < 1.0e4f && fabsf(t.z) < 1.0e4f);        // NaN, infinities, far-away garbage
+    u0 = fminf(u0, t.x); u1 = fmaxf(u1, t.x); v0 = fminf(v0, t.y); v1 = fmaxf(v1, t.y); z0 = fminf(z0, t.z); z1 = fmaxf(z1, t.z);
+  }
+  const bool any_bad = __ballot(bad) != 0ull;
+  u0 = wave_min_f32(u0); u1 = wave_max_f32(u1); v0 = wave_min_f32(v0); v1 = wave_max_f32(v1); z0 = wave_min_f32(z0); z1 = wave_max_f32(z1);
+  if (ln == 0) {
+    const float q = __builtin_nanf("");
+    bounds[2 * item] = any_bad ? make_float4(q, q, q, q) : make_float4(u0, u1, v0, v1);
+    bounds[2 * item + 1] = any_bad ? make_float4(q, q, q, q) : make_float4(z0, z1, 0.0f, 0.0f);
+  }
+}
+void launch_tile_bounds(hipStream_t st, const StreamTable& T, const Volume& V, float4* bounds) {
+  const long long items = (long long)V.n_stored_tiles * T.n;
+  hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, T, V, bounds, V.n_stored_tiles);
+}
+
 #ifndef RR_K1_BOXCAP
 #define RR_K1_BOXCAP 384
 #endif
@@ -275,8 +368,10 @@ constexpr int kBoxCap = RR_K1_BOXCAP;   // LUT texels per stream held in LDS
 constexpr int kRowCap = 512;           // (separable form) x-pass results: dz * dy rows of 8
 static_assert(kBoxCap <= 1024, "phase B's division-free index decomposition is exact below 1024 only");
 
-template <bool kList, bool kSep>
-__global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check) {
+template <bool kList, bool kSep, bool kRanges = false>
+__global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
+                                                                             const float4* __restrict__ tile_bounds) {
+  __shared__ int s_pair[TSDF_MAX_STREAMS];        // (kRanges) class of (this tile, stream): kPairFull / Carve / Neg / Nop
   __shared__ float4 s_box[kBoxCap];             // the stream's texel box, x fastest: ((z - mz) * dy + (y - my)) * dx + (x - mx)
   __shared__ float4 s_row[kSep ? kRowCap : 1];  // (separable form) x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
   __shared__ int s_i0a[TSDF_MAX_STREAMS][3][8], s_i1a[TSDF_MAX_STREAMS][3][8];   // per stream, axis and voxel coordinate of the tile: the two texel indices ...
@@ -306,6 +401,14 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       wsum[h] = 0.0f;
     }
     // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)
+    if (kRanges) {                                                      // which streams treat every voxel of this tile alike?  one wave per stream
+      const uint32_t st_tile = stored_tile_index(V, tile);
+      for (int i = tid >> 6; i < T.n; i += 4) {
+        const size_t o = 2 * ((size_t)st_tile * T.n + i);
+        const int pair = classify_pair(F, i, tile_bounds[o], tile_bounds[o + 1], limit);
+        if ((tid & 63) == 0) s_pair[i] = pair;
+      }
+    }
     for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
       const int i = t / 24, a = (t % 24) >> 3, k = t & 7;
       const int coord = min(t3[a] * 8 + k, V.res[a] - 1);               // padding voxels reuse the last real coordinate
@@ -314,6 +417,18 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
     }
     __syncthreads();
     for (int i = 0; i < T.n; ++i) {
+      if (kRanges) {
+        const int pair = s_pair[i];                                     // workgroup-uniform
+        if (pair != kPairFull) {                                        // no box, no passes, no gathers: the branch is the same for every voxel
+#pragma unroll
+          for (int h = 0; h < kVox; ++h)
+            if (drawn[h]) {
+              if (pair == kPairNeg) tsd[h] = -limit;
+              else if (pair == kPairCarve && tsd[h] >= limit) tsd[h] = -limit;
+            }
+          continue;
+        }
+      }
       const StreamLut& L = T.s[i];
       const int (*s_i0)[8] = s_i0a[i];
       const int (*s_i1)[8] = s_i1a[i];
@@ -549,7 +664,7 @@ __global__ __launch_bounds__(256, RR_K1WS_BOUNDS) void k_integrate_tiles_ws(Stre
 }
 
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, int ws_box, int ws_row) {
+                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, int ws_box, int ws_row, const float4* tile_bounds) {
   const WsCaps wc{ws_box, ws_row};
   const size_t ws_lds = (size_t)kWsWaves * (size_t)(ws_box + ws_row) * sizeof(float4);
   // phase 1: tile classification + stale-tile clear; phase 2: the integrate kernel; 0: both (the split lets the caller time the kernel alone)
@@ -566,14 +681,15 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
     if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_ws<true>), grid, dim3(256), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, wc);
-    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
-    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
+    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
   } else {
     if (phase == 1) return;
     if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_ws<false>), dim3(S.n), dim3(256), ws_lds, st, T, F, V, B, S, 0, wc);
-    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
-    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
+    else if (lds_ok == 2 && F.ranges && tile_bounds) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds);
+    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr);
+    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
   }
 }

@@ -29,6 +29,10 @@ struct FrameImages {
   const float* depth;     // [N][H][W] depth.r alone (brick marking reads nothing else)
   const uchar4* color;    // [N][Hc][Wc]
   int w, h, cw, ch;
+  // per 8x8-pixel cell {min depth, max depth, min silhouette, max silhouette} of the packed image, [N][rch][rcw] (k_frame_ranges): lets the
+  // dense integrate decide for a whole tile and stream that every voxel takes the same branch of the fusion rule.  nullptr: not built.
+  const float4* ranges;
+  int rcw, rch;
 };
 
 // TSDF volume, tile-major: tile (tx,ty,tz) at ((tz - tz0) * nty + ty) * ntx + tx, voxel (x&7,y&7,z&7) inside
@@ -175,6 +179,7 @@ void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, 
 // launchers (one per kernel family, defined in the .hip files)
 void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, size_t n);
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);
+void launch_frame_ranges(hipStream_t st, const float4* dqs, int n_streams, int w, int h, float4* ranges);
 void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
 void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B);
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, uint32_t* next_count);
@@ -184,7 +189,9 @@ void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels
 // ... and so does the zeroing of the spare brick-counter buffer (`zero`, in 16-byte units of zero_words / 4)
 struct PeelClear { uint4* peels; const uint8_t* touched_prev; int w, h, ntx, n_tiles; uint32_t* zero; uint32_t zero_words; };   // null pointers: nothing to do
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr, int ws_box = 0, int ws_row = 0);
+                      int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr, int ws_box = 0, int ws_row = 0,
+                      const float4* tile_bounds = nullptr);   // per (stored tile, stream) 2 x float4 LUT-box bounds (launch_tile_bounds), or null
+void launch_tile_bounds(hipStream_t st, const StreamTable& T, const Volume& V, float4* bounds);
 int integrate_box_cap();
 int integrate_row_cap();
 void launch_mark_all_mixed(hipStream_t st, const TileState& S);

@@ -15,7 +15,7 @@ from importlib import import_module
 import numpy as np
 import pytest
 
-from helpers import assert_same
+from helpers import assert_same, tsdf_close
 from oracle.oracle import OracleRecon
 
 pytestmark = pytest.mark.gpu
@@ -347,3 +347,49 @@ def test_box_march_on_uploaded_volumes(rr, small_scene):
         o.integrate(); o.draw(mv, pr)
     (ha, hd, hn, _), (oa, od, on, _) = hip.view_images(), orc.view_images()
     assert same(hn, on).all() and same(hd, od).all() and same(ha, oa).all() and (hd < 1).sum() > 300
+
+
+# ------------------------------------------------------------------------------------------------ uniform (tile, stream) pairs in the dense integrate
+def test_dense_integrate_uniform_pair_shortcut_equals_per_voxel_evaluation(rr, monkeypatch):
+    """The dense integrate proves per tile and stream, from the LUT box bounds and the per-cell depth / silhouette ranges of the
+    frame, that every voxel takes the same branch of the fusion rule, and then skips the per-voxel gathers.  Against the same kernel
+    with the shortcut off (RR_K1_RANGES=0) and against the oracle: plain frames, a frame with NaN / infinite / out-of-range LUT
+    texels, NaN and negative depths, silhouettes that are neither 0 nor 1, zero quality (NaN voxels), and the raw-frame path."""
+    base = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
+    rng = np.random.default_rng(11)
+    scenes = [base, rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2))]
+    odd = dict(base)
+    inv = odd["cv_xyz_inv"].copy()
+    n = inv.shape[1]
+    for i, vals in enumerate(([np.nan, 0.3, 0.5], [np.inf, -np.inf, 0.4], [7.5, -3.25, 0.45], [0.5, 0.5, -2.0e5])):
+        inv[i, rng.choice(n, n // 60, replace=False), :3] = np.array(vals, np.float32)
+    odd["cv_xyz_inv"] = inv
+    d = odd["depth"].copy(); q = odd["quality"].copy(); s = odd["silhouette"].copy()
+    d[0, 10:14, 20:40, 0] = np.nan; d[1, 50:60, 70:90, 0] = -0.3; d[2, 80:82, :, 0] = np.inf
+    s[1, 30:50, 30:50] = 0.5; s[3, 60:70, 10:30] = np.nan; s[2, 5:9, 100:140] = 2.0
+    q[0] = 0.0
+    odd["depth"], odd["quality"], odd["silhouette"] = d, q, s
+    scenes.append(odd)
+    for res in ((64, 64, 64), (40, 56, 72), (128, 128, 128)):
+        kw = dict(res=res, brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04 if res[0] < 100 else 0.02, view=(64, 36))
+        for k, sc in enumerate(scenes):
+            fast = rr.ReconIntegrationHip(sc, **kw)
+            monkeypatch.setenv("RR_K1_RANGES", "0")
+            slow = rr.ReconIntegrationHip(sc, **kw)
+            monkeypatch.delenv("RR_K1_RANGES")
+            orc = OracleRecon(sc, **kw)
+            for o in (fast, slow, orc):
+                o.setUseBricks(False)
+                o.integrate()
+            a, b, c = fast.tsdf(), slow.tsdf(), orc.tsdf()
+            assert same(a, b).all(), f"res {res} scene {k}: shortcut vs per-voxel"
+            assert same(a, c).all(), f"res {res} scene {k}: shortcut vs oracle"
+            assert (a == np.float32(-kw["limit"])).mean() > 0.3 and (np.abs(a) < kw["limit"]).sum() > 100
+    # the pre-processing path produces the packed image (and its ranges) on the device
+    kw = dict(res=(64, 64, 64), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(64, 36))
+    hip, orc = rr.ReconIntegrationHip(base, **kw), OracleRecon(base, **kw)
+    hip.upload_raw_frame(base); orc.upload_raw_frame(base)
+    for o in (hip, orc):
+        o.setUseBricks(False)
+        o.clearOccupiedBricks(); o.processTextures(); o.updateOccupiedBricks(); o.integrate()
+    assert tsdf_close(hip.tsdf(), orc.tsdf(), 0.04).all()
