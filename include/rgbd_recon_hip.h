@@ -217,6 +217,9 @@ int32_t tsdf_draw_f(tsdf_ctx* ctx, const float modelview[16], const float projec
 
 /* ---- setters mirroring recon_integration.hpp:43-49,57 and reconstruction.hpp:20-23 --------------- */
 int32_t tsdf_set_tsdf_limit(tsdf_ctx* ctx, float limit);
+/* setVoxelSize(), recon_integration.cpp:340-353: resolution = ceil(bbox / size); the volume is re-allocated (its content is gone
+ * until the next integrate(), as in the reference) and the brick grid re-snapped from the current brick size.  Whole-volume contexts only. */
+int32_t tsdf_set_voxel_size(tsdf_ctx* ctx, float size);
 int32_t tsdf_set_use_bricks(tsdf_ctx* ctx, int32_t active);
 int32_t tsdf_set_space_skip(tsdf_ctx* ctx, int32_t active);
 int32_t tsdf_set_color_filling(tsdf_ctx* ctx, int32_t active);

@@ -113,6 +113,12 @@ class OracleRecon:
     def setShadeMode(self, m): self.flags["shade_mode"] = int(m); self._apply_flags()
     def setTsdfLimit(self, v): self._L.orc_set_limit(self._c, C.c_float(v))
 
+    def setVoxelSize(self, size):
+        self._L.orc_set_voxel_size(self._c, C.c_float(size))
+        res3, rb3, b3, nl = (C.c_uint32 * 3)(), (C.c_uint32 * 3)(), (C.c_float * 3)(), C.c_uint32()
+        self._L.orc_get_layout(self._c, res3, rb3, b3, C.byref(nl))
+        self.res, self.res_bricks, self.brick_size = tuple(res3), tuple(rb3), tuple(b3)
+
     # stereo modes of the client (kinect_client.cpp:616-669)
     def _apply_stereo(self):
         s = self.stereo

@@ -297,6 +297,15 @@ orc_ctx* orc_create(const orc_config* cfg) {
   return c;
 }
 void orc_destroy(orc_ctx* c) { delete c; }
+// setVoxelSize(), recon_integration.cpp:340-353: a new resolution, a new (uninitialised -> zero here) volume, and
+// setBrickSize(m_brick_size) with the brick size that is CURRENT, i.e. already snapped to the old voxels (:351, :462-464)
+void orc_set_voxel_size(orc_ctx* c, float size) {
+  const float ext[3] = {c->bsize.x, c->bsize.y, c->bsize.z};
+  for (int a = 0; a < 3; ++a) c->res[a] = (uint32_t)ceilf(ext[a] / size);
+  c->brick = {size * roundf(c->brick.x / size), size * roundf(c->brick.y / size), size * roundf(c->brick.z / size)};
+  c->tsdf.assign((size_t)c->res[0] * c->res[1] * c->res[2], 0.0f);
+  divide_box(c);
+}
 
 void orc_get_layout(orc_ctx* c, uint32_t* res3, uint32_t* res_bricks3, float* brick3, uint32_t* num_lods) {
   memcpy(res3, c->res, 12); memcpy(res_bricks3, c->res_bricks, 12);

@@ -369,6 +369,12 @@ class ReconIntegrationHip:
     def fillColors(self): self._ck(self._L.tsdf_fill_colors(self._c))
     def drawF(self, mv, proj): self._ck(self._L.tsdf_draw_f(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
     def setTsdfLimit(self, v): self._ck(self._L.tsdf_set_tsdf_limit(self._c, C.c_float(v)))
+
+    def setVoxelSize(self, size):
+        self._ck(self._L.tsdf_set_voxel_size(self._c, C.c_float(size)))
+        r3, b3, s3 = (C.c_uint32 * 3)(), (C.c_uint32 * 3)(), (C.c_float * 3)()
+        self._ck(self._L.tsdf_get_resolution(self._c, r3, b3, s3))
+        self.res, self.res_bricks, self.brick_size = tuple(r3), tuple(b3), tuple(s3)
     def setUseBricks(self, a): self._ck(self._L.tsdf_set_use_bricks(self._c, int(a)))
     def setSpaceSkip(self, a): self._ck(self._L.tsdf_set_space_skip(self._c, int(a)))
     def setColorFilling(self, a): self._ck(self._L.tsdf_set_color_filling(self._c, int(a)))

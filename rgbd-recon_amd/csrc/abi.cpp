@@ -430,6 +430,92 @@ RayTarget ray_target(tsdf_ctx* c) {
   return R;
 }
 
+// setVoxelSize()'s device side, recon_integration.cpp:340-348: the volume for the current c->res (tile-major storage, slot table of a
+// sparse pool, per-tile state and work lists).  Called by tsdf_create and tsdf_set_voxel_size; everything it allocates is released first.
+void release_volume(tsdf_ctx* c) {
+   hipFree(c->tiles.stamp); hipFree(c->d_cls_all);
+  hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts); hipFree(c->d_linear); hipFree(c->d_tile_bounds);
+  c->vol.data = nullptr; c->vol.slot = nullptr; c->tiles.stamp = nullptr; c->d_cls_all = nullptr;
+  c->d_tile_list[0] = c->d_tile_list[1] = nullptr; c->d_tile_counts = nullptr; c->d_linear = nullptr; c->d_tile_bounds = nullptr;
+  c->tile_bounds_valid = false; c->tile_parity = 0; c->full_classify = true; c->frame_stamp = 0;
+}
+int32_t setup_volume(tsdf_ctx* c) {
+  Volume& V = c->vol;
+  for (int a = 0; a < 3; ++a) V.res[a] = c->res[a];
+  V.ntx = (c->res[0] + 7) / 8; V.nty = (c->res[1] + 7) / 8;
+  const int ntz = (c->res[2] + 7) / 8;
+  if (!(V.limit > 0.0f)) V.limit = c->cfg.limit;                       // (re-created by setVoxelSize: keeps the current setTsdfLimit value)
+  uint32_t z0 = c->cfg.slab_z0, z1 = c->cfg.slab_z1;
+  if (z0 == 0 && z1 == 0) z1 = (uint32_t)c->res[2];
+  if (z1 > (uint32_t)c->res[2] || z0 >= z1 || (z0 % 8) != 0 || (z1 % 8 != 0 && z1 != (uint32_t)c->res[2])) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "slab range must be tile (8) aligned and inside the volume");
+  V.own_tz0 = (int)z0 / 8; V.own_tz1 = ((int)z1 + 7) / 8;
+  // How far past a slab face an owned sample can make this context read (x = limit/2 * res_z voxels = one sampleDistance):
+  // the refined hit position lies up to one step behind the owned sample (tsdf_raymarch.fs:99-101), its gradient taps another
+  // sampleDistance further (:140-149), and the trilinear footprint of that tap half a voxel + one plane beyond:
+  // ceil(2x + 0.5) planes below the face, floor(2x + 0.5) + 1 above.  (limit * res_z + 2) planes cover both.
+  c->halo_layers = halo_layers_for(V.limit, c->res[2]);
+  const bool whole = (V.own_tz0 == 0 && V.own_tz1 == ntz);
+  V.tz0 = whole ? 0 : std::max(0, V.own_tz0 - c->halo_layers);
+  V.tz1 = whole ? ntz : std::min(ntz, V.own_tz1 + c->halo_layers);
+  V.zlo = V.tz0 * 8; V.zhi = std::min(V.tz1 * 8, c->res[2]) - 1;
+  const bool recompute = !whole && c->cfg.slab_recompute_halo != 0;
+  V.int_tz0 = recompute ? V.tz0 : V.own_tz0;
+  V.int_tz1 = recompute ? V.tz1 : V.own_tz1;
+  if (!whole && V.own_tz1 - V.own_tz0 < c->halo_layers) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "slab thinner than its halo");
+  const bool sparse = c->cfg.sparse_pool_tiles > 0;
+  V.n_stored_tiles = (V.tz1 - V.tz0) * V.nty * V.ntx;
+  if ((uint64_t)(V.tz1 - V.tz0) * V.nty * V.ntx >= (1ull << 31)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "more than 2^31 storage tiles");
+  if (sparse && !whole && !recompute) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "a sparse slab context needs slab_recompute_halo (exchanged halo layers have no pool slots)");
+  if (sparse && c->cfg.sparse_pool_tiles >= (1u << 23)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "sparse_pool_tiles must be below 2^23 (16 GiB of tiles)");
+  const size_t nvox = sparse ? (size_t)c->cfg.sparse_pool_tiles * TILE_VOX : (size_t)(V.tz1 - V.tz0) * V.nty * V.ntx * TILE_VOX;
+  if (nvox >= (1ull << 32)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "a context stores at most 2^32 voxels (32-bit tap offsets); split the volume into Z-slabs or use a sparse pool");
+  int32_t rc;
+  auto tryhip = [&](hipError_t e, const char* what) -> int32_t {
+    if (e == hipSuccess) return TSDF_OK;
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? TSDF_ERR_OUT_OF_MEMORY : TSDF_ERR_HIP;
+  };
+  release_volume(c);
+  if ((rc = tryhip(hipMalloc(&V.data, nvox * sizeof(float)), "hipMalloc(volume)"))) return rc;
+  launch_fill_u32(c->stream, (uint32_t*)V.data, 0u, nvox);
+  V.slot = nullptr; V.pool_tiles = 0;
+  if (sparse) {
+    if ((rc = tryhip(hipMalloc(&V.slot, (size_t)V.n_stored_tiles * sizeof(uint32_t)), "hipMalloc(slot table)"))) return rc;
+    if ((rc = tryhip(hipMemsetAsync(V.slot, 0xff, (size_t)V.n_stored_tiles * sizeof(uint32_t), c->stream), "hipMemset(slot table)"))) return rc;
+    V.pool_tiles = c->cfg.sparse_pool_tiles;
+  }
+  TileState& S = c->tiles;
+  S.n = (V.int_tz1 - V.int_tz0) * V.nty * V.ntx;
+  if ((rc = tryhip(hipMalloc(&S.stamp, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return rc;
+  if ((rc = tryhip(hipMalloc(&c->d_cls_all, (size_t)V.n_stored_tiles), "hipMalloc(tiles)"))) return rc;
+  hipMemsetAsync(c->d_cls_all, kTileMixed, (size_t)V.n_stored_tiles, c->stream);   // halo layers keep this value for good
+  V.cls = c->d_cls_all;
+  S.cls = c->d_cls_all + (size_t)(V.int_tz0 - V.tz0) * V.nty * V.ntx;
+  for (int k = 0; k < 2; ++k)
+    if ((rc = tryhip(hipMalloc(&c->d_tile_list[k], (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return rc;
+  if ((rc = tryhip(hipMalloc(&c->d_tile_counts, 2 * sizeof(uint32_t)), "hipMalloc(tiles)"))) return rc;
+  hipMemsetAsync(c->d_tile_counts, 0, 2 * sizeof(uint32_t), c->stream);
+  hipMemsetAsync(S.stamp, 0, (size_t)S.n * sizeof(uint32_t), c->stream);
+  S.list = c->d_tile_list[0]; S.count = c->d_tile_counts;
+  return TSDF_OK;
+}
+// the largest LUT texel box any 8^3 tile of the current volume touches, with the kernel's own fp32 index arithmetic, against the LDS
+// budget of the integrate kernels: which form stream i can use (depends on the LUT and on the volume resolution)
+void fit_lut_to_volume(tsdf_ctx* c, uint32_t i) {
+  const StreamLut& L = c->luts.s[i];
+  int worst[3] = {1, 1, 1};
+  for (int a = 0; a < 3; ++a) {
+    const float step = 1.0f / (float)c->res[a];
+    const int n = L.inv_res[a];
+    auto idx0 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k, 0), n - 1); };
+    auto idx1 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k + 1, 0), n - 1); };
+    for (int t = 0; t * 8 < c->res[a]; ++t) worst[a] = std::max(worst[a], idx1(std::min(t * 8 + 7, c->res[a] - 1)) - idx0(t * 8) + 1);
+  }
+  c->ws_box[i] = std::max(worst[0] * worst[1] * worst[2], worst[2] * 64);
+  c->ws_row[i] = worst[1] * worst[2] * 8;
+  c->lds_ok[i] = worst[0] * worst[1] * worst[2] > integrate_box_cap() ? 0 : ((worst[1] * worst[2] * 8 <= integrate_row_cap() && worst[2] * 64 <= integrate_box_cap()) ? 2 : 1);
+}
+
 }  // namespace
 
 extern "C" {
@@ -474,62 +560,13 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
     }
     if (c->res[a] < 1 || c->res[a] > 4096) { c->err = "volume resolution out of range [1, 4096]"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
   }
-  Volume& V = c->vol;
-  for (int a = 0; a < 3; ++a) V.res[a] = c->res[a];
-  V.ntx = (c->res[0] + 7) / 8; V.nty = (c->res[1] + 7) / 8;
-  const int ntz = (c->res[2] + 7) / 8;
-  V.limit = cfg->limit;
-  uint32_t z0 = cfg->slab_z0, z1 = cfg->slab_z1;
-  if (z0 == 0 && z1 == 0) z1 = (uint32_t)c->res[2];
-  if (z1 > (uint32_t)c->res[2] || z0 >= z1 || (z0 % 8) != 0 || (z1 % 8 != 0 && z1 != (uint32_t)c->res[2])) { c->err = "slab range must be tile (8) aligned and inside the volume"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
-  V.own_tz0 = (int)z0 / 8; V.own_tz1 = ((int)z1 + 7) / 8;
-  // How far past a slab face an owned sample can make this context read (x = limit/2 * res_z voxels = one sampleDistance):
-  // the refined hit position lies up to one step behind the owned sample (tsdf_raymarch.fs:99-101), its gradient taps another
-  // sampleDistance further (:140-149), and the trilinear footprint of that tap half a voxel + one plane beyond:
-  // ceil(2x + 0.5) planes below the face, floor(2x + 0.5) + 1 above.  (limit * res_z + 2) planes cover both.
-  c->halo_layers = halo_layers_for(cfg->limit, c->res[2]);
-  const bool whole = (V.own_tz0 == 0 && V.own_tz1 == ntz);
-  V.tz0 = whole ? 0 : std::max(0, V.own_tz0 - c->halo_layers);
-  V.tz1 = whole ? ntz : std::min(ntz, V.own_tz1 + c->halo_layers);
-  V.zlo = V.tz0 * 8; V.zhi = std::min(V.tz1 * 8, c->res[2]) - 1;
-  const bool recompute = !whole && cfg->slab_recompute_halo != 0;
-  V.int_tz0 = recompute ? V.tz0 : V.own_tz0;
-  V.int_tz1 = recompute ? V.tz1 : V.own_tz1;
-  if (!whole && V.own_tz1 - V.own_tz0 < c->halo_layers) { c->err = "slab thinner than its halo"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
-  const bool sparse = cfg->sparse_pool_tiles > 0;
-  V.n_stored_tiles = (V.tz1 - V.tz0) * V.nty * V.ntx;
-  if ((uint64_t)(V.tz1 - V.tz0) * V.nty * V.ntx >= (1ull << 31)) { c->err = "more than 2^31 storage tiles"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
-  if (sparse && !whole && !recompute) { c->err = "a sparse slab context needs slab_recompute_halo (exchanged halo layers have no pool slots)"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
-  if (sparse && cfg->sparse_pool_tiles >= (1u << 23)) { c->err = "sparse_pool_tiles must be below 2^23 (16 GiB of tiles)"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
-  const size_t nvox = sparse ? (size_t)cfg->sparse_pool_tiles * TILE_VOX : (size_t)(V.tz1 - V.tz0) * V.nty * V.ntx * TILE_VOX;
-  if (nvox >= (1ull << 32)) { c->err = "a context stores at most 2^32 voxels (32-bit tap offsets); split the volume into Z-slabs or use a sparse pool"; return fail(TSDF_ERR_INVALID_ARGUMENT); }
   int32_t rc;
+  if ((rc = setup_volume(c))) return fail(rc);
   auto tryhip = [&](hipError_t e, const char* what) -> int32_t {
     if (e == hipSuccess) return TSDF_OK;
     c->err = std::string(what) + ": " + hipGetErrorString(e);
     return e == hipErrorOutOfMemory ? TSDF_ERR_OUT_OF_MEMORY : TSDF_ERR_HIP;
   };
-  if ((rc = tryhip(hipMalloc(&V.data, nvox * sizeof(float)), "hipMalloc(volume)"))) return fail(rc);
-  launch_fill_u32(c->stream, (uint32_t*)V.data, 0u, nvox);
-  V.slot = nullptr; V.pool_tiles = 0;
-  if (sparse) {
-    if ((rc = tryhip(hipMalloc(&V.slot, (size_t)V.n_stored_tiles * sizeof(uint32_t)), "hipMalloc(slot table)"))) return fail(rc);
-    if ((rc = tryhip(hipMemsetAsync(V.slot, 0xff, (size_t)V.n_stored_tiles * sizeof(uint32_t), c->stream), "hipMemset(slot table)"))) return fail(rc);
-    V.pool_tiles = cfg->sparse_pool_tiles;
-  }
-  TileState& S = c->tiles;
-  S.n = (V.int_tz1 - V.int_tz0) * V.nty * V.ntx;
-  if ((rc = tryhip(hipMalloc(&S.stamp, (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
-  if ((rc = tryhip(hipMalloc(&c->d_cls_all, (size_t)V.n_stored_tiles), "hipMalloc(tiles)"))) return fail(rc);
-  hipMemsetAsync(c->d_cls_all, kTileMixed, (size_t)V.n_stored_tiles, c->stream);   // halo layers keep this value for good
-  V.cls = c->d_cls_all;
-  S.cls = c->d_cls_all + (size_t)(V.int_tz0 - V.tz0) * V.nty * V.ntx;
-  for (int k = 0; k < 2; ++k)
-    if ((rc = tryhip(hipMalloc(&c->d_tile_list[k], (size_t)S.n * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
-  if ((rc = tryhip(hipMalloc(&c->d_tile_counts, 2 * sizeof(uint32_t)), "hipMalloc(tiles)"))) return fail(rc);
-  hipMemsetAsync(c->d_tile_counts, 0, 2 * sizeof(uint32_t), c->stream);
-  hipMemsetAsync(S.stamp, 0, (size_t)S.n * sizeof(uint32_t), c->stream);
-  S.list = c->d_tile_list[0]; S.count = c->d_tile_counts;
   if ((rc = tryhip(hipHostMalloc((void**)&c->h_num_occupied, sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc"))) return fail(rc);
   *c->h_num_occupied = 0;
   if ((rc = setup_bricks(c, cfg->brick_size))) return fail(rc);
@@ -557,14 +594,13 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipStreamSynchronize(c->stream);          // (a null handle is the NULL stream: tsdf_adopt_null_stream)
   if (c->copy_stream) hipStreamSynchronize(c->copy_stream);   // an asynchronous upload may still be writing a frame slot
   release_view(c); release_bricks(c);
-  hipFree(c->tiles.stamp); hipFree(c->d_cls_all); hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts);
-  hipFree(c->vol.data); hipFree(c->vol.slot); 
+  release_volume(c);
   for (auto& sl : c->slots) { hipFree(sl.dqs); hipFree(sl.depth); hipFree(sl.color); hipFree(sl.ranges); if (sl.ready) hipEventDestroy(sl.ready); if (sl.released) hipEventDestroy(sl.released); }
   for (int k = 0; k < 2; ++k) { if (c->h_stage[k]) hipHostFree(c->h_stage[k]); if (c->stage_done[k]) hipEventDestroy(c->stage_done[k]); }
-  hipFree(c->d_astage); hipFree(c->d_tile_bounds);
+  hipFree(c->d_astage);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal);
-  hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col); hipFree(c->d_linear);
+  hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col);
   for (auto& per : c->lut_alloc) for (void* p : per) hipFree(p);
   if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
   hipFree(c->d_occ_counts);
@@ -654,19 +690,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
       c->have_cam[i] = true;
     }
   }
-  // largest LUT texel box any 8^3 tile touches, with the kernel's own fp32 index arithmetic, against the LDS budget of
-  // k_integrate_tiles_lds (kBoxCap texels)
-  int worst[3] = {1, 1, 1};
-  for (int a = 0; a < 3; ++a) {
-    const float step = 1.0f / (float)c->res[a];
-    const int n = (int)ri[a];
-    auto idx0 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k, 0), n - 1); };
-    auto idx1 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k + 1, 0), n - 1); };
-    for (int t = 0; t * 8 < c->res[a]; ++t) worst[a] = std::max(worst[a], idx1(std::min(t * 8 + 7, c->res[a] - 1)) - idx0(t * 8) + 1);
-  }
-  c->ws_box[i] = std::max(worst[0] * worst[1] * worst[2], worst[2] * 64);
-  c->ws_row[i] = worst[1] * worst[2] * 8;
-  c->lds_ok[i] = worst[0] * worst[1] * worst[2] > integrate_box_cap() ? 0 : ((worst[1] * worst[2] * 8 <= integrate_row_cap() && worst[2] * 64 <= integrate_box_cap()) ? 2 : 1);
+  fit_lut_to_volume(c, i);
   c->have_calib[i] = true;
   c->tile_bounds_valid = false;                                          // the tiles' LUT-box bounds belong to the old volumes
   return TSDF_OK;
@@ -1191,6 +1215,36 @@ int32_t tsdf_set_tsdf_limit(tsdf_ctx* c, float limit) {
   c->vol.limit = limit;
   launch_mark_all_mixed(c->stream, c->tiles);    // the clear value changed: no tile is known to hold it
   c->full_classify = true;
+  return TSDF_OK;
+}
+// setVoxelSize(), recon_integration.cpp:340-353: res = ceil(bbox / size), a new volume, and the brick grid re-snapped to the new
+// voxels from the CURRENT (already snapped) brick size -- the reference passes m_brick_size, not the originally requested value.
+int32_t tsdf_set_voxel_size(tsdf_ctx* c, float size) {
+  CHECK_CTX(c);
+  if (!(size > 0.0f)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "voxel size must be > 0");
+  if (c->cfg.slab_z0 != 0 || c->cfg.slab_z1 != 0) FAIL(c, TSDF_ERR_STATE, "setVoxelSize on a slab context: the slab range is in voxel planes of the old grid (re-create the contexts)");
+  int res[3];
+  for (int a = 0; a < 3; ++a) {
+    res[a] = (int)ceilf((c->cfg.bbox_max[a] - c->cfg.bbox_min[a]) / size);
+    if (res[a] < 1 || res[a] > 4096) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "volume resolution out of range [1, 4096]");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int old_res[3] = {c->res[0], c->res[1], c->res[2]};
+  const float old_vox[3] = {c->vox[0], c->vox[1], c->vox[2]};
+  const float brick[3] = {c->br.size[0], c->br.size[1], c->br.size[2]};
+  for (int a = 0; a < 3; ++a) { c->res[a] = res[a]; c->vox[a] = size; }
+  int32_t rc = setup_volume(c);
+  if (rc == TSDF_OK) rc = setup_bricks(c, brick);
+  if (rc != TSDF_OK) {                                                   // leave a usable context behind: back to the old grid
+    const std::string why = c->err;
+    for (int a = 0; a < 3; ++a) { c->res[a] = old_res[a]; c->vox[a] = old_vox[a]; }
+    if (setup_volume(c) == TSDF_OK) setup_bricks(c, brick);
+    c->err = why;
+    return rc;
+  }
+  for (uint32_t i = 0; i < c->cfg.num_streams; ++i) if (c->have_calib[i]) fit_lut_to_volume(c, i);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSDF_OK;
 }
 int32_t tsdf_set_use_bricks(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->use_bricks = a != 0; return TSDF_OK; }

@@ -290,7 +290,17 @@ __device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v
 // Per (tile, stream) the (u, v, z) range over the tile's LUT texel box -- static: it depends on the calibration volume and the voxel
 // grid only -- is computed once (k_tile_bounds, below) as two float4 {u0, u1, v0, v1}, {z0, z1, -, -}; NaN marks a box with a
 // non-finite or far-away texel.  The class of (tile, stream i) for THIS frame, by one wave (the result is wave-uniform):
-__device__ __forceinline__ int classify_pair(const FrameImages& F, int i, float4 b0, float4 b1, float limit) {
+// (not inlined, arguments by value: inlined into the integrate kernel its temporaries cost two spilled VGPRs at 8 waves/SIMD, and the
+// spill stores of 8 M threads were 44 MB of extra write traffic per dense launch)
+#ifndef RR_K1_CLASSIFY_INLINE
+#define RR_K1_CLASSIFY_INLINE 0
+#endif
+#if RR_K1_CLASSIFY_INLINE
+__device__ __forceinline__
+#else
+__device__ __attribute__((noinline))
+#endif
+int classify_pair(const float4* __restrict__ ranges, int rcw, int rch, int img_w, int img_h, int i, float4 b0, float4 b1, float limit) {
   const int ln = threadIdx.x & 63;
   const float inf = __builtin_inff();
   const float u0 = b0.x, u1 = b0.y, v0 = b0.z, v1 = b0.w, z0 = b1.x, z1 = b1.y;
@@ -298,7 +308,7 @@ __device__ __forceinline__ int classify_pair(const FrameImages& F, int i, float4
   // slack of the three nested lerps (each within ~3 ulps of a value bounded by the box): 1e-5 relative is two orders above it
   const float su = 1.0e-5f * (1.0f + fmaxf(fabsf(u0), fabsf(u1))), sv = 1.0e-5f * (1.0f + fmaxf(fabsf(v0), fabsf(v1)));
   // the texel rectangle of the bilinear footprints (axis_linear: f = u * n - 0.5, taps floor(f) and floor(f) + 1, clamped)
-  const float wf = (float)F.w, hf = (float)F.h;
+  const float wf = (float)img_w, hf = (float)img_h;
   const int x0 = (int)__builtin_amdgcn_fmed3f(floorf((u0 - su) * wf - 0.5f), 0.0f, wf - 1.0f), x1 = (int)__builtin_amdgcn_fmed3f(floorf((u1 + su) * wf - 0.5f) + 1.0f, 0.0f, wf - 1.0f);
   const int y0 = (int)__builtin_amdgcn_fmed3f(floorf((v0 - sv) * hf - 0.5f), 0.0f, hf - 1.0f), y1 = (int)__builtin_amdgcn_fmed3f(floorf((v1 + sv) * hf - 0.5f) + 1.0f, 0.0f, hf - 1.0f);
   const int cx0 = x0 >> 3, cy0 = y0 >> 3, cw = (x1 >> 3) - cx0 + 1, chh = (y1 >> 3) - cy0 + 1;
@@ -306,7 +316,7 @@ __device__ __forceinline__ int classify_pair(const FrameImages& F, int i, float4
   float d0 = inf, d1 = -inf, s0 = inf, s1 = -inf;
   if (ln < __mul24(cw, chh)) {
     const int ry = (int)(((float)ln + 0.5f) * __builtin_amdgcn_rcpf((float)cw));          // ln / cw
-    const float4 r = F.ranges[(size_t)__mul24(__mul24(i, F.rch) + cy0 + ry, F.rcw) + (cx0 + ln - __mul24(ry, cw))];
+    const float4 r = ranges[(size_t)__mul24(__mul24(i, rch) + cy0 + ry, rcw) + (cx0 + ln - __mul24(ry, cw))];
     d0 = r.x; d1 = r.y; s0 = r.z; s1 = r.w;
   }
   d0 = wave_min_f32(d0); d1 = wave_max_f32(d1); s0 = wave_min_f32(s0); s1 = wave_max_f32(s1);
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       const uint32_t st_tile = stored_tile_index(V, tile);
       for (int i = tid >> 6; i < T.n; i += 4) {
         const size_t o = 2 * ((size_t)st_tile * T.n + i);
-        const int pair = classify_pair(F, i, tile_bounds[o], tile_bounds[o + 1], limit);
+        const int pair = classify_pair(F.ranges, F.rcw, F.rch, F.w, F.h, i, tile_bounds[o], tile_bounds[o + 1], limit);
         if ((tid & 63) == 0) s_pair[i] = pair;
       }
     }

@@ -106,7 +106,7 @@ class ReconIntegrationHip {
   void setUseBricks(bool active) { check(tsdf_set_use_bricks(m_ctx, active)); }
   void setSpaceSkip(bool active) { check(tsdf_set_space_skip(m_ctx, active)); }
   void setDrawBricks(bool active) { m_draw_bricks = active; }    // wireframe debug overlay: not part of the HIP path
-  void setVoxelSize(float) { throw std::runtime_error("setVoxelSize: re-create the operator (the volume allocation is fixed at construction)"); }
+  void setVoxelSize(float size) { check(tsdf_set_voxel_size(m_ctx, size)); }      // recon_integration.cpp:340-353
   void setTsdfLimit(float limit) { check(tsdf_set_tsdf_limit(m_ctx, limit)); }
   void setBrickSize(float size) { const float s[3] = {size, size, size}; check(tsdf_set_brick_size(m_ctx, s)); m_brick_size = size; }
   unsigned numBricks() const { uint32_t n = 0; tsdf_num_bricks(m_ctx, &n); return n; }

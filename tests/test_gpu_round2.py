@@ -393,3 +393,30 @@ def test_dense_integrate_uniform_pair_shortcut_equals_per_voxel_evaluation(rr, m
         o.setUseBricks(False)
         o.clearOccupiedBricks(); o.processTextures(); o.updateOccupiedBricks(); o.integrate()
     assert tsdf_close(hip.tsdf(), orc.tsdf(), 0.04).all()
+
+
+# ------------------------------------------------------------------------------------------------ setVoxelSize
+def test_set_voxel_size_recreates_the_volume_like_the_reference(rr, small_scene):
+    """setVoxelSize(), recon_integration.cpp:340-353: resolution = ceil(bbox / size), a fresh volume, and the brick grid re-snapped from
+    the CURRENT (already snapped) brick size.  A sequence of sizes through one context and one oracle, culled and dense, each frame
+    against the oracle and against a context constructed with that size."""
+    kw = dict(voxel_size=0.05, brick_size=0.22, limit=0.04, view=(160, 90))
+    hip, orc = rr.ReconIntegrationHip(small_scene, **kw), OracleRecon(small_scene, **kw)
+    mv, pr = rr.scene.default_view(160, 90)
+    assert hip.res == orc.res == (40, 44, 40)
+    for size, dense in ((0.05, False), (0.031, False), (0.04, True), (0.07, False), (0.025, True)):
+        for o in (hip, orc):
+            o.setVoxelSize(size)
+            o.setUseBricks(not dense); o.setSpaceSkip(not dense)
+        assert hip.res == orc.res and hip.res_bricks == orc.res_bricks, (size, hip.res, orc.res, hip.res_bricks, orc.res_bricks)
+        assert np.allclose(hip.brick_size, orc.brick_size, rtol=0, atol=0)
+        assert frame_vs_oracle(hip, orc, mv, pr, f"voxel size {size}", peels=not dense) > 300
+        assert_same(hip.tsdf(), orc.tsdf(), f"voxel size {size} tsdf")
+    fresh = rr.ReconIntegrationHip(small_scene, **dict(kw, voxel_size=0.025))
+    assert fresh.res == hip.res                                               # (the brick grids differ: 0.22 snapped once vs through the sequence)
+    with pytest.raises(rr.TsdfError):
+        hip.setVoxelSize(0.0)
+    mgpu = import_module("rgbd-recon_amd.multigpu")
+    slab = rr.ReconIntegrationHip(small_scene, res=(64, 64, 64), brick_size=0.25, limit=0.04, view=(160, 90), slab=mgpu.slab_range(64, 0, 2))
+    with pytest.raises(rr.TsdfError):
+        slab.setVoxelSize(0.05)
