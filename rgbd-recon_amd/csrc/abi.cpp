@@ -123,6 +123,18 @@ struct tsdf_ctx {
 
 namespace {
 
+// n / d == (n * m) >> k for every n < 2^27: with l = ceil(log2 d), k = 27 + l and m = floor(2^k / d) + 1 = (2^k + e) / d, 0 < e <= d <= 2^l,
+// the product is n / d + n e / (d 2^k) with n e < 2^27 2^l = 2^k, i.e. less than 1 / d above the true quotient: the floor is the same.
+// (tile ids stay below 2^27: resolutions are capped at 4096 = 512 tiles per axis)
+FastDiv make_fast_div(uint32_t d) {
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  FastDiv f;
+  f.k = 27 + l;
+  f.m = (uint32_t)(((1ull << f.k) / d) + 1);
+  return f;
+}
+
 // ---- small double-precision matrix kit (column-major), results rounded once to float
 void mat_mul_d(const double* a, const double* b, double* o) {
   double r[16];
@@ -443,6 +455,7 @@ int32_t setup_volume(tsdf_ctx* c) {
   Volume& V = c->vol;
   for (int a = 0; a < 3; ++a) V.res[a] = c->res[a];
   V.ntx = (c->res[0] + 7) / 8; V.nty = (c->res[1] + 7) / 8;
+  V.div_layer = make_fast_div((uint32_t)(V.ntx * V.nty)); V.div_row = make_fast_div((uint32_t)V.ntx);
   const int ntz = (c->res[2] + 7) / 8;
   if (!(V.limit > 0.0f)) V.limit = c->cfg.limit;                       // (re-created by setVoxelSize: keeps the current setTsdfLimit value)
   uint32_t z0 = c->cfg.slab_z0, z1 = c->cfg.slab_z1;

@@ -58,8 +58,11 @@ __device__ __forceinline__ bool voxel_drawn(const Bricks& B, int x, int y, int z
 
 // index of integrated tile `tile` (int_tz0-relative) in the per-stored-tile tables (tz0-relative)
 __device__ __forceinline__ uint32_t stored_tile_index(const Volume& V, int tile) { return (uint32_t)tile + (uint32_t)((V.int_tz0 - V.tz0) * V.nty * V.ntx); }
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv f) { return (uint32_t)(((uint64_t)n * f.m) >> f.k); }
 __device__ __forceinline__ void tile_coords(const Volume& V, int tile, int& tx, int& ty, int& tz) {
-  tx = tile % V.ntx; ty = (tile / V.ntx) % V.nty; tz = V.int_tz0 + tile / (V.ntx * V.nty);
+  const uint32_t layer = fast_div((uint32_t)tile, V.div_layer), in_layer = (uint32_t)tile - layer * (uint32_t)(V.ntx * V.nty);
+  const uint32_t row = fast_div(in_layer, V.div_row);
+  tx = (int)(in_layer - row * (uint32_t)V.ntx); ty = (int)row; tz = V.int_tz0 + (int)layer;
 }
 
 // One lane per owned tile: is any occupied brick among those whose voxel lists can reach into the tile?  Active tiles go

@@ -36,10 +36,14 @@ struct FrameImages {
 };
 
 // TSDF volume, tile-major: tile (tx,ty,tz) at ((tz - tz0) * nty + ty) * ntx + tx, voxel (x&7,y&7,z&7) inside
+// n / d for n < 2^27 by one 64-bit multiply and a shift (m = floor(2^k / d) + 1, k = 27 + ceil(log2 d): exact, see make_fast_div).
+// A tile id is workgroup-uniform in the integrate kernels: this form stays on the scalar unit, an integer division does not.
+struct FastDiv { uint32_t m, k; };
 struct Volume {
   float* data;
   int res[3];          // logical resolution
   int ntx, nty;        // tiles per axis (x, y); z tiles stored: [tz0, tz1)
+  FastDiv div_layer, div_row;   // tile id / (ntx * nty), (tile id within a layer) / ntx
   int tz0, tz1;        // stored tile layers (owned slab + halo)
   int own_tz0, own_tz1;  // owned tile layers: the samples of the raymarch this context is responsible for
   int int_tz0, int_tz1;  // tile layers integrate() computes: the owned ones, plus the halo when it is recomputed locally
