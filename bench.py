@@ -134,6 +134,10 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--halo", default="recompute", choices=["recompute", "exchange"], help="N > 1: integrate the halo layers locally, or RCCL all-gather them")
     ap.add_argument("--composite", default="compact", choices=["compact", "dense"], help="N > 1: gather hit records, or whole partial images")
+    ap.add_argument("--compositor", default="auto", choices=["auto", "shared", "dedicated"],
+                    help="N > 1: 'dedicated' = rank 0 only receives, composites and fills holes and the volume is split over ranks 1..N-1 "
+                         "(the gathering rank's image-space tail is longer than a slab's share of the volume work, so an even split makes "
+                         "rank 0 every frame's critical path); 'shared' = N slabs, rank 0 composites as well.  auto = dedicated")
     ap.add_argument("--scene", default="moving", choices=["moving", "static"], help="alternate two resident frames in the timed region (default), or repeat one")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3, 4],
                     help="single GPU: process this many frames concurrently, one context + HIP stream per slot (every frame rebuilds the "
@@ -208,7 +212,8 @@ def main():
     scenes = [scene] + ([rr.scene.make_scene(**mk, **MOVED)] if args.scene == "moving" else [])
     ext = scene["bbox_max"] - scene["bbox_min"]
     brick = [float(ext[a]) / cfg["res"][a] * 8 for a in range(3)]          # 8^3 voxels per brick
-    slab = mg.slab_range(cfg["res"][2], rank, world) if slabs_mode else (0, 0)
+    dedicated = world > 1 and args.compositor != "shared"
+    slab = (mg.worker_slab_range if dedicated else mg.slab_range)(cfg["res"][2], rank, world) if slabs_mode else (0, 0)
 
     def make_ctx(slab=(0, 0), recompute=False, sparse=0):
         h = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=VIEW, device=local, slab=slab,
@@ -220,13 +225,15 @@ def main():
         return h
 
     hip = make_ctx(slab, args.halo == "recompute" and slabs_mode, args.sparse_pool)
+    if dedicated and world == 2 and rank == 1:
+        hip.setMarchCap(0)       # the one worker holds the whole volume: every hit has to be on the hit list the compact exchange ships
     # ONE explicit torch stream carries the context's kernels, the HIP event timers and the collectives (multigpu.py: the handle
     # of torch's default stream is 0 and cannot be handed over)
     stream = torch.cuda.Stream()
     if args.preprocess:
         hip.upload_raw_frame(scene)
     drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite,
-                        preprocess=args.preprocess, exchange_when_alone=alone, stream=stream)
+                        preprocess=args.preprocess, exchange_when_alone=alone, stream=stream, compositor="dedicated" if dedicated else "shared")
     mv, pr = rr.scene.default_view(*VIEW)
     nsc = len(scenes)
 
@@ -271,7 +278,13 @@ def main():
                 whole.clearOccupiedBricks(); whole.markBricks(); whole.updateOccupiedBricks(False); whole.integrate(); whole.drawF(mv, pr)
                 (wa, wd, wn, _), (wc, wdd) = whole.view_images(), whole.framebuffer()
                 (sa, sd, sn), (sc, sdd) = got[k]
-                ok &= same(np, sa, wa) and same(np, sd, wd) and same(np, sn, wn) and same(np, sc, wc) and same(np, sdd, wdd) and int((wd < 1).sum()) > 1000
+                if dedicated and args.composite == "compact":
+                    # the compositor did not march: the write-only sample-count image holds 0 where no slab hit (multigpu.py)
+                    hitpx = wd < 1
+                    ok &= same(np, sn[hitpx], wn[hitpx]) and bool((sn[~hitpx] == 0).all())
+                else:
+                    ok &= same(np, sn, wn)
+                ok &= same(np, sa, wa) and same(np, sd, wd) and same(np, sc, wc) and same(np, sdd, wdd) and int((wd < 1).sum()) > 1000
             whole.close()
             del whole
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{local}" if backend == "nccl" else "cpu")
@@ -279,7 +292,8 @@ def main():
             dist.broadcast(flag, src=0)
         if int(flag.item()) != 1:
             raise SystemExit("slab partition does NOT reproduce the unpartitioned frame: refusing to time it")
-        slab_check = f"rank 0: raymarch colour/depth/sample counts and the hole-filled framebuffer of {nsc} frame(s) bit-identical to an unpartitioned context"
+        slab_check = (f"rank 0: raymarch colour/depth/sample counts and the hole-filled framebuffer of {nsc} frame(s) bit-identical to an unpartitioned context"
+                      + (" (sample counts: at the hit pixels; the compositor does not march, the write-only count image holds 0 elsewhere)" if dedicated and args.composite == "compact" else ""))
 
     # host -> device frame upload, outside the timed region (value = HBM-resident rate); reported for the PCIe-inclusive figure
     hip.sync()
@@ -388,6 +402,12 @@ def main():
             frame_ms = {"frames": int(smp.size), "median": float(np.median(smp)), "p95": float(smp[min(smp.size - 1, int(0.95 * smp.size))]),
                         "min": float(smp[0]), "max": float(smp[-1]), "note": "HIP events around whole frames on rank 0, separate pass after the timed region"}
     ratio = hip.occupiedRatio()
+    stages_rank0 = None
+    if dedicated:
+        # rank 0 neither marks bricks nor integrates: the volume-side stage times and the occupancy come from the first worker
+        infos = [None] * world
+        dist.all_gather_object(infos, {"stage_ms": stages, "ratio": ratio})
+        stages_rank0, stages, ratio = stages, infos[1]["stage_ms"], infos[1]["ratio"]
     out = {
         "metric": "frames/sec (integrate+raymarch) at %d^3 x %d streams" % (cfg["res"][0], n_streams),
         "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -399,10 +419,12 @@ def main():
                    "frames_in_flight": args.frames_in_flight,
                    "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
                    "parallelism": ("single GPU, slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else
-                                  f"ONE volume in {world} Z-slabs (strong scaling), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame"},
+                                  (f"ONE volume in {world - 1} Z-slab(s) on ranks 1..{world - 1} + rank 0 as dedicated compositor (receive, composite, hole filling)" if dedicated else
+                                   f"ONE volume in {world} Z-slabs") + f" (strong scaling), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame"},
         "static": static,
         "long_run": long_run,
         "stage_ms": stages,
+        **({"stage_ms_compositor": stages_rank0} if stages_rank0 is not None else {}),
         "frame_device_ms": frame_ms,
         "stage_ms_note": "per-stage device time from a separate all-timers pass before the timed region (not part of `value`)",
         "upload_ms_per_frame": upload_ms,

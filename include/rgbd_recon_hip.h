@@ -282,6 +282,12 @@ int32_t tsdf_composite_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n);
 int32_t tsdf_export_hits_dev(tsdf_ctx* ctx, void* dst_dev, uint32_t capacity);
 /* n record buffers, stride_bytes apart, composited into this context's raymarch target (rank 0) */
 int32_t tsdf_composite_hits_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n, uint64_t stride_bytes);
+/* A whole-volume context marches in two passes: rays still running after `samples` samples are finished and shaded by a
+ * wave-per-ray pass, which writes the pixel directly -- such rays are NOT on the hit list tsdf_export_hits_dev ships.  0 switches the
+ * second pass off (every hit goes through the hit list, as in a slab context); the default is 24 (or RR_MARCH_CAP).  Used where one
+ * context holds the whole volume but its frame is composited elsewhere (one worker + one compositing GPU, multigpu.py).  Results do
+ * not depend on the value. */
+int32_t tsdf_set_march_cap(tsdf_ctx* ctx, uint32_t samples);
 
 /* ---- timers: the reference's TimerDatabase names: "2integrate", "3recon", "draw",
  * "holefill", "brickdraw", plus "bricks" (clear + mark + update).

@@ -379,6 +379,7 @@ class ReconIntegrationHip:
     def setSpaceSkip(self, a): self._ck(self._L.tsdf_set_space_skip(self._c, int(a)))
     def setColorFilling(self, a): self._ck(self._L.tsdf_set_color_filling(self._c, int(a)))
     def setMinVoxelsPerBrick(self, n): self._ck(self._L.tsdf_set_min_voxels_per_brick(self._c, int(n)))
+    def setMarchCap(self, samples): self._ck(self._L.tsdf_set_march_cap(self._c, C.c_uint32(int(samples))))
     def setShadeMode(self, m): self._ck(self._L.tsdf_set_shade_mode(self._c, int(m)))
     # stereo modes of the client (kinect_client.cpp:616-669): Reconstruction::setViewportOffset / setColorMaskMode + the GL state around them
     def setViewportOffset(self, x, y): self._ck(self._L.tsdf_set_viewport_offset(self._c, C.c_float(x), C.c_float(y)))

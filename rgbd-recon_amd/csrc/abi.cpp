@@ -102,6 +102,7 @@ struct tsdf_ctx {
   bool use_ranges = true;         // RR_K1_RANGES=0: the dense integrate evaluates every voxel of every stream (A/B and test hook, read at creation)
   bool march_box = true;          // RR_MARCH_BOX=0: the dense march gathers from global memory as in round 1 (A/B and test hook, read at creation)
   void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
+  bool own_miss_counts = false;   // this context has marched at this view size: its sample-count image holds the miss counts (-count, or count after a composite)
   unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
   float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
   float* d_linear = nullptr;     // scratch for volume up/download
@@ -224,6 +225,7 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   if (const char* e = getenv("RR_K1_FORM")) c->k1_form_cap = atoi(e);     // A/B and test hook, read when the context is created
   if (const char* e = getenv("RR_IMAGE_TILES")) c->use_tile_history = atoi(e) != 0;
   c->hit_parity = 0;
+  c->own_miss_counts = false;
   // the atlas starts as ViewLod::enable() leaves it (colour (0,1,0,0), depth 1); regions no kernel writes keep that
   launch_clear_image(c->stream, A.color, A.depth, na, make_float4(0.0f, 1.0f, 0.0f, 0.0f), 1.0f);
   launch_clear_image(c->stream, c->d_fb_c, c->d_fb_d, nv, make_float4(0, 0, 0, 0), 1.0f);
@@ -1117,6 +1119,7 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   timer_end(c, "k_march");
   launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
   c->hit_parity ^= 1;
+  c->own_miss_counts = true;
   if (masked_direct(c)) launch_resolve_masked(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
   timer_end(c, "draw");
   HIP_TRY(c, hipGetLastError());
@@ -1486,10 +1489,13 @@ int32_t tsdf_composite_hits_dev(tsdf_ctx* c, const void* gathered, uint32_t n, u
   if (!gathered || n < 1 || n > 32 || stride_bytes < 32) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->d_comp_key) HIP_TRY(c, hipMalloc(&c->d_comp_key, (size_t)c->vw * c->vh * sizeof(unsigned long long)));
-  launch_composite_hits(c->stream, gathered, (size_t)stride_bytes, (int)n, ray_target(c), c->vw, c->vh, c->d_comp_key);
+  // a compositing context that did not march this frame (dedicated compositor, multigpu.py) has no miss counts of its own: 0 then
+  launch_composite_hits(c->stream, gathered, (size_t)stride_bytes, (int)n, ray_target(c), c->vw, c->vh, c->d_comp_key, c->own_miss_counts ? 1 : 0);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
 }
+
+int32_t tsdf_set_march_cap(tsdf_ctx* c, uint32_t samples) { CHECK_CTX(c); c->march_cap = samples; c->tile_history = false; return TSDF_OK; }
 
 // ---- timers
 int32_t tsdf_enable_timers(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->timers_on = a != 0; return TSDF_OK; }

@@ -997,13 +997,13 @@ void launch_export_hits(hipStream_t st, const RayTarget& R, int w, const void* h
 // composite on the gathering rank: (1) every pixel starts as "no rank hit" (clear colour, depth 1, the common miss count),
 // (2) every record bids for its pixel with the key (sample count, rank, index) -- the smallest sample count is the first zero
 // crossing along the ray --, (3) the winning record writes the pixel.
-__global__ __launch_bounds__(256) void k_comp_init(RayTarget R, int w, int h, unsigned long long* __restrict__ key) {
+__global__ __launch_bounds__(256) void k_comp_init(RayTarget R, int w, int h, unsigned long long* __restrict__ key, int own_counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w * h) return;
   const int x = i % w, y = i / w;
   R.color[(size_t)y * R.stride + x] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
   R.depth[(size_t)y * R.stride + x] = 1.0f;
-  R.nsamples[i] = fabsf(R.nsamples[i]);             // misses carry -count in slab mode; a hit pixel is overwritten in (3)
+  R.nsamples[i] = own_counts ? fabsf(R.nsamples[i]) : 0.0f;   // misses carry -count in slab mode (a context that did not march has none); a hit pixel is overwritten in (3)
   key[i] = ~0ull;
 }
 __device__ __forceinline__ unsigned long long hit_key(float ns, uint32_t rank, uint32_t idx) {
@@ -1034,9 +1034,9 @@ __global__ __launch_bounds__(256) void k_comp_write(const char* __restrict__ g, 
     R.nsamples[h.pix] = h.ns;
   }
 }
-void launch_composite_hits(hipStream_t st, const void* gathered, size_t stride_bytes, int n, const RayTarget& R, int w, int h, unsigned long long* key) {
+void launch_composite_hits(hipStream_t st, const void* gathered, size_t stride_bytes, int n, const RayTarget& R, int w, int h, unsigned long long* key, int own_counts) {
   const int np = w * h;
-  hipLaunchKernelGGL(k_comp_init, dim3((np + 255) / 256), dim3(256), 0, st, R, w, h, key);
+  hipLaunchKernelGGL(k_comp_init, dim3((np + 255) / 256), dim3(256), 0, st, R, w, h, key, own_counts);
   hipLaunchKernelGGL(k_comp_bid, dim3(128, n), dim3(256), 0, st, (const char*)gathered, stride_bytes, n, key);
   hipLaunchKernelGGL(k_comp_write, dim3(128, n), dim3(256), 0, st, (const char*)gathered, stride_bytes, n, key, R, w);
 }

@@ -15,6 +15,15 @@ no multi-GPU path at all; what is partitioned here is the reference's single vol
     one 32-byte record per hit ray (composite="compact") -- and the hit with the smallest sample count wins, which is
     exactly the single-GPU first zero crossing.
   * K3/K4 (hole filling) are image space and tiny: rank 0 only.
+  * compositor="dedicated": rank 0 holds NO slab.  The image-space tail of a frame on the gathering rank (receive, composite, hole
+    filling: ~70 us at 1280x720) is longer than a slab's share of the volume work at any of the BASELINE configurations, so with an
+    even split rank 0 is the frame's critical path and the other ranks wait for it in every gather.  With a dedicated compositor the
+    volume is split over ranks 1 .. N-1 and rank 0 only receives, composites and fills: while it finishes frame f the workers are
+    already integrating frame f + 1 (each rank's work is queued on its stream; the gather is the only meeting point), and the frame
+    period is max(worker, compositor) instead of their sum.  With the compact composite the compositor does not march, so the
+    write-only diagnostic image of sample counts (tex_num_samples, recon_integration.cpp:207-209: cleared and bound for imageStore,
+    read by nothing) holds 0 at the pixels no slab hit instead of the ray's total sample count; colour, depth, the sample counts of
+    hit pixels and the hole-filled framebuffer are those of the single-GPU frame, bit for bit.
 
 The exchange works on plain device pointers across the C ABI (tsdf_halo_*_dev, tsdf_export_partial_dev,
 tsdf_composite_dev); torch only owns the buffers and the collective.
@@ -37,6 +46,14 @@ import contextlib
 
 import torch
 import torch.distributed as dist
+
+
+def worker_slab_range(res_z: int, rank: int, world: int):
+    """Slab of rank `rank` when rank 0 is a dedicated compositor: ranks 1 .. world-1 split the volume; rank 0 gets the first tile
+    layer as a placeholder (its context needs SOME volume; it is never integrated or marched)."""
+    if rank == 0:
+        return 0, min(8, res_z)
+    return slab_range(res_z, rank - 1, world - 1)
 
 
 def slab_range(res_z: int, rank: int, world: int):
@@ -63,13 +80,19 @@ class SlabDriver:
                with the one rank anyway -- used to drive the RCCL calls on a box with a single GPU.
     stream     the torch stream everything runs on (default: a new one).  CUDA buffers only.
     min_capacity  smallest number of hit records gathered per rank (compact composite).
+    compositor "shared": every rank owns a slab, rank 0 composites as well; "dedicated" (world >= 2): rank 0 owns no slab -- its
+               backend only needs the view (worker_slab_range() gives the workers' slabs) -- and never integrates or marches.
     """
 
     LAG = 2            # frames between a hit count and its use as the gather size: its pinned copy has long arrived, the host never waits
 
     def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense", preprocess=False,
-                 exchange_when_alone=False, stream=None, min_capacity=4096):
-        assert halo in ("exchange", "recompute") and composite in ("dense", "compact")
+                 exchange_when_alone=False, stream=None, min_capacity=4096, compositor="shared"):
+        assert halo in ("exchange", "recompute") and composite in ("dense", "compact") and compositor in ("shared", "dedicated")
+        assert compositor == "shared" or world >= 2, "a dedicated compositor needs at least one worker rank"
+        self.dedicated = compositor == "dedicated"
+        self.is_worker = not (self.dedicated and rank == 0)          # owns a slab: marks bricks, integrates, marches, exports
+        self.first_worker = 1 if self.dedicated else 0
         self.b, self.rank, self.world, self.dev, self.group = backend, rank, world, torch.device(buf_device), group
         self.view, self.halo, self.composite = view, halo, composite
         self.preprocess = preprocess          # frames start from the raw sensor images: processTextures() instead of markBricks()
@@ -94,7 +117,8 @@ class SlabDriver:
                     self.send = torch.empty((2, n), dtype=torch.float32, device=self.dev)
                     self.gath = torch.empty((world, 2, n), dtype=torch.float32, device=self.dev)
                 if composite == "dense":
-                    self.part = torch.empty(npx * 6, dtype=torch.float32, device=self.dev)          # 24 B / pixel
+                    # 24 B / pixel; a compositor without a slab contributes "no hit, no samples" for every pixel (sample count 0)
+                    self.part = (torch.empty if self.is_worker else torch.zeros)(npx * 6, dtype=torch.float32, device=self.dev)
                     self.parts = torch.empty((world, npx * 6), dtype=torch.float32, device=self.dev) if rank == 0 else None
                 else:
                     self.hitbuf = torch.zeros(8 + npx * 8, dtype=torch.float32, device=self.dev)     # 32 B header + 32 B records; a slab cannot hit more rays than there are pixels
@@ -131,9 +155,12 @@ class SlabDriver:
 
     def exchange_halo(self):
         b = self.b
-        b.halo_pack_dev(self.send[0].data_ptr(), self.send[1].data_ptr())
+        if self.is_worker:
+            b.halo_pack_dev(self.send[0].data_ptr(), self.send[1].data_ptr())
         self._all_gather(self.gath, self.send)
-        below = self.gath[self.rank - 1, 1].data_ptr() if self.rank > 0 else 0
+        if not self.is_worker:
+            return                                                   # (took part in the collective; has no slab faces of its own)
+        below = self.gath[self.rank - 1, 1].data_ptr() if self.rank > self.first_worker else 0
         above = self.gath[self.rank + 1, 0].data_ptr() if self.rank < self.world - 1 else 0
         b.halo_unpack_dev(below, above)
 
@@ -155,7 +182,8 @@ class SlabDriver:
 
     def _exchange_hits(self, cap, record_counts_of=None):
         b = self.b
-        b.export_hits_dev(self.hitbuf.data_ptr(), cap)
+        if self.is_worker:
+            b.export_hits_dev(self.hitbuf.data_ptr(), cap)          # (a compositor's header stays {0 records, 0 hits})
         if record_counts_of is not None:
             self._all_gather(self.counts, self.hitbuf[:2].view(torch.int32))
             slot = record_counts_of % (self.LAG + 1)
@@ -177,21 +205,24 @@ class SlabDriver:
 
     def _frame(self, mv, proj):
         b = self.b
-        b.clearOccupiedBricks()
-        if self.preprocess:
-            b.processTextures()
-        else:
-            b.markBricks()
-        b.updateOccupiedBricks(False)
-        b.integrate()
+        if self.is_worker:
+            b.clearOccupiedBricks()
+            if self.preprocess:
+                b.processTextures()
+            else:
+                b.markBricks()
+            b.updateOccupiedBricks(False)
+            b.integrate()
         if not self.exchanging:
             b.drawF(mv, proj)
             return
         if self.halo == "exchange":
             self.exchange_halo()
-        b.draw(mv, proj)
+        if self.is_worker:
+            b.draw(mv, proj)
         if self.composite == "dense":
-            b.export_partial_dev(self.part.data_ptr())
+            if self.is_worker:
+                b.export_partial_dev(self.part.data_ptr())
             self._gather0(list(self.parts.unbind(0)) if self.rank == 0 else None, self.part)
             if self.rank == 0:
                 b.composite_dev(self.parts.data_ptr(), self.world)

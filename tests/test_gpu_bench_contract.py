@@ -45,19 +45,26 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 
 @pytest.mark.timeout(1500)
-def test_bench_with_two_ranks_runs_the_slab_partition_by_default():
-    """`--gpus 2` without further flags = ONE volume in two Z-slabs, strong scaling, and the run itself checks the composite against
-    an unpartitioned context before timing.  Two processes on the one GPU of the box, gloo standing in for RCCL (RCCL refuses two
-    ranks on one device): everything else is the driver's command."""
+@pytest.mark.parametrize("world,extra,what", [(2, [], "1 Z-slab(s) on ranks 1..1 + rank 0 as dedicated compositor"),
+                                              (3, [], "2 Z-slab(s) on ranks 1..2 + rank 0 as dedicated compositor"),
+                                              (2, ["--compositor", "shared"], "ONE volume in 2 Z-slabs")])
+def test_bench_with_more_ranks_runs_the_slab_partition_by_default(world, extra, what):
+    """`--gpus N` without further flags = ONE volume in Z-slabs on ranks 1..N-1 with rank 0 as the compositing rank (`--compositor
+    shared`: N slabs, rank 0 composites as well), strong scaling, and the run itself checks the composite against an unpartitioned
+    context before timing.  N processes on the one GPU of the box, gloo standing in for RCCL (RCCL refuses two ranks on one
+    device): everything else is the driver's command."""
     env = dict(os.environ, RR_BENCH_BACKEND="gloo", RR_BENCH_DEVICE="0")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--long-steps", "0"],
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29571 + world + len(extra)),
+                        os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "10", "--warmup", "2", "--long-steps", "0"] + extra,
                        cwd=ROOT, capture_output=True, text=True, timeout=1400, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, p.stdout[:500]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "Z-slabs" in d["config"]["parallelism"]
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and what in d["config"]["parallelism"], d["config"]["parallelism"]
     assert "bit-identical" in d["slab_check"] and d["regathers"] == 0
     assert d["frame_replicas"]["scaling"] == "weak" and d["frame_replicas"]["value"] > 0     # an extra key beside the slab value, never instead of it
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"] and d["value"] > 30.0
+    assert d["stage_ms"]["k_integrate_tiles"] > 0                                # (from a rank that owns a slab)
+    if not extra:
+        assert d["stage_ms_compositor"]["holefill"] > 0 and "k_integrate_tiles" not in d["stage_ms_compositor"]

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 KW = dict(res=(64, 64, 64), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(160, 90))
 
 
-def _worker(rank, world, port, q, halo, composite, tiny_capacity=False):
+def _worker(rank, world, port, q, halo, composite, tiny_capacity=False, compositor="shared"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
@@ -24,8 +24,12 @@ def _worker(rank, world, port, q, halo, composite, tiny_capacity=False):
         torch.cuda.set_device(0)
         scene = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
         mv, pr = rr.scene.default_view(*KW["view"])
-        hip = rr.ReconIntegrationHip(scene, slab=mgpu.slab_range(KW["res"][2], rank, world), recompute_halo=(halo == "recompute"), **KW)
-        drv = mgpu.SlabDriver(hip, rank, world, "cuda:0", view=KW["view"], halo=halo, composite=composite)      # (creates and hands over its own torch stream)
+        dedicated = compositor == "dedicated"
+        slab = (mgpu.worker_slab_range if dedicated else mgpu.slab_range)(KW["res"][2], rank, world)
+        hip = rr.ReconIntegrationHip(scene, slab=slab, recompute_halo=(halo == "recompute"), **KW)
+        if dedicated and world == 2 and rank == 1:
+            hip.setMarchCap(0)                       # one worker with the whole volume: every hit goes through the hit list
+        drv = mgpu.SlabDriver(hip, rank, world, "cuda:0", view=KW["view"], halo=halo, composite=composite, compositor=compositor)      # (creates and hands over its own torch stream)
         if tiny_capacity:
             drv._capacity = lambda f: 64             # every gather is too small: finish() has to repair each frame it is asked about
         for _ in range(5):                           # past the LAG frames that gather the full capacity; buffers are reused
@@ -40,7 +44,11 @@ def _worker(rank, world, port, q, halo, composite, tiny_capacity=False):
             whole.clearOccupiedBricks(); whole.markBricks(); whole.updateOccupiedBricks()
             whole.integrate(); whole.drawF(mv, pr)
             (wa, wd, wn, _), (sa, sd, sn, _) = whole.view_images(), hip.view_images()
-            ok &= bool((sd == wd).all()) and bool((sn == wn).all())
+            if dedicated and composite == "compact":     # the compositor does not march: the write-only count image holds 0 where no slab hit
+                ok &= bool((sn[wd < 1] == wn[wd < 1]).all()) and bool((sn[~(wd < 1)] == 0).all())
+            else:
+                ok &= bool((sn == wn).all())
+            ok &= bool((sd == wd).all())
             ok &= bool(((sa == wa) | (np.isnan(sa) & np.isnan(wa))).all())
             (wc, wdd), (sc, sdd) = whole.framebuffer(), hip.framebuffer()
             ok &= bool((sdd == wdd).all()) and bool(((sc == wc) | (np.isnan(sc) & np.isnan(wc))).all())
@@ -66,6 +74,29 @@ def test_two_rank_slab_driver_matches_single_context(halo, composite, tiny):
         p.join(900)
         assert p.exitcode == 0
     assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("world,halo,composite,tiny", [(2, "recompute", "compact", False), (3, "recompute", "compact", False), (3, "exchange", "dense", False),
+                                                       (3, "recompute", "compact", True)])
+def test_dedicated_compositor_rank_matches_single_context(world, halo, composite, tiny):
+    """compositor="dedicated": rank 0 holds no slab -- it takes part in the collectives, composites and fills holes -- and ranks
+    1 .. world-1 split the volume (world 2: one worker with the whole volume and the long-ray pass off; world 3: two slabs).  The
+    composite on rank 0 equals the unpartitioned frame; with the compact gather the write-only sample-count image is 0 at the
+    pixels no slab hit (the compositor does not march)."""
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, halo, composite, tiny, "dedicated")) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(world)) == {r: True for r in range(world)}
 
 
 def _rccl_alone(port, q, halo, composite):

@@ -260,3 +260,68 @@ def test_capacity_rule():
     assert d._capacity(2) == 15360                                            # 1.5 * 9000 + 1024 = 14524 -> the next multiple of 1024
     assert d._capacity(3) == 4096                                             # nothing hit two frames ago: the floor
     assert d._capacity(7) == 921600                                           # capped at one record per pixel
+
+
+# ------------------------------------------------------------------------------------------------ dedicated compositor rank
+def _dedicated_worker(rank, world, port, q, halo, composite):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mgpu = import_module("rgbd-recon_amd.multigpu")
+        workers = world - 1
+        # rank 0 owns no slab: the stand-in for its context is a slab nobody integrates or draws; workers are slabs 0 .. workers-1
+        fake = FakeSlab(max(rank - 1, 0), workers)
+        drv = mgpu.SlabDriver(fake, rank, world, "cpu", view=VIEW, halo=halo, composite=composite, min_capacity=4, compositor="dedicated")
+        for _ in range(4):
+            drv.frame(None, None)
+        drv.finish()
+        ok = True
+        frame_calls = fake.calls[-(7 if rank == 0 else 5):]
+        if rank == 0:
+            ok &= set(fake.calls) == {"composite", "fill"}                   # never marks, integrates or draws
+            r = fake.result
+            p = np.arange(VIEW[0] * VIEW[1])
+            hits = p % 3 != 2
+            # a gathered part's index is the RANK (worker index + 1); part 0 (the compositor's own) never wins a pixel
+            ok &= bool((r["rank_of_pixel"][hits] == (p % workers + 1)[hits]).all()) and bool((r["rank_of_pixel"][~hits] == -1).all())
+            ok &= bool(np.allclose(r["ns"][hits], ((p + 1) * 0.0027)[hits])) and bool((r["colour"][hits] == (p % workers + 1)[hits]).all())
+            if composite == "dense":
+                ok &= bool(np.allclose(r["ns"][~hits], 40 * 0.0027))          # whole partial images carry the miss counts
+        else:
+            ok &= frame_calls == ["clear", "mark", "update", "integrate", "draw"]
+            if halo == "exchange":                                            # neighbours are worker ranks only: rank 1 has none below
+                own, w = fake.own, rank - 1
+                if w > 0:
+                    ok &= bool((fake.vol[0] == ((w * own - 1) * 1000.0 + np.arange(TILE_LAYER) % 7)).all())
+                if w < workers - 1:
+                    ok &= bool((fake.vol[-1] == (((w + 1) * own) * 1000.0 + np.arange(TILE_LAYER) % 7)).all())
+                ok &= not np.isnan(fake.vol).any()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("halo,composite", [("recompute", "compact"), ("exchange", "dense")])
+def test_dedicated_compositor_world_size_3_gloo(halo, composite):
+    """compositor="dedicated": rank 0 takes part in every collective but owns no slab; ranks 1 and 2 are slabs 0 and 1."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dedicated_worker, args=(r, 3, port, q, halo, composite)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(3)) == {0: True, 1: True, 2: True}
+
+
+def test_worker_slab_range():
+    mgpu = import_module("rgbd-recon_amd.multigpu")
+    for res_z, world in [(512, 8), (512, 2), (1024, 8), (221, 3)]:
+        r = [mgpu.worker_slab_range(res_z, k, world) for k in range(world)]
+        assert r[0] == (0, 8)                                                 # the compositor's placeholder layer
+        assert r[1:] == [mgpu.slab_range(res_z, k, world - 1) for k in range(world - 1)]
+    with pytest.raises(AssertionError):
+        mgpu.SlabDriver(None, 0, 1, "cpu", compositor="dedicated")
