@@ -478,6 +478,22 @@ def main():
         else:
             alg, note = db["march"], "dense march: 4V + 24R (BASELINE.md section 3); with depth limits the rays sample only inside occupied bricks, so this is an upper figure"
         out["roofline"] = roofline(dom, alg, dom_ms, args.config, note)
+    if world > 1:
+        # N > 1: the same object for the slowest slab launch (every rank that owns a slab measures its own; counters -- `traffic` -- were
+        # only collected on one GPU).  Only culled integrate launches: the units are the slab's active tiles (halo layers it recomputes included)
+        mine = None
+        owns_slab = not (dedicated and rank == 0)
+        if owns_slab and dom_ms and dom == "k_integrate_tiles" and cfg["use_bricks"]:
+            alg, tiles_n = culled_integrate_bytes(np, hip, scenes, cfg["res"], n_streams)
+            mine = {"rank": rank, "ms": dom_ms, "alg": alg, "tiles": tiles_n, "slab": list(slab)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        allr = [r for r in allr if r]
+        if allr:
+            r = max(allr, key=lambda r: r["ms"])
+            out["roofline"] = roofline("k_integrate_tiles", r["alg"], r["ms"], "none", f"the slowest slab launch of the {len(allr)} slab ranks: rank {r['rank']}, voxel planes {r['slab']}, "
+                                       f"{r['tiles']} active tiles in the timed frames (the halo layers it recomputes included); bytes as at N = 1 with the frame's valid depth pixels "
+                                       "counted in full for every slab (an upper figure); other ranks: " + ", ".join(f"rank {q['rank']} {q['ms'] * 1e3:.1f} us / {q['alg'] / 1e6:.1f} MB" for q in allr if q is not r))
     # ---- the dense configuration (configs[1]): both kernels against the dense byte counts, in the same line
     if world == 1 and not alone and not args.no_c1 and not args.no_timers and args.config != "c1" and args.frames_in_flight == 1:
         c1 = CONFIGS["c1"]

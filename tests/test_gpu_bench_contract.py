@@ -66,5 +66,8 @@ def test_bench_with_more_ranks_runs_the_slab_partition_by_default(world, extra, 
     assert d["frame_replicas"]["scaling"] == "weak" and d["frame_replicas"]["value"] > 0     # an extra key beside the slab value, never instead of it
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"] and d["value"] > 30.0
     assert d["stage_ms"]["k_integrate_tiles"] > 0                                # (from a rank that owns a slab)
+    r = d["roofline"]                                                            # the slowest slab launch, measured on its own rank
+    assert r["bound"] == "hbm" and 0.0 < r["frac"] < 1.0 and r["traffic"] is None and "slab" in r["note"]
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
     if not extra:
         assert d["stage_ms_compositor"]["holefill"] > 0 and "k_integrate_tiles" not in d["stage_ms_compositor"]
