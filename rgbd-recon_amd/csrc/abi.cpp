@@ -65,8 +65,8 @@ struct tsdf_ctx {
   // the stream's per-tile LUT box against the integrate kernel's LDS budget: 0 = does not fit (global-memory kernel), 1 = the box fits
   // (direct 8-tap form), 2 = the separable passes' rows and planes fit as well (the fastest form)
   int lds_ok[TSDF_MAX_STREAMS]{};
-  int k1_form_cap = 2;           // RR_K1_FORM: 2 = separable form (default), 1 = direct 8-tap form, 0 = global-memory kernel, 3 = wave-per-stream separable form (measured slower: DESIGN.md section 4)
-  int ws_box[TSDF_MAX_STREAMS]{}, ws_row[TSDF_MAX_STREAMS]{};   // per stream: LDS float4 of the wave-per-stream form for the worst tile box
+  int k1_form_cap = 2;           // RR_K1_FORM: 2 = separable form (default), 1 = direct 8-tap form, 0 = global-memory kernel, 3 = one wave per tile (separable passes, no workgroup barrier)
+  int ws_box[TSDF_MAX_STREAMS]{}, ws_row[TSDF_MAX_STREAMS]{};   // per stream: LDS float4 of the one-wave-per-tile form for the worst tile box
   FrameImages frame{};           // the CURRENT frame slot's images (what mark / integrate / draw read)
   // Two frame slots (the reference's double PBO + texture arrays, NetKinectArray.cpp:225-236): while the path computes on slot
   // `cur_slot`, tsdf_upload_frame_async fills the other one on a copy stream; tsdf_select_frame_slot makes it current.
@@ -1036,10 +1036,11 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   timer_begin(c, "2integrate");
   int lds = 2;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = std::min(lds, c->lds_ok[i]);
-  // the wave-per-stream form needs the separable form's preconditions and 4 x (box + rows) float4 of dynamic LDS within 64 KiB
+  // the one-wave-per-tile form needs the separable form's preconditions and (box + rows) float4 of dynamic LDS per wave: within 24 KiB
+  // (at least six waves per CU)
   int ws_box = 0, ws_row = 0;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) { ws_box = std::max(ws_box, c->ws_box[i]); ws_row = std::max(ws_row, c->ws_row[i]); }
-  if (lds == 2 && (size_t)4 * (ws_box + ws_row) * 16 <= 60 * 1024) lds = 3;
+  if (lds == 2 && (size_t)(ws_box + ws_row) * 16 <= 24 * 1024) lds = 3;
   lds = std::min(lds, c->k1_form_cap);
   if (c->use_bricks) {
     // this frame's list / count, the previous integrate()'s (trusted unless something else may have written the volume)
@@ -1067,7 +1068,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
   // dense launches: the static half of the uniform-pair shortcut (k_integrate.hip), built once per calibration
   const float4* bounds = nullptr;
-  if (!c->use_bricks && lds == 2 && c->frame.ranges) {
+  if (!c->use_bricks && lds >= 2 && c->frame.ranges) {
     if (!c->d_tile_bounds) HIP_TRY(c, hipMalloc((void**)&c->d_tile_bounds, (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 2 * sizeof(float4)));
     if (!c->tile_bounds_valid) { launch_tile_bounds(c->stream, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
     bounds = c->d_tile_bounds;

@@ -534,152 +534,209 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
 }
 
 
-// Wave-per-stream form (round 2).  The separable form above walks the streams one after another and separates its phases with
-// workgroup barriers: a tile is a chain of ~4 barriers and two dependent round trips (LUT box, image gather) PER STREAM, ~21 us for
-// a 4-stream tile at c2, and the launch lasts (tiles / resident workgroups) x that chain.  Here the four waves of the workgroup take
-// one stream each: wave w evaluates the filter set-up, copies the texel box and runs the X and Y passes of stream (chunk + w)
-// entirely by itself -- LDS traffic of one wave is processed in order, so these phases need no workgroup barrier, and the four
-// streams' box loads are in flight together.  One barrier later every thread reads the y-lerped planes of all four streams, issues
-// the four image gathers of a voxel together and applies the fusion rule in stream order.  Two barriers per tile and chunk of four
-// streams instead of ~17, one LUT round trip and two image round trips instead of four each.  Operands and operation order per
-// voxel are those of the separable form: bit-identical.
-// Dynamic LDS: per wave box_cap + row_cap float4 (the context's worst tile box: box_cap = max(dx dy dz, 64 dz), row_cap = 8 dy dz).
-constexpr int kWsWaves = 4;
+// One wave per tile (round 2).  The forms above give a tile to a 256-thread workgroup: four waves that meet at ~4 workgroup barriers
+// per stream, each of which repeats the tile's set-up, and a machine that holds 2048 tiles at a time (8 waves per SIMD) -- a culled
+// launch of ~5000 tiles is 2.6 rounds of a ~18 us chain.  Here a tile belongs to ONE wave: lane (lx, ly) owns the column of 8 voxels
+// along z.  Nothing is shared between waves, so there is no workgroup barrier at all -- the LDS operations of one wave are processed
+// in order, the phases only need the compiler kept from reordering them (wave_barrier) -- the set-up is done once per tile instead of
+// four times, and every tile of a culled launch is resident at once (6 waves per SIMD = 6144 tiles), each wave's round trips hidden
+// behind five others at different phases.  Per voxel the operands and the order of operations are those of the separable form: the
+// results are bit-identical.  A wave-per-stream variant (four waves per tile, one stream each, the four image gathers of a voxel in
+// flight together) was built first and measured slower (c2 65.8 vs 53.2 us: 24-43 KB of LDS and 128 VGPRs per workgroup); removed.
+// Dynamic LDS per wave: box + row float4 (the context's worst tile box: box = max(dx dy dz, 64 dz), row = 8 dy dz).
 struct WsCaps { int box, row; };
-#ifndef RR_K1WS_BOUNDS
-#define RR_K1WS_BOUNDS 4
+#ifndef RR_K1W_WAVES
+#define RR_K1W_WAVES 6
 #endif
-template <bool kList>
-__global__ __launch_bounds__(256, RR_K1WS_BOUNDS) void k_integrate_tiles_ws(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check, WsCaps C) {
+#ifndef RR_K1W_BATCH
+#define RR_K1W_BATCH 1      // voxels of a lane whose image gathers are in flight together (2: 10 spilled VGPRs at 6 waves/SIMD, c2 52.8 instead of 50.5 us)
+#endif
+// class of (tile, stream) by a half wave (two streams per call, up to 32 range cells each): see classify_pair
+__device__ __forceinline__ float half_min_f32(float v) {
+#define RR_DPP_MIN(ctrl, rm, bm) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rm, bm, false)))
+  RR_DPP_MIN(0x111, 0xf, 0xf); RR_DPP_MIN(0x112, 0xf, 0xf); RR_DPP_MIN(0x114, 0xf, 0xe); RR_DPP_MIN(0x118, 0xf, 0xc);
+  RR_DPP_MIN(0x142, 0xa, 0xf);                                          // row_bcast:15 -> lane 31 holds rows 0-1, lane 63 rows 2-3
+#undef RR_DPP_MIN
+  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)), hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ float half_max_f32(float v) { return -half_min_f32(-v); }
+__device__ __forceinline__ int classify_pair_half(const float4* __restrict__ ranges, int rcw, int rch, int img_w, int img_h, int i, bool valid, float4 b0, float4 b1, float limit) {
+  const int r = threadIdx.x & 31;
+  const float inf = __builtin_inff();
+  const float u0 = b0.x, u1 = b0.y, v0 = b0.z, v1 = b0.w, z0 = b1.x, z1 = b1.y;
+  bool ok = valid && (u0 <= u1);                                       // NaN: the box holds something non-finite
+  const float su = 1.0e-5f * (1.0f + fmaxf(fabsf(u0), fabsf(u1))), sv = 1.0e-5f * (1.0f + fmaxf(fabsf(v0), fabsf(v1)));
+  const float wf = (float)img_w, hf = (float)img_h;
+  const int x0 = (int)__builtin_amdgcn_fmed3f(floorf((u0 - su) * wf - 0.5f), 0.0f, wf - 1.0f), x1 = (int)__builtin_amdgcn_fmed3f(floorf((u1 + su) * wf - 0.5f) + 1.0f, 0.0f, wf - 1.0f);
+  const int y0 = (int)__builtin_amdgcn_fmed3f(floorf((v0 - sv) * hf - 0.5f), 0.0f, hf - 1.0f), y1 = (int)__builtin_amdgcn_fmed3f(floorf((v1 + sv) * hf - 0.5f) + 1.0f, 0.0f, hf - 1.0f);
+  const int cx0 = x0 >> 3, cy0 = y0 >> 3, cw = (x1 >> 3) - cx0 + 1, chh = (y1 >> 3) - cy0 + 1;
+  ok = ok && cw >= 1 && chh >= 1 && __mul24(cw, chh) <= 32;
+  float d0 = inf, d1 = -inf, s0 = inf, s1 = -inf;
+  if (ok && r < __mul24(cw, chh)) {
+    const int ry = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)cw));           // r / cw
+    const float4 q = ranges[(size_t)__mul24(__mul24(i, rch) + cy0 + ry, rcw) + (cx0 + r - __mul24(ry, cw))];
+    d0 = q.x; d1 = q.y; s0 = q.z; s1 = q.w;
+  }
+  d0 = half_min_f32(d0); d1 = half_max_f32(d1); s0 = half_min_f32(s0); s1 = half_max_f32(s1);
+  const float sz = 1.0e-5f * (1.0f + fmaxf(fabsf(z0), fabsf(z1)) + fmaxf(fabsf(d0), fabsf(d1)));
+  const bool all_le = (z1 + sz) - d0 <= -limit - sz, all_ge = (z0 - sz) - d1 >= limit + sz;
+  const bool sil0 = s0 == 0.0f && s1 == 0.0f, sil1 = s0 == 1.0f && s1 == 1.0f;
+  if (!ok) return kPairFull;
+  if (sil0 && all_ge) return kPairCarve;
+  if ((sil0 || sil1) && all_le) return kPairNeg;
+  if (sil1 && all_ge) return kPairNop;
+  return kPairFull;
+}
+template <bool kList, bool kRanges>
+__global__ __launch_bounds__(64, RR_K1W_WAVES) void k_integrate_tiles_w1(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
+                                                                         const float4* __restrict__ tile_bounds, WsCaps C) {
   extern __shared__ float4 s_dyn[];
-  __shared__ int s_i0a[kWsWaves][3][8], s_i1a[kWsWaves][3][8];
-  __shared__ float s_wa[kWsWaves][3][8];
+  float4* const s_box = s_dyn;                   // the stream's texel box, later its y-lerped planes: ((z - mz) * 8 + y) * 8 + x
+  float4* const s_row = s_dyn + C.box;           // its x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
+  __shared__ int s_i0[3][8], s_i1[3][8];         // per axis and voxel coordinate of the tile: the two texel indices ...
+  __shared__ float s_w[3][8];                    // ... and the weight of the GL LINEAR filter (current stream)
   const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
-  const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-  float4* const s_box = s_dyn + wv * (C.box + C.row);          // this wave's stream: texel box, later its y-lerped planes
-  float4* const s_row = s_box + C.box;                         // ... and its x-lerped rows
-  if (kList && blockIdx.x == 0 && tid == 0) *S.next_count = 0u;                    // the previous list was consumed by the classify launch
+  const int ln = threadIdx.x, lx = ln & 7, ly = ln >> 3;
+  if (kList && blockIdx.x == 0 && ln == 0) *S.next_count = 0u;                     // the previous list was consumed by the classify launch
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     const int tile = work_tile<kList>(S, w);
     int t3[3];
     tile_coords(V, tile, t3[0], t3[1], t3[2]);
     if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
     float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
-    constexpr int kVox = 2;                                             // voxels per thread: local z = lz and lz + 4, same x and y
-    const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
-    bool drawn[kVox];
-    float tsd[kVox], wsum[kVox];
+    uint32_t drawn = 0;                                                 // bit kz: voxel (x, y, 8 tz + kz) is integrated
+    float tsd[8], wsum[8];
 #pragma unroll
-    for (int h = 0; h < kVox; ++h) {
-      const int z = t3[2] * 8 + lz + 4 * h;
-      drawn[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
-      if (drawn[h] && per_voxel_check) drawn[h] = voxel_drawn(B, x, y, z);
-      tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
-      wsum[h] = 0.0f;
+    for (int kz = 0; kz < 8; ++kz) {
+      const int z = t3[2] * 8 + kz;
+      bool d = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      if (d && per_voxel_check) d = voxel_drawn(B, x, y, z);
+      drawn |= (d ? 1u : 0u) << kz;
+      tsd[kz] = limit;                                                  // tsdf_integration.vs:28-29
+      wsum[kz] = 0.0f;
     }
-    for (int cb = 0; cb < T.n; cb += kWsWaves) {
-      __syncthreads();                                                  // the previous chunk's / tile's readers of the planes are done
-      const int i = cb + wv;                                            // this wave's stream
-      int mx = 0, my = 0, mz = 0, dx = 1, dy = 1, dz = 1;
-      if (i < T.n) {
-        const StreamLut& L = T.s[i];
-        if (ln < 24) {                                                  // phase A: GL LINEAR set-up of the tile's 8 coordinates per axis
-          const int a = ln >> 3, k = ln & 7;
-          const int coord = min(t3[a] * 8 + k, V.res[a] - 1);           // padding voxels reuse the last real coordinate
-          const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], L.inv_res[a]);
-          s_i0a[wv][a][k] = ax.i0; s_i1a[wv][a][k] = ax.i1; s_wa[wv][a][k] = ax.a;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int (*s_i0)[8] = s_i0a[wv];
-        const int (*s_i1)[8] = s_i1a[wv];
-        const float (*s_w)[8] = s_wa[wv];
-        mx = s_i0[0][0]; my = s_i0[1][0]; mz = s_i0[2][0];
-        dx = s_i1[0][7] - mx + 1; dy = s_i1[1][7] - my + 1; dz = s_i1[2][7] - mz + 1;
-        {                                                               // phase B: the stream's texel box, independent 16-byte loads
-          const int n = min(__mul24(__mul24(dx, dy), dz), C.box);
-          const float rdx = __builtin_amdgcn_rcpf((float)dx), rdy = __builtin_amdgcn_rcpf((float)dy);   // division-free e -> (bx, by, bz), see above
-          for (int e = ln; e < n; e += 64) {
-            const int row = (int)(((float)e + 0.5f) * rdx);
-            const int bz = (int)(((float)row + 0.5f) * rdy);
-            const int bx = e - __mul24(row, dx), by = row - __mul24(bz, dy);
-            s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int n1 = min(__mul24(__mul24(dy, dz), 8), C.row);         // pass X
-        for (int e = ln; e < n1; e += 64) {
-          const int k = e & 7, rb = __mul24(e >> 3, dx);
-          const float3 r = lerp3(s_box[rb + (s_i0[0][k] - mx)], s_box[rb + (s_i1[0][k] - mx)], s_w[0][k]);
-          s_row[e] = make_float4(r.x, r.y, r.z, 0.0f);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int n2 = min(dz << 6, C.box);                             // pass Y: the y-lerped planes overwrite the box
-        for (int e = ln; e < n2; e += 64) {
-          const int k = e & 7, j = (e >> 3) & 7, zb = __mul24(e >> 6, dy);
-          const float3 r = lerp3(s_row[((zb + (s_i0[1][j] - my)) << 3) + k], s_row[((zb + (s_i1[1][j] - my)) << 3) + k], s_w[1][j]);
-          s_box[e] = make_float4(r.x, r.y, r.z, 0.0f);
-        }
+    uint32_t pairs = 0;                                                 // (kRanges) 2 bits per stream: kPairFull / Carve / Neg / Nop
+    if (kRanges) {
+      const uint32_t st = stored_tile_index(V, tile);
+      for (int cb = 0; cb < T.n; cb += 2) {
+        const int i = cb + (ln >> 5);
+        const bool valid = i < T.n;
+        const size_t o = 2 * ((size_t)st * T.n + (valid ? i : 0));
+        const int pair = classify_pair_half(F.ranges, F.rcw, F.rch, F.w, F.h, i, valid, tile_bounds[o], tile_bounds[o + 1], limit);
+        pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 0) << (2 * cb);
+        if (cb + 1 < T.n) pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 32) << (2 * cb + 2);
       }
-      __syncthreads();
-      bool any_drawn = false;
+    }
+    const bool any_drawn = __ballot(drawn != 0u) != 0ull;
+    for (int i = 0; i < T.n; ++i) {
+      if (kRanges) {
+        const int pair = (int)((pairs >> (2 * i)) & 3u);                // wave-uniform
+        if (pair != kPairFull) {                                        // the branch is the same for every voxel of the tile: no box, no passes, no gathers
 #pragma unroll
-      for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
-      if (__ballot(any_drawn) != 0ull) {                                // phase Z, all streams of the chunk
-        const int nc = min(kWsWaves, T.n - cb);
-#pragma unroll
-        for (int h = 0; h < kVox; ++h) {
-          const int kz = lz + 4 * h;
-          float3 pc[kWsWaves];
-          Dqs q[kWsWaves];
-#pragma unroll
-          for (int c = 0; c < kWsWaves; ++c)
-            if (c < nc) {                                               // texture(cv_xyz_inv[i], position).xyz, :31
-              const float4* pl = s_dyn + c * (C.box + C.row);
-              const int mzc = s_i0a[c][2][0];
-              pc[c] = lerp3(pl[(((s_i0a[c][2][kz] - mzc) << 3) + ly) * 8 + lx], pl[(((s_i1a[c][2][kz] - mzc) << 3) + ly) * 8 + lx], s_wa[c][2][kz]);
+          for (int kz = 0; kz < 8; ++kz)
+            if (drawn & (1u << kz)) {
+              if (pair == kPairNeg) tsd[kz] = -limit;
+              else if (pair == kPairCarve && tsd[kz] >= limit) tsd[kz] = -limit;
             }
+          continue;
+        }
+      }
+      const StreamLut& L = T.s[i];
+      __builtin_amdgcn_wave_barrier();                                  // (the previous stream's reads of the tables are issued)
+      if (ln < 24) {                                                    // phase A: GL LINEAR set-up of the tile's 8 coordinates per axis
+        const int a = ln >> 3, k = ln & 7;
+        const int coord = min(t3[a] * 8 + k, V.res[a] - 1);             // padding voxels reuse the last real coordinate
+        const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], L.inv_res[a]);
+        s_i0[a][k] = ax.i0; s_i1[a][k] = ax.i1; s_w[a][k] = ax.a;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int mx = s_i0[0][0], my = s_i0[1][0], mz = s_i0[2][0];
+      const int dx = s_i1[0][7] - mx + 1, dy = s_i1[1][7] - my + 1, dz = s_i1[2][7] - mz + 1;
+      {                                                                 // phase B: the stream's texel box, independent 16-byte loads
+        const int n = min(__mul24(__mul24(dx, dy), dz), C.box);
+        const float rdx = __builtin_amdgcn_rcpf((float)dx), rdy = __builtin_amdgcn_rcpf((float)dy);   // division-free e -> (bx, by, bz), see above
+        for (int e = ln; e < n; e += 64) {
+          const int row = (int)(((float)e + 0.5f) * rdx);
+          const int bz = (int)(((float)row + 0.5f) * rdy);
+          const int bx = e - __mul24(row, dx), by = row - __mul24(bz, dy);
+          s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int n1 = min(__mul24(__mul24(dy, dz), 8), C.row);           // pass X
+      for (int e = ln; e < n1; e += 64) {
+        const int k = e & 7, rb = __mul24(e >> 3, dx);
+        const float3 r = lerp3(s_box[rb + (s_i0[0][k] - mx)], s_box[rb + (s_i1[0][k] - mx)], s_w[0][k]);
+        s_row[e] = make_float4(r.x, r.y, r.z, 0.0f);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int n2 = min(dz << 6, C.box);                               // pass Y: the y-lerped planes overwrite the box
+      for (int e = ln; e < n2; e += 64) {
+        const int k = e & 7, j = (e >> 3) & 7, zb = __mul24(e >> 6, dy);
+        const float3 r = lerp3(s_row[((zb + (s_i0[1][j] - my)) << 3) + k], s_row[((zb + (s_i1[1][j] - my)) << 3) + k], s_w[1][j]);
+        s_box[e] = make_float4(r.x, r.y, r.z, 0.0f);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (!any_drawn) continue;
+      constexpr int kB = RR_K1W_BATCH;
 #pragma unroll
-          for (int c = 0; c < kWsWaves; ++c)
-            if (c < nc && drawn[h]) q[c] = dqs_fetch(F, cb + c, pc[c].x, pc[c].y);
-          if (drawn[h]) {
-            float weighted_tsd = tsd[h], total_weight = wsum[h];        // tsdf_integration.vs:30-55, in stream order
+      for (int kb = 0; kb < 8; kb += kB) {                              // phase Z: the lane's column, kB voxels' gathers in flight together
+        float3 pc[kB];
+        Dqs q[kB];
 #pragma unroll
-            for (int c = 0; c < kWsWaves; ++c)
-              if (c < nc) {
-                bool skip = false;
-                if (dqs_silhouette(q[c]) < 1.0f) {
-                  if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
-                }
-                if (!skip) {
-                  const float sdist = pc[c].z - dqs_depth(q[c]);
-                  if (sdist <= -limit) {
-                    weighted_tsd = -limit;
-                  } else if (sdist >= limit) {
-                  } else {
-                    const float weight = dqs_quality(q[c]);
-                    weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
-                    total_weight += weight;
-                  }
-                }
+        for (int h = 0; h < kB; ++h) {                                  // texture(cv_xyz_inv[i], position).xyz, :31
+          const int kz = kb + h;
+          pc[h] = lerp3(s_box[(((s_i0[2][kz] - mz) << 3) + ly) * 8 + lx], s_box[(((s_i1[2][kz] - mz) << 3) + ly) * 8 + lx], s_w[2][kz]);
+        }
+        // the gathers and the fusion rule are separate loops on purpose: both voxels' loads are issued before either is consumed
+#pragma unroll
+        for (int h = 0; h < kB; ++h)
+          if (drawn & (1u << (kb + h))) q[h] = dqs_fetch(F, i, pc[h].x, pc[h].y);
+#pragma unroll
+        for (int h = 0; h < kB; ++h) {
+          const int kz = kb + h;
+          if (drawn & (1u << kz)) {
+            float weighted_tsd = tsd[kz], total_weight = wsum[kz];      // tsdf_integration.vs:30-55, in stream order
+            bool skip = false;
+            if (dqs_silhouette(q[h]) < 1.0f) {
+              if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
+            }
+            if (!skip) {
+              const float sdist = pc[h].z - dqs_depth(q[h]);
+              if (sdist <= -limit) {
+                weighted_tsd = -limit;
+              } else if (sdist >= limit) {
+              } else {
+                const float weight = dqs_quality(q[h]);
+                weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
+                total_weight += weight;
               }
-            tsd[h] = weighted_tsd; wsum[h] = total_weight;
+            }
+            tsd[kz] = weighted_tsd; wsum[kz] = total_weight;
           }
         }
       }
     }
+    bool all_clear = true;
 #pragma unroll
-    for (int h = 0; h < kVox; ++h) { tsd[h] = drawn[h] ? tsd[h] : -limit; out[tid + 256 * h] = tsd[h]; }   // clearImage(-limit), :249-250
-    store_tile_class(S, tile, tsd[0] == -limit && tsd[1] == -limit);
+    for (int kz = 0; kz < 8; ++kz) {                                    // clearImage(-limit), :249-250
+      const float v = (drawn & (1u << kz)) ? tsd[kz] : -limit;
+      out[kz * 64 + ln] = v;
+      all_clear = all_clear && (v == -limit);
+    }
+    const bool tile_clear = __ballot(!all_clear) == 0ull;               // exact class: every stored voxel is the clear value
+    if (ln == 0) S.cls[tile] = tile_clear ? kTileMinus : kTileMixed;
   }
 }
 
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
                       int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, int ws_box, int ws_row, const float4* tile_bounds) {
   const WsCaps wc{ws_box, ws_row};
-  const size_t ws_lds = (size_t)kWsWaves * (size_t)(ws_box + ws_row) * sizeof(float4);
+  const size_t ws_lds = (size_t)(ws_box + ws_row) * sizeof(float4);
   // phase 1: tile classification + stale-tile clear; phase 2: the integrate kernel; 0: both (the split lets the caller time the kernel alone)
   if (use_bricks) {
     if (phase != 2) {
@@ -693,13 +750,14 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     }
     if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
-    if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_ws<true>), grid, dim3(256), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, wc);
+    if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<true, false>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr, wc);
     else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
   } else {
     if (phase == 1) return;
-    if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_ws<false>), dim3(S.n), dim3(256), ws_lds, st, T, F, V, B, S, 0, wc);
+    if (lds_ok == 3 && F.ranges && tile_bounds) hipLaunchKernelGGL((k_integrate_tiles_w1<false, true>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, tile_bounds, wc);
+    else if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<false, false>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, nullptr, wc);
     else if (lds_ok == 2 && F.ranges && tile_bounds) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds);
     else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr);

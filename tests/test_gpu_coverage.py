@@ -65,8 +65,8 @@ def test_lds_box_near_its_capacity(rr, res, inv_res):
 
 @pytest.mark.parametrize("form", ["3", "2", "1", "0"])
 def test_all_three_integrate_kernels_give_the_same_volume(rr, small_scene, form, monkeypatch):
-    """RR_K1_FORM caps the kernel choice when a context is created: 3 = separable passes with one wave per stream (opt-in: measured
-    slower), 2 = separable LDS passes stream by stream (the default), 1 = direct 8-tap LDS form, 0 = every tap from global memory.  The choice is normally made from the LUT box size; each must be bit-identical."""
+    """RR_K1_FORM caps the kernel choice when a context is created: 3 = separable passes with one wave per tile and no workgroup
+    barrier (opt-in), 2 = separable LDS passes stream by stream (the default), 1 = direct 8-tap LDS form, 0 = every tap from global memory.  The choice is normally made from the LUT box size; each must be bit-identical."""
     monkeypatch.setenv("RR_K1_FORM", form)
     hip, orc = rr.ReconIntegrationHip(small_scene, **KW), OracleRecon(small_scene, **KW)
     for use_bricks in (True, False):

@@ -350,11 +350,13 @@ def test_box_march_on_uploaded_volumes(rr, small_scene):
 
 
 # ------------------------------------------------------------------------------------------------ uniform (tile, stream) pairs in the dense integrate
-def test_dense_integrate_uniform_pair_shortcut_equals_per_voxel_evaluation(rr, monkeypatch):
+@pytest.mark.parametrize("form", ["2", "3"])
+def test_dense_integrate_uniform_pair_shortcut_equals_per_voxel_evaluation(rr, monkeypatch, form):
     """The dense integrate proves per tile and stream, from the LUT box bounds and the per-cell depth / silhouette ranges of the
     frame, that every voxel takes the same branch of the fusion rule, and then skips the per-voxel gathers.  Against the same kernel
     with the shortcut off (RR_K1_RANGES=0) and against the oracle: plain frames, a frame with NaN / infinite / out-of-range LUT
     texels, NaN and negative depths, silhouettes that are neither 0 nor 1, zero quality (NaN voxels), and the raw-frame path."""
+    monkeypatch.setenv("RR_K1_FORM", form)      # 2: workgroup per tile, a wave classifies a stream; 3: wave per tile, a half wave classifies a stream
     base = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
     rng = np.random.default_rng(11)
     scenes = [base, rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2))]
