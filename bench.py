@@ -329,6 +329,8 @@ def main():
                 stages[name] = ms / n
         cands = [k for k in ("k_integrate_tiles", "k_march") if k in stages]
         dom = max(cands, key=lambda k: stages[k]) if cands else None
+        if world > 1 and "k_integrate_tiles" in stages:
+            dom = "k_integrate_tiles"       # N > 1: every slab rank times the same kernel (a thin slab's march can outlast its integrate launch)
         # ... and the timed region records only the dominant kernel's two events per frame (the roofline's live measurement)
         if dom:
             hip.timer_reserve(dom, args.steps)       # no hipEventCreate inside the timed loop
