@@ -277,16 +277,15 @@ int32_t tsdf_export_partial_dev(tsdf_ctx* ctx, void* dst_dev);
 int32_t tsdf_composite_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n);
 /* The same exchange in compact form: one 32-byte record {pixel, nsamples, depth, pad, rgba} per ray that hit inside this
  * slab, behind a 32-byte header {records written = min(hits, capacity), hits, overflow flag, ...}.  dst must hold
- * 32 + 32 * capacity bytes.  The hit list stays valid until the next tsdf_raymarch: a second call with a larger capacity
+ * 32 + 32 * capacity bytes (a whole-volume context also ships one record per ray of its second march pass, hit or not: a miss is the
+ * clear colour at depth 1 with the ray's sample count).  The hit list stays valid until the next tsdf_raymarch: a second call with a larger capacity
  * re-exports the same frame (how the slab driver repairs an under-sized gather without a per-frame host synchronisation). */
 int32_t tsdf_export_hits_dev(tsdf_ctx* ctx, void* dst_dev, uint32_t capacity);
 /* n record buffers, stride_bytes apart, composited into this context's raymarch target (rank 0) */
 int32_t tsdf_composite_hits_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n, uint64_t stride_bytes);
 /* A whole-volume context marches in two passes: rays still running after `samples` samples are finished and shaded by a
- * wave-per-ray pass, which writes the pixel directly -- such rays are NOT on the hit list tsdf_export_hits_dev ships.  0 switches the
- * second pass off (every hit goes through the hit list, as in a slab context); the default is 24 (or RR_MARCH_CAP).  Used where one
- * context holds the whole volume but its frame is composited elsewhere (one worker + one compositing GPU, multigpu.py).  Results do
- * not depend on the value. */
+ * wave-per-ray pass (0 switches the second pass off; the default is 24, or RR_MARCH_CAP).  A tuning knob: results do not depend on the
+ * value, and tsdf_export_hits_dev ships the second pass's rays as well. */
 int32_t tsdf_set_march_cap(tsdf_ctx* ctx, uint32_t samples);
 
 /* ---- timers: the reference's TimerDatabase names: "2integrate", "3recon", "draw",

@@ -102,6 +102,7 @@ struct tsdf_ctx {
   bool use_ranges = true;         // RR_K1_RANGES=0: the dense integrate evaluates every voxel of every stream (A/B and test hook, read at creation)
   bool march_box = true;          // RR_MARCH_BOX=0: the dense march gathers from global memory as in round 1 (A/B and test hook, read at creation)
   void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
+  bool last_two_pass = false;     // the last march handed its long rays to the wave-per-ray pass (they are not on the hit list)
   bool own_miss_counts = false;   // this context has marched at this view size: its sample-count image holds the miss counts (-count, or count after a composite)
   unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
   float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
@@ -1120,6 +1121,7 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   timer_end(c, "k_march");
   launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
   c->hit_parity ^= 1;
+  c->last_two_pass = !partial && P.skip && c->d_long && c->march_cap != 0;          // launch_raymarch's own condition
   c->own_miss_counts = true;
   if (masked_direct(c)) launch_resolve_masked(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
   timer_end(c, "draw");
@@ -1481,7 +1483,8 @@ int32_t tsdf_export_hits_dev(tsdf_ctx* c, void* dst, uint32_t capacity) {
   if (!dst || capacity < 1) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
   // the raymarch that just ran used counter (hit_parity ^ 1): raymarch_impl flips the parity after its launch
-  launch_export_hits(c->stream, ray_target(c), c->vw, c->d_hits, c->d_hit_counters + (c->hit_parity ^ 1), dst, capacity);
+  const int p = c->hit_parity ^ 1;
+  launch_export_hits(c->stream, ray_target(c), c->vw, c->d_hits, c->d_hit_counters + p, c->last_two_pass ? c->d_long : nullptr, c->d_hit_counters + 2 + p, dst, capacity);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
 }

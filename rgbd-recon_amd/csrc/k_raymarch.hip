@@ -976,13 +976,17 @@ namespace rr {
 struct HitRecord { uint32_t pix; float ns; float depth; uint32_t pad; float4 color; };
 static_assert(sizeof(HitRecord) == 32, "HitRecord is 32 bytes");
 // buffer = [written, hit, overflow, 5 pad words][records...]
+// A whole-volume context marches in two passes: the rays of the second (wave-per-ray) pass are not on the hit list -- they were shaded,
+// or cleared, where the pass ended.  Their list is still there, so they are exported too, every one of them: a long ray that missed
+// ships (clear colour, depth 1, its sample count), which is what the pixel holds in the unpartitioned frame as well.
 __global__ __launch_bounds__(256) void k_export_hits(RayTarget R, int w, const Hit* __restrict__ hits, const uint32_t* __restrict__ hit_count,
+                                                     const LongRay* __restrict__ longs, const uint32_t* __restrict__ long_count,
                                                      uint32_t* __restrict__ header, HitRecord* __restrict__ rec, uint32_t capacity) {
-  const uint32_t n_hits = *hit_count, n = n_hits < capacity ? n_hits : capacity;
+  const uint32_t n_first = *hit_count, n_hits = n_first + (longs ? *long_count : 0u), n = n_hits < capacity ? n_hits : capacity;
   // header: [records written, rays that hit (may exceed the capacity: the receiver then asks again with a larger one), overflow flag]
   if (blockIdx.x == 0 && threadIdx.x == 0) { header[0] = n; header[1] = n_hits; header[2] = n_hits > capacity ? 1u : 0u; }
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t pix = hits[i].pix;
+    const uint32_t pix = i < n_first ? hits[i].pix : longs[i - n_first].pix;
     const int px = (int)(pix % (uint32_t)w), py = (int)(pix / (uint32_t)w);
     HitRecord r;
     r.pix = pix; r.ns = R.nsamples[pix]; r.depth = R.depth[(size_t)py * R.stride + px]; r.pad = 0u;
@@ -990,8 +994,10 @@ __global__ __launch_bounds__(256) void k_export_hits(RayTarget R, int w, const H
     rec[i] = r;
   }
 }
-void launch_export_hits(hipStream_t st, const RayTarget& R, int w, const void* hit_list, const uint32_t* hit_count, void* dst, uint32_t capacity) {
-  hipLaunchKernelGGL(k_export_hits, dim3(512), dim3(256), 0, st, R, w, (const Hit*)hit_list, hit_count, (uint32_t*)dst, (HitRecord*)((char*)dst + 32), capacity);
+void launch_export_hits(hipStream_t st, const RayTarget& R, int w, const void* hit_list, const uint32_t* hit_count, const void* long_list, const uint32_t* long_count,
+                        void* dst, uint32_t capacity) {
+  hipLaunchKernelGGL(k_export_hits, dim3(512), dim3(256), 0, st, R, w, (const Hit*)hit_list, hit_count, (const LongRay*)long_list, long_count, (uint32_t*)dst,
+                     (HitRecord*)((char*)dst + 32), capacity);
 }
 
 // composite on the gathering rank: (1) every pixel starts as "no rank hit" (clear colour, depth 1, the common miss count),

@@ -223,7 +223,8 @@ void launch_resolve_masked(hipStream_t st, const Atlas& A, int w, int h, float4*
 void launch_clear_image(hipStream_t st, float4* color, float* depth, size_t n, float4 c, float d);
 void launch_export_partial(hipStream_t st, const RayTarget& R, int w, int h, void* dst);
 void launch_composite(hipStream_t st, const void* gathered, int n, const RayTarget& R, int w, int h);
-void launch_export_hits(hipStream_t st, const RayTarget& R, int w, const void* hit_list, const uint32_t* hit_count, void* dst, uint32_t capacity);
+void launch_export_hits(hipStream_t st, const RayTarget& R, int w, const void* hit_list, const uint32_t* hit_count, const void* long_list, const uint32_t* long_count,
+                        void* dst, uint32_t capacity);   // long_list: the second-pass rays of a two-pass march (null: none)
 void launch_composite_hits(hipStream_t st, const void* gathered, size_t stride_bytes, int n, const RayTarget& R, int w, int h, unsigned long long* key, int own_counts);
 
 }  // namespace rr

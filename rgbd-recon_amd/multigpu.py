@@ -22,7 +22,7 @@ no multi-GPU path at all; what is partitioned here is the reference's single vol
     already integrating frame f + 1 (each rank's work is queued on its stream; the gather is the only meeting point), and the frame
     period is max(worker, compositor) instead of their sum.  With the compact composite the compositor does not march, so the
     write-only diagnostic image of sample counts (tex_num_samples, recon_integration.cpp:207-209: cleared and bound for imageStore,
-    read by nothing) holds 0 at the pixels no slab hit instead of the ray's total sample count; colour, depth, the sample counts of
+    read by nothing) holds 0 at the pixels no exported ray covers instead of the ray's total sample count; colour, depth, the sample counts of
     hit pixels and the hole-filled framebuffer are those of the single-GPU frame, bit for bit.
 
 The exchange works on plain device pointers across the C ABI (tsdf_halo_*_dev, tsdf_export_partial_dev,

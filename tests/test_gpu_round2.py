@@ -422,3 +422,39 @@ def test_set_voxel_size_recreates_the_volume_like_the_reference(rr, small_scene)
     slab = rr.ReconIntegrationHip(small_scene, res=(64, 64, 64), brick_size=0.25, limit=0.04, view=(160, 90), slab=mgpu.slab_range(64, 0, 2))
     with pytest.raises(rr.TsdfError):
         slab.setVoxelSize(0.05)
+
+
+# ------------------------------------------------------------------------------------------------ compact export of a two-pass march
+def test_compact_export_of_a_whole_context_ships_the_long_ray_pass_too(rr, small_scene):
+    """tsdf_export_hits_dev on a whole-volume context: the rays its second (wave-per-ray) march pass finished are not on the hit list,
+    so they are exported from the long-ray list -- every one, a miss as (clear colour, depth 1, its sample count).  Composited into a
+    second context that never marched, the records reproduce the frame: colour and depth everywhere, the sample counts wherever a
+    record landed.  The same with the second pass switched off (tsdf_set_march_cap(0): everything on the hit list) and with a
+    capacity that is too small (overflow flag, no write past the capacity)."""
+    import torch
+    kw = dict(res=(64, 64, 64), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(320, 180))
+    mv, pr = rr.scene.default_view(*kw["view"])
+    npx = kw["view"][0] * kw["view"][1]
+    src, dst = rr.ReconIntegrationHip(small_scene, **kw), rr.ReconIntegrationHip(small_scene, **kw)
+    for cap in (2, 24, 0):                                                  # 2: almost every ray goes to the second pass
+        src.setMarchCap(cap)
+        src.clearOccupiedBricks(); src.markBricks(); src.updateOccupiedBricks(); src.integrate(); src.draw(mv, pr)
+        buf = torch.zeros(8 + npx * 8, dtype=torch.float32, device="cuda:0")
+        src.export_hits_dev(buf.data_ptr(), npx); src.sync()
+        hdr = buf[:8].cpu().numpy().view(np.uint32)
+        assert hdr[0] == hdr[1] and hdr[2] == 0 and 300 < hdr[0] <= npx
+        dst.composite_hits_dev(buf.data_ptr(), 1, buf.numel() * 4); dst.sync()
+        (sa, sd, sn, _), (da, dd, dn, _) = src.view_images(), dst.view_images()
+        assert same(sd, dd).all() and same(sa, da).all() and int((sd < 1).sum()) > 300, f"cap {cap}"
+        rec = buf[8:8 + int(hdr[0]) * 8].cpu().numpy().reshape(-1, 8)
+        pix = rec[:, 0].copy().view(np.uint32)
+        assert np.unique(pix).size == pix.size                                # a ray is on one list only
+        assert same(sn.reshape(-1)[pix], dn.reshape(-1)[pix]).all() and (dn.reshape(-1)[np.setdiff1d(np.arange(npx), pix)] == 0).all()
+        if cap == 2:
+            first = hdr[0]
+        # too small a capacity: exactly `capacity` records, the overflow flag, nothing written behind them
+        small = torch.full((8 + 64 * 8 + 8,), -7.0, dtype=torch.float32, device="cuda:0")
+        src.export_hits_dev(small.data_ptr(), 64); src.sync()
+        h2 = small[:8].cpu().numpy().view(np.uint32)
+        assert h2[0] == 64 and h2[1] == hdr[1] and h2[2] == 1 and bool((small[8 + 64 * 8:] == -7.0).all())
+    assert first > 0
