@@ -138,6 +138,9 @@ def main():
                     help="N > 1: 'dedicated' = rank 0 only receives, composites and fills holes and the volume is split over ranks 1..N-1 "
                          "(the gathering rank's image-space tail is longer than a slab's share of the volume work, so an even split makes "
                          "rank 0 every frame's critical path); 'shared' = N slabs, rank 0 composites as well.  auto = dedicated")
+    ap.add_argument("--partition", default="even", choices=["even", "balanced"],
+                    help="N > 1: slabs of equal thickness, or boundaries by the occupied bricks per tile layer of the bench frames (measured no better: "
+                         "a slab's march cost follows its position along the view, not its bricks -- DESIGN.md section 6)")
     ap.add_argument("--scene", default="moving", choices=["moving", "static"], help="alternate two resident frames in the timed region (default), or repeat one")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3, 4],
                     help="single GPU: process this many frames concurrently, one context + HIP stream per slot (every frame rebuilds the "
@@ -211,6 +214,40 @@ def main():
     brick = [float(ext[a]) / cfg["res"][a] * 8 for a in range(3)]          # 8^3 voxels per brick
     dedicated = world > 1 and args.compositor != "shared"
     slab = (mg.worker_slab_range if dedicated else mg.slab_range)(cfg["res"][2], rank, world) if slabs_mode else (0, 0)
+    partition_note = "equal thickness"
+
+    def balanced_ranges(n_slabs):
+        """slab boundaries from the occupied bricks per tile layer of the bench frames (every rank computes the same ones: the brick tables
+        depend on the frames alone) -- a layer's weight is its occupied bricks plus a constant for what a layer costs however empty it is"""
+        t = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=(64, 36), device=local, slab=mg.slab_range(cfg["res"][2], 0, 4), recompute_halo=True)
+        layers = (cfg["res"][2] + 7) // 8
+        w = np.zeros(layers)
+        rb = t.res_bricks
+        for sc in scenes:
+            t.upload_frame(sc)
+            t.clearOccupiedBricks(); t.markBricks(); t.updateOccupiedBricks(False)
+            fl = t.bricks()[1].reshape(rb[2], rb[1], rb[0])
+            per_z = fl.sum((1, 2)).astype(float)
+            if rb[2] != layers:                           # bricks are not 8 voxels thick: spread a brick row over the layers it covers
+                per_z = np.interp((np.arange(layers) + 0.5) / layers, (np.arange(rb[2]) + 0.5) / rb[2], per_z) * rb[2] / layers
+            w += per_z
+        t.close()
+        w += 0.5 * w.sum() / layers
+        return mg.balanced_slab_ranges(w, n_slabs, cfg["res"][2])
+
+    if world > 1 and args.partition == "balanced" and cfg["use_bricks"]:
+        if dedicated:
+            slab = balanced_ranges(world - 1)[max(rank - 1, 0)]
+        else:
+            slab = balanced_ranges(world)[rank]
+        partition_note = "balanced by occupied bricks per tile layer"
+    # RR_BENCH_ALONE_SLAB="k/n" (with RR_BENCH_EXCHANGE_ALONE=1; rehearsal, never set by the driver): the one rank holds slab k of n --
+    # what ONE worker rank of an n-slab partition does per frame, measured on the one GPU (its composite is of course not the frame)
+    alone_slab = os.environ.get("RR_BENCH_ALONE_SLAB") if alone else None
+    if alone_slab:
+        parts = alone_slab.split("/")                    # "k/n" (equal thickness) or "k/n/balanced"
+        k_, n_ = int(parts[0]), int(parts[1])
+        slab = balanced_ranges(n_)[k_] if len(parts) > 2 else mg.slab_range(cfg["res"][2], k_, n_)
 
     def make_ctx(slab=(0, 0), recompute=False, sparse=0):
         h = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=VIEW, device=local, slab=slab,
@@ -257,7 +294,9 @@ def main():
 
     # ---- N > 1: the partition must reproduce the unpartitioned frame, bit for bit, before it is worth timing
     slab_check = None
-    if slabs_mode:
+    if alone_slab:
+        slab_check = f"skipped: one slab ({alone_slab}, voxel planes {list(slab)}) alone is not the frame"
+    elif slabs_mode:
         ok = True
         got = []
         for k in range(nsc):
@@ -415,9 +454,9 @@ def main():
                    "scene": "two resident frames alternating every step (objects moved: every active tile churns)" if nsc > 1 else "one static frame",
                    "frames_in_flight": args.frames_in_flight,
                    "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
-                   "parallelism": ("single GPU, slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else
+                   "parallelism": ((f"single GPU holding slab {alone_slab} of the volume, " if alone_slab else "single GPU, ") + "slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else
                                   (f"ONE volume in {world - 1} Z-slab(s) on ranks 1..{world - 1} + rank 0 as dedicated compositor (receive, composite, hole filling)" if dedicated else
-                                   f"ONE volume in {world} Z-slabs") + f" (strong scaling), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame"},
+                                   f"ONE volume in {world} Z-slabs") + f" (strong scaling; slab boundaries {partition_note}; this rank's voxel planes {list(slab)}), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame"},
         "static": static,
         "long_run": long_run,
         "stage_ms": stages,

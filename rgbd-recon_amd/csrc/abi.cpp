@@ -1095,7 +1095,9 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   const bool shifted = P.vp_org[0] != 0 || P.vp_org[1] != 0 || P.vp_off[0] != 0.0f || P.vp_off[1] != 0.0f;
   if (shifted && partial) FAIL(c, TSDF_ERR_STATE, "a viewport origin / offset is not available on a slab context (the composite indexes pixels)");
   if (shifted) HIP_TRY(c, hipMemsetAsync(c->d_nsamples, 0, (size_t)c->vw * c->vh * sizeof(float), c->stream));   // clearImage of tex_num_samples, :207-208: the stores land at origin + pixel
-  const bool use_tiles = P.skip && !partial && c->use_tile_history && !shifted && !masked_direct(c);
+  // (slab contexts too: a tile without a brick under it holds clear values after the march AND after a composite into this target --
+  // the brick tables are replicated, so no rank can hit there)
+  const bool use_tiles = P.skip && c->use_tile_history && !shifted && !masked_direct(c);
   if (P.skip) {
     timer_begin(c, "brickdraw");
     if (use_tiles && !c->tile_history) {

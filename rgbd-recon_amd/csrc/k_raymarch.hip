@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
   const int px = blockIdx.x * 16 + (wv & 1) * 8 + (ln & 7);
   const int py = blockIdx.y * 16 + (wv >> 1) * 8 + (ln >> 3);
   const bool inside = px < P.w && py < P.h;
-  if (!partial && R.touched_cur) {
+  if (R.touched_cur) {
     // this wave IS one 8x8 image tile: untouched now -> nothing to march; untouched before as well -> already holds clear values
     const int ntx = (P.w + 7) >> 3, tx = blockIdx.x * 2 + (wv & 1), ty = blockIdx.y * 2 + (wv >> 1);
     if (tx >= ntx || ty * 8 >= P.h) return;

@@ -49,11 +49,35 @@ import torch.distributed as dist
 
 
 def worker_slab_range(res_z: int, rank: int, world: int):
-    """Slab of rank `rank` when rank 0 is a dedicated compositor: ranks 1 .. world-1 split the volume; rank 0 gets the first tile
-    layer as a placeholder (its context needs SOME volume; it is never integrated or marched)."""
-    if rank == 0:
-        return 0, min(8, res_z)
-    return slab_range(res_z, rank - 1, world - 1)
+    """Slab of rank `rank` when rank 0 is a dedicated compositor: ranks 1 .. world-1 split the volume; rank 0 gets the first worker's
+    slab as a placeholder (its context needs SOME valid volume -- a slab may not be thinner than its halo --; it is never integrated
+    or marched)."""
+    return slab_range(res_z, max(rank - 1, 0), world - 1)
+
+
+def balanced_slab_ranges(layer_weights, world: int, res_z: int):
+    """Contiguous tile-aligned split of the Z axis into `world` slabs of about equal total weight (every slab at least one tile layer):
+    the occupied bricks of a scene are not spread evenly over z, and the frame period of the partition is its slowest slab's.
+    `layer_weights[l]` is the cost of tile layer l (e.g. its occupied bricks plus a constant for the per-layer floor); every rank
+    must pass the same weights.  Returns [(z0, z1)] in voxel planes."""
+    w = [float(x) for x in layer_weights]
+    layers = len(w)
+    assert layers == (res_z + 7) // 8 and 1 <= world <= layers
+    cum = [0.0]
+    for x in w:
+        cum.append(cum[-1] + x)
+    bounds = [0]
+    for k in range(1, world):
+        target = cum[-1] * k / world
+        b = bounds[-1] + 1
+        while b < layers and cum[b] < target:
+            b += 1
+        if b > bounds[-1] + 1 and abs(cum[b - 1] - target) <= abs(cum[b] - target):
+            b -= 1                                       # the boundary nearest to the target
+        b = max(bounds[-1] + 1, min(b, layers - (world - k)))
+        bounds.append(b)
+    bounds.append(layers)
+    return [(bounds[k] * 8, min(bounds[k + 1] * 8, res_z)) for k in range(world)]
 
 
 def slab_range(res_z: int, rank: int, world: int):

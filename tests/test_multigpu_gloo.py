@@ -321,7 +321,20 @@ def test_worker_slab_range():
     mgpu = import_module("rgbd-recon_amd.multigpu")
     for res_z, world in [(512, 8), (512, 2), (1024, 8), (221, 3)]:
         r = [mgpu.worker_slab_range(res_z, k, world) for k in range(world)]
-        assert r[0] == (0, 8)                                                 # the compositor's placeholder layer
+        assert r[0] == r[1]                                                   # the compositor's placeholder: a valid slab (never integrated)
         assert r[1:] == [mgpu.slab_range(res_z, k, world - 1) for k in range(world - 1)]
     with pytest.raises(AssertionError):
         mgpu.SlabDriver(None, 0, 1, "cpu", compositor="dedicated")
+
+
+def test_balanced_slab_ranges():
+    mgpu = import_module("rgbd-recon_amd.multigpu")
+    assert mgpu.balanced_slab_ranges([1] * 64, 8, 512) == [mgpu.slab_range(512, k, 8) for k in range(8)]
+    w = [0.2] * 20 + [5] * 10 + [10] * 8 + [5] * 10 + [0.2] * 16
+    for world in (2, 3, 7, 8):
+        r = mgpu.balanced_slab_ranges(w, world, 512)
+        assert r[0][0] == 0 and r[-1][1] == 512 and all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(hi > lo and lo % 8 == 0 for lo, hi in r)
+        cost = [sum(w[lo // 8:(hi + 7) // 8]) for lo, hi in r]
+        assert max(cost) <= 1.6 * sum(w) / world                              # no slab much heavier than its share
+    assert mgpu.balanced_slab_ranges([0] * 63 + [1], 4, 512) == [(0, 488), (488, 496), (496, 504), (504, 512)]   # every slab at least one layer
+    assert mgpu.balanced_slab_ranges([1, 1, 1], 3, 20) == [(0, 8), (8, 16), (16, 20)]
