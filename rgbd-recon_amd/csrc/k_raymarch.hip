@@ -241,6 +241,14 @@ constexpr int kBatchSkip = RR_MARCH_BATCH_SKIP;
 #endif
 constexpr int kLongBatch = RR_LONG_BATCH;   // samples per lane and round in the long-ray pass
 
+#ifdef RR_MARCH_STATS     // instrumented build (tools/march_stats.py): [max (wave cycles << 32 | pixel), max pre-run steps, max batches, max max_n, working waves, sum of wave cycles]
+__device__ unsigned long long g_march_stats[8];
+extern "C" int32_t tsdf_debug_march_stats(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_march_stats), sizeof(g_march_stats)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_march_stats), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 template <bool kPartial, bool kSparse, int kBatch>
 __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count,
                                                                  LongRay* __restrict__ longs, uint32_t* __restrict__ long_count, uint32_t cap) {
@@ -267,6 +275,10 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
       return;
     }
   }
+#ifdef RR_MARCH_STATS
+  const unsigned long long t_start = wall_clock64();
+  uint32_t st_pre = 0, st_batches = 0;
+#endif
   const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
   const float3 dn = normalize3(pixel_dir_vol(P, fx, fy));
   const float3 step = make_float3(dn.x * sd, dn.y * sd, dn.z * sd);     // :64
@@ -329,9 +341,15 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
       pos = make_float3(pos.x + step.x, pos.y + step.y, pos.z + step.z);
       n += 1;
       prev_valid = false;
+#ifdef RR_MARCH_STATS
+      ++st_pre;
+#endif
     }
   }
   while (n < max_n && !hit) {
+#ifdef RR_MARCH_STATS
+    ++st_batches;
+#endif
     float3 p[kBatch];
     float d[kBatch];
     bool own[kBatch];
@@ -411,6 +429,21 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
     const int sx = px + P.vp_org[0], sy = py + P.vp_org[1];
     if (sx >= 0 && sy >= 0 && sx < P.w && sy < P.h) R.nsamples[(size_t)sy * P.w + sx] = covered ? ((partial && !hit) ? -ns : ns) : 0.0f;
   }
+#ifdef RR_MARCH_STATS
+  {
+    const unsigned long long dt = wall_clock64() - t_start;             // 100 MHz ticks
+    uint32_t m1 = st_pre, m2 = st_batches, m3 = max_n;
+    for (int o = 32; o; o >>= 1) { m1 = max(m1, (uint32_t)__shfl_xor((int)m1, o)); m2 = max(m2, (uint32_t)__shfl_xor((int)m2, o)); m3 = max(m3, (uint32_t)__shfl_xor((int)m3, o)); }
+    if (ln == 0) {
+      atomicMax(&g_march_stats[1], (unsigned long long)m1);
+      atomicMax(&g_march_stats[2], (unsigned long long)m2);
+      atomicMax(&g_march_stats[3], (unsigned long long)m3);
+      atomicMax(&g_march_stats[0], (dt << 32) | (unsigned long long)(uint32_t)(py * P.w + px));
+      atomicAdd(&g_march_stats[4], 1ull);
+      atomicAdd(&g_march_stats[5], dt);
+    }
+  }
+#endif
 }
 
 // Dense march through LDS-staged voxel boxes (round 2; whole-volume dense storage, no depth limits: configs[1]).
