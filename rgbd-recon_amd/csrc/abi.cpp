@@ -99,6 +99,7 @@ struct tsdf_ctx {
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
   bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)
   float4* d_tile_bounds = nullptr; bool tile_bounds_valid = false;   // static per (stored tile, stream) LUT-box bounds, built on the first dense integrate after a calibration
+  bool culled_ranges = true;      // RR_K1_CULLED_RANGES=0: no uniform-pair shortcut in culled launches (A/B hook; dense storage with a bounds table of at most 512 MiB only)
   bool use_ranges = true;         // RR_K1_RANGES=0: the dense integrate evaluates every voxel of every stream (A/B and test hook, read at creation)
   bool march_box = true;          // RR_MARCH_BOX=0: the dense march gathers from global memory as in round 1 (A/B and test hook, read at creation)
   void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
@@ -563,6 +564,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   c->stream = c->own_stream;
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
+  if (const char* e = getenv("RR_K1_CULLED_RANGES")) c->culled_ranges = atoi(e) != 0;
   // setVoxelSize(), :340-347
   for (int a = 0; a < 3; ++a) {
     const float ext = cfg->bbox_max[a] - cfg->bbox_min[a];
@@ -1069,7 +1071,8 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
   // dense launches: the static half of the uniform-pair shortcut (k_integrate.hip), built once per calibration
   const float4* bounds = nullptr;
-  if (!c->use_bricks && lds >= 2 && c->frame.ranges) {
+  const bool culled_ranges = c->use_bricks && c->culled_ranges && !c->vol.slot && (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 32 <= ((size_t)512 << 20);
+  if ((!c->use_bricks || culled_ranges) && lds >= 2 && c->frame.ranges) {
     if (!c->d_tile_bounds) HIP_TRY(c, hipMalloc((void**)&c->d_tile_bounds, (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 2 * sizeof(float4)));
     if (!c->tile_bounds_valid) { launch_tile_bounds(c->stream, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
     bounds = c->d_tile_bounds;

@@ -751,6 +751,7 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     if (phase == 1) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
     if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<true, false>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr, wc);
+    else if (lds_ok == 2 && F.ranges && tile_bounds) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, tile_bounds);
     else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);

@@ -458,3 +458,46 @@ def test_compact_export_of_a_whole_context_ships_the_long_ray_pass_too(rr, small
         h2 = small[:8].cpu().numpy().view(np.uint32)
         assert h2[0] == 64 and h2[1] == hdr[1] and h2[2] == 1 and bool((small[8 + 64 * 8:] == -7.0).all())
     assert first > 0
+
+
+def test_culled_integrate_uniform_pair_shortcut_equals_per_voxel_evaluation(rr, monkeypatch):
+    """The same shortcut in the culled launch (dense storage): per active tile and stream, from the static LUT-box bounds and the frame's
+    per-cell ranges.  Against the launch without it (RR_K1_CULLED_RANGES=0) and the oracle, on the plain frames and on the frame with
+    NaN / infinite / out-of-range LUT texels, NaN and negative depths and silhouettes that are neither 0 nor 1; slab contexts too."""
+    base = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
+    rng = np.random.default_rng(12)
+    odd = dict(base)
+    inv = odd["cv_xyz_inv"].copy()
+    n = inv.shape[1]
+    for i, vals in enumerate(([np.nan, 0.3, 0.5], [np.inf, -np.inf, 0.4], [7.5, -3.25, 0.45], [0.5, 0.5, -2.0e5])):
+        inv[i, rng.choice(n, n // 60, replace=False), :3] = np.array(vals, np.float32)
+    odd["cv_xyz_inv"] = inv
+    d = odd["depth"].copy(); q = odd["quality"].copy(); s = odd["silhouette"].copy()
+    d[0, 10:14, 20:40, 0] = np.nan; d[1, 50:60, 70:90, 0] = -0.3; d[2, 80:82, :, 0] = np.inf
+    s[1, 30:50, 30:50] = 0.5; s[3, 60:70, 10:30] = np.nan; s[2, 5:9, 100:140] = 2.0
+    odd["depth"], odd["quality"], odd["silhouette"] = d, q, s
+    moved = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2))
+    for res in ((64, 64, 64), (128, 128, 128)):
+        kw = dict(res=res, brick_size=[2.0 / res[0] * 8, 2.2 / res[1] * 8, 2.0 / res[2] * 8], limit=0.04 if res[0] < 100 else 0.02, view=(64, 36))
+        for k, sc in enumerate((base, moved, odd)):
+            fast = rr.ReconIntegrationHip(sc, **kw)
+            monkeypatch.setenv("RR_K1_CULLED_RANGES", "0")
+            slow = rr.ReconIntegrationHip(sc, **kw)
+            monkeypatch.delenv("RR_K1_CULLED_RANGES")
+            orc = OracleRecon(sc, **kw)
+            for o in (fast, slow, orc):
+                o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks(); o.integrate()
+            a, b, c = fast.tsdf(), slow.tsdf(), orc.tsdf()
+            assert same(a, b).all(), f"res {res} scene {k}: shortcut vs per-voxel"
+            assert same(a, c).all(), f"res {res} scene {k}: shortcut vs oracle"
+            assert (np.abs(a) < kw["limit"]).sum() > 100
+    mgpu = import_module("rgbd-recon_amd.multigpu")
+    kw = dict(res=(64, 64, 64), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(64, 36))
+    whole = rr.ReconIntegrationHip(odd, **kw)
+    whole.clearOccupiedBricks(); whole.markBricks(); whole.updateOccupiedBricks(); whole.integrate()
+    w = whole.tsdf().reshape(64, 64, 64)
+    for r in range(3):
+        z0, z1 = mgpu.slab_range(64, r, 3)
+        sl = rr.ReconIntegrationHip(odd, slab=(z0, z1), recompute_halo=True, **kw)
+        sl.clearOccupiedBricks(); sl.markBricks(); sl.updateOccupiedBricks(); sl.integrate()
+        assert same(sl.tsdf().reshape(64, 64, 64)[z0:z1], w[z0:z1]).all(), f"slab {r}"
