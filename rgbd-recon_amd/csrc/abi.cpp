@@ -98,6 +98,7 @@ struct tsdf_ctx {
   uint32_t* d_tri_z = nullptr; float4* d_tri_acc = nullptr; float min_length = 0.0125f;   // triangle-grid back-end; KinectCalibrationFile.cpp:96 default
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
   bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)
+  uint32_t* d_pair_masks = nullptr;   // per work item of the integrate launch: this frame's (tile, stream) pair classes (k_pair_masks)
   float4* d_tile_bounds = nullptr; bool tile_bounds_valid = false;   // static per (stored tile, stream) LUT-box bounds, built on the first dense integrate after a calibration
   bool culled_ranges = true;      // RR_K1_CULLED_RANGES=0: no uniform-pair shortcut in culled launches (A/B hook; dense storage with a bounds table of at most 512 MiB only)
   bool use_ranges = true;         // RR_K1_RANGES=0: the dense integrate evaluates every voxel of every stream (A/B and test hook, read at creation)
@@ -450,7 +451,7 @@ RayTarget ray_target(tsdf_ctx* c) {
 // sparse pool, per-tile state and work lists).  Called by tsdf_create and tsdf_set_voxel_size; everything it allocates is released first.
 void release_volume(tsdf_ctx* c) {
    hipFree(c->tiles.stamp); hipFree(c->d_cls_all);
-  hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts); hipFree(c->d_linear); hipFree(c->d_tile_bounds);
+  hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts); hipFree(c->d_linear); hipFree(c->d_tile_bounds); hipFree(c->d_pair_masks); c->d_pair_masks = nullptr;
   c->vol.data = nullptr; c->vol.slot = nullptr; c->tiles.stamp = nullptr; c->d_cls_all = nullptr;
   c->d_tile_list[0] = c->d_tile_list[1] = nullptr; c->d_tile_counts = nullptr; c->d_linear = nullptr; c->d_tile_bounds = nullptr;
   c->tile_bounds_valid = false; c->tile_parity = 0; c->full_classify = true; c->frame_stamp = 0;
@@ -1074,10 +1075,11 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   const bool culled_ranges = c->use_bricks && c->culled_ranges && !c->vol.slot && (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 32 <= ((size_t)512 << 20);
   if ((!c->use_bricks || culled_ranges) && lds >= 2 && c->frame.ranges) {
     if (!c->d_tile_bounds) HIP_TRY(c, hipMalloc((void**)&c->d_tile_bounds, (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 2 * sizeof(float4)));
+    if (!c->d_pair_masks) HIP_TRY(c, hipMalloc((void**)&c->d_pair_masks, (size_t)c->tiles.n * sizeof(uint32_t)));
     if (!c->tile_bounds_valid) { launch_tile_bounds(c->stream, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
     bounds = c->d_tile_bounds;
   }
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 2, nullptr, ws_box, ws_row, bounds);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 2, nullptr, ws_box, ws_row, bounds, bounds ? c->d_pair_masks : nullptr);
   timer_end(c, "k_integrate_tiles");
   if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
   else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them

@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 //     depth range bounds sdist = z - depth for every voxel, nearest texel included.
 // Outcome per pair: kPairFull (evaluate as before), kPairCarve (tsd >= limit ? -limit : tsd), kPairNeg (tsd = -limit), kPairNop.  Any
 // NaN / non-finite value, an oversized rectangle or a mixed range fails the tests (comparisons with NaN are false) -> kPairFull.
-// Each wave of the workgroup derives the class by itself from the box in LDS (same data, same instructions: the same answer), so the
-// shortcut costs no workgroup barrier.
+// The classes of a launch are worked out by a pass of its own (k_pair_masks, below) and read by the integrate kernels with one scalar
+// load per work item.
 constexpr int kPairFull = 0, kPairCarve = 1, kPairNeg = 2, kPairNop = 3;
 __device__ __forceinline__ float wave_min_f32(float v) {          // DPP row shifts + row broadcasts, result wave-uniform (see k_raymarch.hip)
 #define RR_DPP_MIN(ctrl, rm, bm) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rm, bm, false)))
@@ -292,44 +292,42 @@ __device__ __forceinline__ float wave_min_f32(float v) {          // DPP row shi
 __device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
 // Per (tile, stream) the (u, v, z) range over the tile's LUT texel box -- static: it depends on the calibration volume and the voxel
 // grid only -- is computed once (k_tile_bounds, below) as two float4 {u0, u1, v0, v1}, {z0, z1, -, -}; NaN marks a box with a
-// non-finite or far-away texel.  The class of (tile, stream i) for THIS frame, by one wave (the result is wave-uniform):
-// (not inlined, arguments by value: inlined into the integrate kernel its temporaries cost two spilled VGPRs at 8 waves/SIMD, and the
-// spill stores of 8 M threads were 44 MB of extra write traffic per dense launch)
-#ifndef RR_K1_CLASSIFY_INLINE
-#define RR_K1_CLASSIFY_INLINE 0
-#endif
-#if RR_K1_CLASSIFY_INLINE
-__device__ __forceinline__
-#else
-__device__ __attribute__((noinline))
-#endif
-int classify_pair(const float4* __restrict__ ranges, int rcw, int rch, int img_w, int img_h, int i, float4 b0, float4 b1, float limit) {
-  const int ln = threadIdx.x & 63;
+// non-finite or far-away texel.  The class of (tile, stream) for THIS frame is worked out by a half wave (two streams per call, up to
+// 32 range cells each: a lane loads one cell of the rectangle, DPP row shifts and one row broadcast reduce them).
+__device__ __forceinline__ float half_min_f32(float v) {
+#define RR_DPP_MIN(ctrl, rm, bm) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rm, bm, false)))
+  RR_DPP_MIN(0x111, 0xf, 0xf); RR_DPP_MIN(0x112, 0xf, 0xf); RR_DPP_MIN(0x114, 0xf, 0xe); RR_DPP_MIN(0x118, 0xf, 0xc);
+  RR_DPP_MIN(0x142, 0xa, 0xf);                                          // row_bcast:15 -> lane 31 holds rows 0-1, lane 63 rows 2-3
+#undef RR_DPP_MIN
+  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)), hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ float half_max_f32(float v) { return -half_min_f32(-v); }
+__device__ __forceinline__ int classify_pair_half(const float4* __restrict__ ranges, int rcw, int rch, int img_w, int img_h, int i, bool valid, float4 b0, float4 b1, float limit) {
+  const int r = threadIdx.x & 31;
   const float inf = __builtin_inff();
   const float u0 = b0.x, u1 = b0.y, v0 = b0.z, v1 = b0.w, z0 = b1.x, z1 = b1.y;
-  if (!(u0 <= u1)) return kPairFull;                                   // NaN: the box holds something non-finite
-  // slack of the three nested lerps (each within ~3 ulps of a value bounded by the box): 1e-5 relative is two orders above it
+  bool ok = valid && (u0 <= u1);                                       // NaN: the box holds something non-finite
   const float su = 1.0e-5f * (1.0f + fmaxf(fabsf(u0), fabsf(u1))), sv = 1.0e-5f * (1.0f + fmaxf(fabsf(v0), fabsf(v1)));
-  // the texel rectangle of the bilinear footprints (axis_linear: f = u * n - 0.5, taps floor(f) and floor(f) + 1, clamped)
   const float wf = (float)img_w, hf = (float)img_h;
   const int x0 = (int)__builtin_amdgcn_fmed3f(floorf((u0 - su) * wf - 0.5f), 0.0f, wf - 1.0f), x1 = (int)__builtin_amdgcn_fmed3f(floorf((u1 + su) * wf - 0.5f) + 1.0f, 0.0f, wf - 1.0f);
   const int y0 = (int)__builtin_amdgcn_fmed3f(floorf((v0 - sv) * hf - 0.5f), 0.0f, hf - 1.0f), y1 = (int)__builtin_amdgcn_fmed3f(floorf((v1 + sv) * hf - 0.5f) + 1.0f, 0.0f, hf - 1.0f);
   const int cx0 = x0 >> 3, cy0 = y0 >> 3, cw = (x1 >> 3) - cx0 + 1, chh = (y1 >> 3) - cy0 + 1;
-  if (cw < 1 || chh < 1 || __mul24(cw, chh) > 64) return kPairFull;
+  ok = ok && cw >= 1 && chh >= 1 && __mul24(cw, chh) <= 32;
   float d0 = inf, d1 = -inf, s0 = inf, s1 = -inf;
-  if (ln < __mul24(cw, chh)) {
-    const int ry = (int)(((float)ln + 0.5f) * __builtin_amdgcn_rcpf((float)cw));          // ln / cw
-    const float4 r = ranges[(size_t)__mul24(__mul24(i, rch) + cy0 + ry, rcw) + (cx0 + ln - __mul24(ry, cw))];
-    d0 = r.x; d1 = r.y; s0 = r.z; s1 = r.w;
+  if (ok && r < __mul24(cw, chh)) {
+    const int ry = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)cw));           // r / cw
+    const float4 q = ranges[(size_t)__mul24(__mul24(i, rch) + cy0 + ry, rcw) + (cx0 + r - __mul24(ry, cw))];
+    d0 = q.x; d1 = q.y; s0 = q.z; s1 = q.w;
   }
-  d0 = wave_min_f32(d0); d1 = wave_max_f32(d1); s0 = wave_min_f32(s0); s1 = wave_max_f32(s1);
-  const float sz = 1.0e-5f * (1.0f + fmaxf(fabsf(z0), fabsf(z1)) + fmaxf(fabsf(d0), fabsf(d1)));   // lerp slack of z + the rounding of z - depth
-  const bool all_le = (z1 + sz) - d0 <= -limit - sz;                   // sdist <= -limit for every voxel (false for NaN / infinite ranges)
-  const bool all_ge = (z0 - sz) - d1 >= limit + sz;                    // sdist >= limit for every voxel
+  d0 = half_min_f32(d0); d1 = half_max_f32(d1); s0 = half_min_f32(s0); s1 = half_max_f32(s1);
+  const float sz = 1.0e-5f * (1.0f + fmaxf(fabsf(z0), fabsf(z1)) + fmaxf(fabsf(d0), fabsf(d1)));
+  const bool all_le = (z1 + sz) - d0 <= -limit - sz, all_ge = (z0 - sz) - d1 >= limit + sz;
   const bool sil0 = s0 == 0.0f && s1 == 0.0f, sil1 = s0 == 1.0f && s1 == 1.0f;
-  if (sil0 && all_ge) return kPairCarve;                               // silhouette < 1: tsd >= limit -> -limit; otherwise sdist >= limit: nothing
-  if ((sil0 || sil1) && all_le) return kPairNeg;                       // carved by the silhouette rule or by sdist <= -limit: -limit either way
-  if (sil1 && all_ge) return kPairNop;                                 // behind the surface: nothing
+  if (!ok) return kPairFull;
+  if (sil0 && all_ge) return kPairCarve;
+  if ((sil0 || sil1) && all_le) return kPairNeg;
+  if (sil1 && all_ge) return kPairNop;
   return kPairFull;
 }
 // the static half: one wave per (stored tile, stream) reduces min / max of (u, v, z) over the tile's LUT texel box
@@ -371,6 +369,31 @@ void launch_tile_bounds(hipStream_t st, const StreamTable& T, const Volume& V, f
   hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, T, V, bounds, V.n_stored_tiles);
 }
 
+// The per-frame half of the uniform-pair shortcut as a pass of its own: one wave per work item (list entry or tile) classifies the item's
+// (tile, stream) pairs two streams at a time and packs the classes, 2 bits per stream, into masks[work item]; the integrate kernels
+// read their item's word with one scalar load.  (Classifying in the integrate kernel's prologue put two dependent global round trips
+// in front of every tile's chain: c2 53.2 -> 51.8 us; as a pass of its own the shortcut is worth what it skips.)
+template <bool kList>
+__global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F, Volume V, TileState S, const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks) {
+  const int ln = threadIdx.x & 63;
+  const int n_work = kList ? (int)*S.count : S.n;
+  const int n_waves = gridDim.x * 4;
+  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_work; w += n_waves) {
+    const int tile = work_tile<kList>(S, w);
+    const uint32_t st = stored_tile_index(V, tile);
+    uint32_t pairs = 0;
+    for (int cb = 0; cb < T.n; cb += 2) {
+      const int i = cb + (ln >> 5);
+      const bool valid = i < T.n;
+      const size_t o = 2 * ((size_t)st * T.n + (valid ? i : 0));
+      const int pair = classify_pair_half(F.ranges, F.rcw, F.rch, F.w, F.h, i, valid, tile_bounds[o], tile_bounds[o + 1], V.limit);
+      pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 0) << (2 * cb);
+      if (cb + 1 < T.n) pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 32) << (2 * cb + 2);
+    }
+    if (ln == 0) masks[w] = pairs;
+  }
+}
+
 #ifndef RR_K1_BOXCAP
 #define RR_K1_BOXCAP 384
 #endif
@@ -383,8 +406,7 @@ static_assert(kBoxCap <= 1024, "phase B's division-free index decomposition is e
 
 template <bool kList, bool kSep, bool kRanges = false>
 __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
-                                                                             const float4* __restrict__ tile_bounds) {
-  __shared__ int s_pair[TSDF_MAX_STREAMS];        // (kRanges) class of (this tile, stream): kPairFull / Carve / Neg / Nop
+                                                                             const uint32_t* __restrict__ pair_masks) {
   __shared__ float4 s_box[kBoxCap];             // the stream's texel box, x fastest: ((z - mz) * dy + (y - my)) * dx + (x - mx)
   __shared__ float4 s_row[kSep ? kRowCap : 1];  // (separable form) x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
   __shared__ int s_i0a[TSDF_MAX_STREAMS][3][8], s_i1a[TSDF_MAX_STREAMS][3][8];   // per stream, axis and voxel coordinate of the tile: the two texel indices ...
@@ -414,14 +436,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       wsum[h] = 0.0f;
     }
     // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)
-    if (kRanges) {                                                      // which streams treat every voxel of this tile alike?  one wave per stream
-      const uint32_t st_tile = stored_tile_index(V, tile);
-      for (int i = tid >> 6; i < T.n; i += 4) {
-        const size_t o = 2 * ((size_t)st_tile * T.n + i);
-        const int pair = classify_pair(F.ranges, F.rcw, F.rch, F.w, F.h, i, tile_bounds[o], tile_bounds[o + 1], limit);
-        if ((tid & 63) == 0) s_pair[i] = pair;
-      }
-    }
+    const uint32_t pairs = kRanges ? pair_masks[w] : 0u;                // (kRanges) 2 bits per stream, from k_pair_masks: which streams treat every voxel of this tile alike
     for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
       const int i = t / 24, a = (t % 24) >> 3, k = t & 7;
       const int coord = min(t3[a] * 8 + k, V.res[a] - 1);               // padding voxels reuse the last real coordinate
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
     __syncthreads();
     for (int i = 0; i < T.n; ++i) {
       if (kRanges) {
-        const int pair = s_pair[i];                                     // workgroup-uniform
+        const int pair = (int)((pairs >> (2 * i)) & 3u);                // workgroup-uniform
         if (pair != kPairFull) {                                        // no box, no passes, no gathers: the branch is the same for every voxel
 #pragma unroll
           for (int h = 0; h < kVox; ++h)
@@ -551,46 +566,9 @@ struct WsCaps { int box, row; };
 #ifndef RR_K1W_BATCH
 #define RR_K1W_BATCH 1      // voxels of a lane whose image gathers are in flight together (2: 10 spilled VGPRs at 6 waves/SIMD, c2 52.8 instead of 50.5 us)
 #endif
-// class of (tile, stream) by a half wave (two streams per call, up to 32 range cells each): see classify_pair
-__device__ __forceinline__ float half_min_f32(float v) {
-#define RR_DPP_MIN(ctrl, rm, bm) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rm, bm, false)))
-  RR_DPP_MIN(0x111, 0xf, 0xf); RR_DPP_MIN(0x112, 0xf, 0xf); RR_DPP_MIN(0x114, 0xf, 0xe); RR_DPP_MIN(0x118, 0xf, 0xc);
-  RR_DPP_MIN(0x142, 0xa, 0xf);                                          // row_bcast:15 -> lane 31 holds rows 0-1, lane 63 rows 2-3
-#undef RR_DPP_MIN
-  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)), hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-  return (threadIdx.x & 32) ? hi : lo;
-}
-__device__ __forceinline__ float half_max_f32(float v) { return -half_min_f32(-v); }
-__device__ __forceinline__ int classify_pair_half(const float4* __restrict__ ranges, int rcw, int rch, int img_w, int img_h, int i, bool valid, float4 b0, float4 b1, float limit) {
-  const int r = threadIdx.x & 31;
-  const float inf = __builtin_inff();
-  const float u0 = b0.x, u1 = b0.y, v0 = b0.z, v1 = b0.w, z0 = b1.x, z1 = b1.y;
-  bool ok = valid && (u0 <= u1);                                       // NaN: the box holds something non-finite
-  const float su = 1.0e-5f * (1.0f + fmaxf(fabsf(u0), fabsf(u1))), sv = 1.0e-5f * (1.0f + fmaxf(fabsf(v0), fabsf(v1)));
-  const float wf = (float)img_w, hf = (float)img_h;
-  const int x0 = (int)__builtin_amdgcn_fmed3f(floorf((u0 - su) * wf - 0.5f), 0.0f, wf - 1.0f), x1 = (int)__builtin_amdgcn_fmed3f(floorf((u1 + su) * wf - 0.5f) + 1.0f, 0.0f, wf - 1.0f);
-  const int y0 = (int)__builtin_amdgcn_fmed3f(floorf((v0 - sv) * hf - 0.5f), 0.0f, hf - 1.0f), y1 = (int)__builtin_amdgcn_fmed3f(floorf((v1 + sv) * hf - 0.5f) + 1.0f, 0.0f, hf - 1.0f);
-  const int cx0 = x0 >> 3, cy0 = y0 >> 3, cw = (x1 >> 3) - cx0 + 1, chh = (y1 >> 3) - cy0 + 1;
-  ok = ok && cw >= 1 && chh >= 1 && __mul24(cw, chh) <= 32;
-  float d0 = inf, d1 = -inf, s0 = inf, s1 = -inf;
-  if (ok && r < __mul24(cw, chh)) {
-    const int ry = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)cw));           // r / cw
-    const float4 q = ranges[(size_t)__mul24(__mul24(i, rch) + cy0 + ry, rcw) + (cx0 + r - __mul24(ry, cw))];
-    d0 = q.x; d1 = q.y; s0 = q.z; s1 = q.w;
-  }
-  d0 = half_min_f32(d0); d1 = half_max_f32(d1); s0 = half_min_f32(s0); s1 = half_max_f32(s1);
-  const float sz = 1.0e-5f * (1.0f + fmaxf(fabsf(z0), fabsf(z1)) + fmaxf(fabsf(d0), fabsf(d1)));
-  const bool all_le = (z1 + sz) - d0 <= -limit - sz, all_ge = (z0 - sz) - d1 >= limit + sz;
-  const bool sil0 = s0 == 0.0f && s1 == 0.0f, sil1 = s0 == 1.0f && s1 == 1.0f;
-  if (!ok) return kPairFull;
-  if (sil0 && all_ge) return kPairCarve;
-  if ((sil0 || sil1) && all_le) return kPairNeg;
-  if (sil1 && all_ge) return kPairNop;
-  return kPairFull;
-}
 template <bool kList, bool kRanges>
 __global__ __launch_bounds__(64, RR_K1W_WAVES) void k_integrate_tiles_w1(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
-                                                                         const float4* __restrict__ tile_bounds, WsCaps C) {
+                                                                         const uint32_t* __restrict__ pair_masks, WsCaps C) {
   extern __shared__ float4 s_dyn[];
   float4* const s_box = s_dyn;                   // the stream's texel box, later its y-lerped planes: ((z - mz) * 8 + y) * 8 + x
   float4* const s_row = s_dyn + C.box;           // its x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
@@ -619,18 +597,7 @@ __global__ __launch_bounds__(64, RR_K1W_WAVES) void k_integrate_tiles_w1(StreamT
       tsd[kz] = limit;                                                  // tsdf_integration.vs:28-29
       wsum[kz] = 0.0f;
     }
-    uint32_t pairs = 0;                                                 // (kRanges) 2 bits per stream: kPairFull / Carve / Neg / Nop
-    if (kRanges) {
-      const uint32_t st = stored_tile_index(V, tile);
-      for (int cb = 0; cb < T.n; cb += 2) {
-        const int i = cb + (ln >> 5);
-        const bool valid = i < T.n;
-        const size_t o = 2 * ((size_t)st * T.n + (valid ? i : 0));
-        const int pair = classify_pair_half(F.ranges, F.rcw, F.rch, F.w, F.h, i, valid, tile_bounds[o], tile_bounds[o + 1], limit);
-        pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 0) << (2 * cb);
-        if (cb + 1 < T.n) pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 32) << (2 * cb + 2);
-      }
-    }
+    const uint32_t pairs = kRanges ? pair_masks[w] : 0u;                // (kRanges) 2 bits per stream: kPairFull / Carve / Neg / Nop (k_pair_masks)
     const bool any_drawn = __ballot(drawn != 0u) != 0ull;
     for (int i = 0; i < T.n; ++i) {
       if (kRanges) {
@@ -734,7 +701,7 @@ __global__ __launch_bounds__(64, RR_K1W_WAVES) void k_integrate_tiles_w1(StreamT
 }
 
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, int ws_box, int ws_row, const float4* tile_bounds) {
+                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, int ws_box, int ws_row, const float4* tile_bounds, uint32_t* pair_masks) {
   const WsCaps wc{ws_box, ws_row};
   const size_t ws_lds = (size_t)(ws_box + ws_row) * sizeof(float4);
   // phase 1: tile classification + stale-tile clear; phase 2: the integrate kernel; 0: both (the split lets the caller time the kernel alone)
@@ -749,17 +716,22 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
       }
     }
     if (phase == 1) return;
+    const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
+    if (ranges) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, S, tile_bounds, pair_masks);
     const dim3 grid(S.n < 4096 ? S.n : 4096);
-    if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<true, false>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr, wc);
-    else if (lds_ok == 2 && F.ranges && tile_bounds) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, tile_bounds);
+    if (lds_ok == 3 && ranges) hipLaunchKernelGGL((k_integrate_tiles_w1<true, true>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, pair_masks, wc);
+    else if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<true, false>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr, wc);
+    else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, pair_masks);
     else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
   } else {
     if (phase == 1) return;
-    if (lds_ok == 3 && F.ranges && tile_bounds) hipLaunchKernelGGL((k_integrate_tiles_w1<false, true>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, tile_bounds, wc);
+    const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
+    if (ranges) hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, S, tile_bounds, pair_masks);
+    if (lds_ok == 3 && ranges) hipLaunchKernelGGL((k_integrate_tiles_w1<false, true>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, pair_masks, wc);
     else if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<false, false>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, nullptr, wc);
-    else if (lds_ok == 2 && F.ranges && tile_bounds) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds);
+    else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, pair_masks);
     else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);

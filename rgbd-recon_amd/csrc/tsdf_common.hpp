@@ -194,7 +194,8 @@ void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels
 struct PeelClear { uint4* peels; const uint8_t* touched_prev; int w, h, ntx, n_tiles; uint32_t* zero; uint32_t zero_words; };   // null pointers: nothing to do
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
                       int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr, int ws_box = 0, int ws_row = 0,
-                      const float4* tile_bounds = nullptr);   // per (stored tile, stream) 2 x float4 LUT-box bounds (launch_tile_bounds), or null
+                      const float4* tile_bounds = nullptr,   // per (stored tile, stream) 2 x float4 LUT-box bounds (launch_tile_bounds), or null
+                      uint32_t* pair_masks = nullptr);        // per work item: the frame's pair classes (written by the launch itself), or null
 void launch_tile_bounds(hipStream_t st, const StreamTable& T, const Volume& V, float4* bounds);
 int integrate_box_cap();
 int integrate_row_cap();
