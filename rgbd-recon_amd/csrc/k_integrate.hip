@@ -373,6 +373,14 @@ void launch_tile_bounds(hipStream_t st, const StreamTable& T, const Volume& V, f
 // (tile, stream) pairs two streams at a time and packs the classes, 2 bits per stream, into masks[work item]; the integrate kernels
 // read their item's word with one scalar load.  (Classifying in the integrate kernel's prologue put two dependent global round trips
 // in front of every tile's chain: c2 53.2 -> 51.8 us; as a pass of its own the shortcut is worth what it skips.)
+#ifdef RR_PAIR_STATS       // instrumented build (tools/pair_stats.py): [work items, pairs, uniform pairs, items with every pair uniform]
+__device__ unsigned long long g_pair_stats[4];
+extern "C" int32_t tsdf_debug_pair_stats(unsigned long long out[4], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stats), sizeof(g_pair_stats)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[4] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stats), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 template <bool kList>
 __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F, Volume V, TileState S, const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks) {
   const int ln = threadIdx.x & 63;
@@ -391,6 +399,14 @@ __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F
       if (cb + 1 < T.n) pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 32) << (2 * cb + 2);
     }
     if (ln == 0) masks[w] = pairs;
+#ifdef RR_PAIR_STATS
+    if (ln == 0) {
+      int u = 0;
+      for (int i = 0; i < T.n; ++i) u += ((pairs >> (2 * i)) & 3u) != 0u;
+      atomicAdd(&g_pair_stats[0], 1ull); atomicAdd(&g_pair_stats[1], (unsigned long long)T.n); atomicAdd(&g_pair_stats[2], (unsigned long long)u);
+      if (u == T.n) atomicAdd(&g_pair_stats[3], 1ull);
+    }
+#endif
   }
 }
 
