@@ -357,7 +357,7 @@ def main():
             step(drv, i)
         barrier()
         hip.enable_timers(False)
-        for name in ("0ingest", "1preprocess", "bricks", "2integrate", "k_integrate_tiles", "brickdraw", "draw", "k_march", "holefill", "3recon"):
+        for name in ("0ingest", "1preprocess", "bricks", "2integrate", "k_pair_masks", "k_integrate_tiles", "brickdraw", "draw", "k_march", "holefill", "3recon"):
             n, ms = hip.timer_stats(name)
             if n:
                 stages[name] = ms / n
@@ -513,6 +513,9 @@ def main():
             alg, note = db["integrate"], "dense launch: 4V + N*16*L + N*16*P (BASELINE.md section 3)"
         else:
             alg, note = db["march"], "dense march: 4V + 24R (BASELINE.md section 3); with depth limits the rays sample only inside occupied bricks, so this is an upper figure"
+        if dom == "k_integrate_tiles" and "k_pair_masks" in stages:
+            note += (f"; the launch reads its (tile, stream) pair classes from the pair-mask pass that runs right before it (k_pair_masks, {stages['k_pair_masks'] * 1e3:.1f} us, "
+                     "timed on its own: stage_ms)")
         out["roofline"] = roofline(dom, alg, dom_ms, args.config, note)
     if world > 1:
         # N > 1: the same object for the slowest slab launch (every rank that owns a slab measures its own; counters -- `traffic` -- were

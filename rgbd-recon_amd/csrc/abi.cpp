@@ -1069,7 +1069,6 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     c->spare_clean = true;
   }
   launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc, ws_box, ws_row);
-  timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
   // dense launches: the static half of the uniform-pair shortcut (k_integrate.hip), built once per calibration
   const float4* bounds = nullptr;
   const bool culled_ranges = c->use_bricks && c->culled_ranges && !c->vol.slot && (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 32 <= ((size_t)512 << 20);
@@ -1079,7 +1078,13 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     if (!c->tile_bounds_valid) { launch_tile_bounds(c->stream, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
     bounds = c->d_tile_bounds;
   }
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 2, nullptr, ws_box, ws_row, bounds, bounds ? c->d_pair_masks : nullptr);
+  if (bounds) {                                                        // this frame's (tile, stream) pair classes
+    timer_begin(c, "k_pair_masks");
+    launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 3, nullptr, ws_box, ws_row, bounds, c->d_pair_masks);
+    timer_end(c, "k_pair_masks");
+  }
+  timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 4, nullptr, ws_box, ws_row, bounds, bounds ? c->d_pair_masks : nullptr);
   timer_end(c, "k_integrate_tiles");
   if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
   else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them

@@ -303,31 +303,39 @@ __device__ __forceinline__ float half_min_f32(float v) {
   return (threadIdx.x & 32) ? hi : lo;
 }
 __device__ __forceinline__ float half_max_f32(float v) { return -half_min_f32(-v); }
-__device__ __forceinline__ int classify_pair_half(const float4* __restrict__ ranges, int rcw, int rch, int img_w, int img_h, int i, bool valid, float4 b0, float4 b1, float limit) {
+// in two steps, so that a caller can have the cell loads of several pairs in flight before the first reduction: (1) the texel rectangle of
+// the pair's bilinear footprints and this lane's range cell -- loaded unconditionally (index 0 for lanes outside the rectangle) --,
+// (2) the reductions and the class
+struct PairCell { float4 q; float z0, z1; bool ok, mine; };
+__device__ __forceinline__ PairCell pair_cell(const float4* __restrict__ ranges, int rcw, int rch, int img_w, int img_h, int i, bool valid, float4 b0, float4 b1) {
   const int r = threadIdx.x & 31;
-  const float inf = __builtin_inff();
-  const float u0 = b0.x, u1 = b0.y, v0 = b0.z, v1 = b0.w, z0 = b1.x, z1 = b1.y;
-  bool ok = valid && (u0 <= u1);                                       // NaN: the box holds something non-finite
+  const float u0 = b0.x, u1 = b0.y, v0 = b0.z, v1 = b0.w;
+  PairCell c;
+  c.z0 = b1.x; c.z1 = b1.y;
+  c.ok = valid && (u0 <= u1);                                          // NaN: the box holds something non-finite
   const float su = 1.0e-5f * (1.0f + fmaxf(fabsf(u0), fabsf(u1))), sv = 1.0e-5f * (1.0f + fmaxf(fabsf(v0), fabsf(v1)));
   const float wf = (float)img_w, hf = (float)img_h;
   const int x0 = (int)__builtin_amdgcn_fmed3f(floorf((u0 - su) * wf - 0.5f), 0.0f, wf - 1.0f), x1 = (int)__builtin_amdgcn_fmed3f(floorf((u1 + su) * wf - 0.5f) + 1.0f, 0.0f, wf - 1.0f);
   const int y0 = (int)__builtin_amdgcn_fmed3f(floorf((v0 - sv) * hf - 0.5f), 0.0f, hf - 1.0f), y1 = (int)__builtin_amdgcn_fmed3f(floorf((v1 + sv) * hf - 0.5f) + 1.0f, 0.0f, hf - 1.0f);
   const int cx0 = x0 >> 3, cy0 = y0 >> 3, cw = (x1 >> 3) - cx0 + 1, chh = (y1 >> 3) - cy0 + 1;
-  ok = ok && cw >= 1 && chh >= 1 && __mul24(cw, chh) <= 32;
-  float d0 = inf, d1 = -inf, s0 = inf, s1 = -inf;
-  if (ok && r < __mul24(cw, chh)) {
-    const int ry = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)cw));           // r / cw
-    const float4 q = ranges[(size_t)__mul24(__mul24(i, rch) + cy0 + ry, rcw) + (cx0 + r - __mul24(ry, cw))];
-    d0 = q.x; d1 = q.y; s0 = q.z; s1 = q.w;
-  }
+  c.ok = c.ok && cw >= 1 && chh >= 1 && __mul24(cw, chh) <= 32;
+  c.mine = c.ok && r < __mul24(cw, chh);
+  const int ry = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)cw));           // r / cw
+  const size_t idx = c.mine ? (size_t)__mul24(__mul24(i, rch) + cy0 + ry, rcw) + (cx0 + r - __mul24(ry, cw)) : 0;
+  c.q = ranges[idx];
+  return c;
+}
+__device__ __forceinline__ int pair_class(const PairCell& c, float limit) {
+  const float inf = __builtin_inff();
+  float d0 = c.mine ? c.q.x : inf, d1 = c.mine ? c.q.y : -inf, s0 = c.mine ? c.q.z : inf, s1 = c.mine ? c.q.w : -inf;
   d0 = half_min_f32(d0); d1 = half_max_f32(d1); s0 = half_min_f32(s0); s1 = half_max_f32(s1);
-  const float sz = 1.0e-5f * (1.0f + fmaxf(fabsf(z0), fabsf(z1)) + fmaxf(fabsf(d0), fabsf(d1)));
-  const bool all_le = (z1 + sz) - d0 <= -limit - sz, all_ge = (z0 - sz) - d1 >= limit + sz;
+  const float sz = 1.0e-5f * (1.0f + fmaxf(fabsf(c.z0), fabsf(c.z1)) + fmaxf(fabsf(d0), fabsf(d1)));   // lerp slack of z + the rounding of z - depth
+  const bool all_le = (c.z1 + sz) - d0 <= -limit - sz, all_ge = (c.z0 - sz) - d1 >= limit + sz;      // (false for NaN / infinite ranges)
   const bool sil0 = s0 == 0.0f && s1 == 0.0f, sil1 = s0 == 1.0f && s1 == 1.0f;
-  if (!ok) return kPairFull;
-  if (sil0 && all_ge) return kPairCarve;
-  if ((sil0 || sil1) && all_le) return kPairNeg;
-  if (sil1 && all_ge) return kPairNop;
+  if (!c.ok) return kPairFull;
+  if (sil0 && all_ge) return kPairCarve;                               // silhouette < 1: tsd >= limit -> -limit; otherwise sdist >= limit: nothing
+  if ((sil0 || sil1) && all_le) return kPairNeg;                       // carved by the silhouette rule or by sdist <= -limit: -limit either way
+  if (sil1 && all_ge) return kPairNop;                                 // behind the surface: nothing
   return kPairFull;
 }
 // the static half: one wave per (stored tile, stream) reduces min / max of (u, v, z) over the tile's LUT texel box
@@ -390,13 +398,24 @@ __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F
     const int tile = work_tile<kList>(S, w);
     const uint32_t st = stored_tile_index(V, tile);
     uint32_t pairs = 0;
-    for (int cb = 0; cb < T.n; cb += 2) {
-      const int i = cb + (ln >> 5);
-      const bool valid = i < T.n;
-      const size_t o = 2 * ((size_t)st * T.n + (valid ? i : 0));
-      const int pair = classify_pair_half(F.ranges, F.rcw, F.rch, F.w, F.h, i, valid, tile_bounds[o], tile_bounds[o + 1], V.limit);
-      pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 0) << (2 * cb);
-      if (cb + 1 < T.n) pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 32) << (2 * cb + 2);
+    for (int cb = 0; cb < T.n; cb += 4) {                               // four streams per round: the two half-wave pairs' loads in flight together
+      PairCell c[2];
+      float4 b0[2], b1[2];
+      int si[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        si[u] = cb + 2 * u + (ln >> 5);
+        const size_t o = 2 * ((size_t)st * T.n + (si[u] < T.n ? si[u] : 0));
+        b0[u] = tile_bounds[o]; b1[u] = tile_bounds[o + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) c[u] = pair_cell(F.ranges, F.rcw, F.rch, F.w, F.h, si[u], si[u] < T.n, b0[u], b1[u]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pair = pair_class(c[u], V.limit), s0 = cb + 2 * u;
+        if (s0 < T.n) pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 0) << (2 * s0);
+        if (s0 + 1 < T.n) pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 32) << (2 * s0 + 2);
+      }
     }
     if (ln == 0) masks[w] = pairs;
 #ifdef RR_PAIR_STATS
@@ -720,9 +739,10 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
                       int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, int ws_box, int ws_row, const float4* tile_bounds, uint32_t* pair_masks) {
   const WsCaps wc{ws_box, ws_row};
   const size_t ws_lds = (size_t)(ws_box + ws_row) * sizeof(float4);
-  // phase 1: tile classification + stale-tile clear; phase 2: the integrate kernel; 0: both (the split lets the caller time the kernel alone)
+  // phase 1: tile classification + stale-tile clear; 2: pair-mask pass + integrate kernel; 3: the pair-mask pass alone; 4: the integrate
+  // kernel alone; 0: everything (the split lets the caller time the kernels separately)
   if (use_bricks) {
-    if (phase != 2) {
+    if (phase < 2) {
       if (full_classify) hipLaunchKernelGGL(k_classify_clear_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
       else {
         PeelClear none{};
@@ -733,7 +753,8 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     }
     if (phase == 1) return;
     const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
-    if (ranges) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, S, tile_bounds, pair_masks);
+    if (ranges && phase != 4) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, S, tile_bounds, pair_masks);
+    if (phase == 3) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
     if (lds_ok == 3 && ranges) hipLaunchKernelGGL((k_integrate_tiles_w1<true, true>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, pair_masks, wc);
     else if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<true, false>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr, wc);
@@ -744,7 +765,8 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
   } else {
     if (phase == 1) return;
     const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
-    if (ranges) hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, S, tile_bounds, pair_masks);
+    if (ranges && phase != 4) hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, S, tile_bounds, pair_masks);
+    if (phase == 3) return;
     if (lds_ok == 3 && ranges) hipLaunchKernelGGL((k_integrate_tiles_w1<false, true>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, pair_masks, wc);
     else if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<false, false>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, nullptr, wc);
     else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, pair_masks);
