@@ -46,6 +46,7 @@ struct tsdf_ctx {
   uint8_t* d_vox_count[3]{};
   uint16_t* d_tile_b0[3]{};
   uint16_t* d_tile_b1[3]{};
+  uint8_t* d_tile_full[3]{};
   uint16_t* d_brick_t0[3]{};
   uint16_t* d_brick_t1[3]{};
   // active-tile lists of this and the previous integrate() (k_classify_lists), their two device counts, and what decides
@@ -185,7 +186,7 @@ void release_bricks(tsdf_ctx* c) {
   c->d_counters[0] = c->d_counters[1] = nullptr;
   c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr;
   for (int a = 0; a < 3; ++a) {
-    hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); hipFree(c->d_tile_b0[a]); hipFree(c->d_tile_b1[a]);
+    hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); hipFree(c->d_tile_b0[a]); hipFree(c->d_tile_b1[a]); hipFree(c->d_tile_full[a]); c->d_tile_full[a] = nullptr;
     hipFree(c->d_brick_t0[a]); hipFree(c->d_brick_t1[a]);
     c->d_vox_first[a] = nullptr; c->d_vox_count[a] = nullptr; c->d_tile_b0[a] = nullptr; c->d_tile_b1[a] = nullptr;
     c->d_brick_t0[a] = nullptr; c->d_brick_t1[a] = nullptr;
@@ -301,6 +302,12 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
     HIP_TRY(c, hipMemcpy(c->d_tile_b1[a], t1.data(), nt * sizeof(uint16_t), hipMemcpyHostToDevice));
     B.tile_b0[a] = c->d_tile_b0[a];
     B.tile_b1[a] = c->d_tile_b1[a];
+    std::vector<uint8_t> full(nt, 1);
+    for (int t = 0; t < nt; ++t)
+      for (int v = t * 8; v < std::min(t * 8 + 8, c->res[a]); ++v) if (!count[a][v]) full[t] = 0;
+    HIP_TRY(c, hipMalloc(&c->d_tile_full[a], nt));
+    HIP_TRY(c, hipMemcpy(c->d_tile_full[a], full.data(), nt, hipMemcpyHostToDevice));
+    B.tile_full[a] = c->d_tile_full[a];
     // and the inverse: the storage tiles a brick's voxel list reaches into
     const int nb = (int)starts[a].size();
     std::vector<uint16_t> bt0(nb, 1), bt1(nb, 0);

@@ -390,7 +390,8 @@ extern "C" int32_t tsdf_debug_pair_stats(unsigned long long out[4], int reset) {
 }
 #endif
 template <bool kList>
-__global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F, Volume V, TileState S, const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks) {
+__global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
+                                                    const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks) {
   const int ln = threadIdx.x & 63;
   const int n_work = kList ? (int)*S.count : S.n;
   const int n_waves = gridDim.x * 4;
@@ -417,11 +418,34 @@ __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F
         if (s0 + 1 < T.n) pairs |= (uint32_t)__builtin_amdgcn_readlane(pair, 32) << (2 * s0 + 2);
       }
     }
+    // bit 31: where bricks and tiles do not coincide the integrate kernel asks per voxel "is it in the list of an occupied brick" (two
+    // dependent global round trips at the head of the tile's chain, 7 of c2's 51 us).  When every voxel coordinate of the tile is listed
+    // and EVERY brick that reaches into the tile is occupied -- the usual case away from the rim of the occupied set -- the answer is yes
+    // for the whole tile, and this pass can say so: one flag per lane of the tile's (at most 64) bricks
+    if (per_voxel_check) {
+      int t3[3];
+      tile_coords(V, tile, t3[0], t3[1], t3[2]);
+      const int b0x = B.tile_b0[0][t3[0]], nbx = (int)B.tile_b1[0][t3[0]] - b0x + 1, b0y = B.tile_b0[1][t3[1]], nby = (int)B.tile_b1[1][t3[1]] - b0y + 1;
+      const int b0z = B.tile_b0[2][t3[2]], nbz = (int)B.tile_b1[2][t3[2]] - b0z + 1;
+      const bool listed = B.tile_full[0][t3[0]] && B.tile_full[1][t3[1]] && B.tile_full[2][t3[2]];
+      const int nb = (nbx > 0 && nby > 0 && nbz > 0) ? __mul24(__mul24(nbx, nby), nbz) : 0;
+      bool all = listed && nb > 0 && nb <= 64;
+      if (all) {                                                        // (wave-uniform)
+        bool occ = true;
+        if (ln < nb) {
+          const int bz = ln / __mul24(nbx, nby), rem = ln - __mul24(bz, __mul24(nbx, nby)), by = rem / nbx, bx = rem - __mul24(by, nbx);
+          occ = B.flags[((size_t)(b0z + bz) * B.res[1] + (b0y + by)) * B.res[0] + (b0x + bx)] != 0;
+        }
+        all = __ballot(!occ) == 0ull;
+      }
+      if (all && T.n <= 15) pairs |= 0x80000000u;                       // (16 streams use all 32 bits for their classes)
+    }
     if (ln == 0) masks[w] = pairs;
 #ifdef RR_PAIR_STATS
     if (ln == 0) {
       int u = 0;
       for (int i = 0; i < T.n; ++i) u += ((pairs >> (2 * i)) & 3u) != 0u;
+      if (pairs >> 31) atomicAdd(&g_pair_stats[3], 1ull << 32);       // (high half of [3]: tiles whose bricks are all occupied)
       atomicAdd(&g_pair_stats[0], 1ull); atomicAdd(&g_pair_stats[1], (unsigned long long)T.n); atomicAdd(&g_pair_stats[2], (unsigned long long)u);
       if (u == T.n) atomicAdd(&g_pair_stats[3], 1ull);
     }
@@ -462,16 +486,17 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
     bool drawn[kVox];
     float tsd[kVox], wsum[kVox];
+    const uint32_t pairs = kRanges ? pair_masks[w] : 0u;                // (kRanges) from k_pair_masks: 2 bits per stream -- which streams treat every voxel of this tile alike --, bit 31: every brick reaching into the tile is occupied
+    const bool check_voxels = per_voxel_check && !(kRanges && T.n <= 15 && (pairs >> 31));
 #pragma unroll
     for (int h = 0; h < kVox; ++h) {
       const int z = t3[2] * 8 + lz + 4 * h;
       drawn[h] = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
-      if (drawn[h] && per_voxel_check) drawn[h] = voxel_drawn(B, x, y, z);
+      if (drawn[h] && check_voxels) drawn[h] = voxel_drawn(B, x, y, z);
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
       wsum[h] = 0.0f;
     }
-    // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)
-    const uint32_t pairs = kRanges ? pair_masks[w] : 0u;                // (kRanges) 2 bits per stream, from k_pair_masks: which streams treat every voxel of this tile alike
+    // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)                // (kRanges) 2 bits per stream, from k_pair_masks: which streams treat every voxel of this tile alike
     for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
       const int i = t / 24, a = (t % 24) >> 3, k = t & 7;
       const int coord = min(t3[a] * 8 + k, V.res[a] - 1);               // padding voxels reuse the last real coordinate
@@ -753,7 +778,7 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     }
     if (phase == 1) return;
     const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
-    if (ranges && phase != 4) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, S, tile_bounds, pair_masks);
+    if (ranges && phase != 4) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, tile_bounds, pair_masks);
     if (phase == 3) return;
     const dim3 grid(S.n < 4096 ? S.n : 4096);
     if (lds_ok == 3 && ranges) hipLaunchKernelGGL((k_integrate_tiles_w1<true, true>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, pair_masks, wc);
@@ -765,7 +790,7 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
   } else {
     if (phase == 1) return;
     const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
-    if (ranges && phase != 4) hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, S, tile_bounds, pair_masks);
+    if (ranges && phase != 4) hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds, pair_masks);
     if (phase == 3) return;
     if (lds_ok == 3 && ranges) hipLaunchKernelGGL((k_integrate_tiles_w1<false, true>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, pair_masks, wc);
     else if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<false, false>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, nullptr, wc);

@@ -91,6 +91,7 @@ struct Bricks {
   const uint8_t* vox_count[3];
   const uint16_t* tile_b0[3];   // per storage tile index along an axis: first / last brick whose voxel list reaches into it
   const uint16_t* tile_b1[3];   // (b0 > b1: none)
+  const uint8_t* tile_full[3];  // per storage tile index along an axis: 1 = every voxel coordinate of the tile is in at least one brick's list
   const uint16_t* brick_t0[3];  // the inverse: per brick index along an axis, first / last storage tile its voxel list reaches into
   const uint16_t* brick_t1[3];  // (t0 > t1: the brick holds no voxel)
   int res[3];               // brick grid
