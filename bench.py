@@ -331,6 +331,7 @@ def main():
 
     # host -> device frame upload, outside the timed region (value = HBM-resident rate); reported for the PCIe-inclusive figure
     hip.sync()
+    hip.select_frame_slot(0)        # scene A's slot (the slab check above leaves the LAST slot current: uploading A there would overwrite frame B)
     tu0 = time.perf_counter()
     for _ in range(5):
         hip.upload_frame(scene)

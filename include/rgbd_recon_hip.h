@@ -66,7 +66,14 @@ typedef struct tsdf_config {
    * possible (4096^3 = 256 GiB dense).  Needs brick culling (setUseBricks(true)); with a slab, slab_recompute_halo = 1.
    * A frame that needs more tiles than the pool holds drops the excess (they read -limit): tsdf_sparse_pool_stats. 0: dense. */
   uint32_t sparse_pool_tiles;
+  /* Projection cache (dense storage, culled or dense integrate): texture(cv_xyz_inv[i], voxel centre).xyz of tsdf_integration.vs:31
+   * depends on the calibration and the voxel grid only, so the integrate kernel keeps it in HBM per 8^3-voxel tile once the tile has
+   * been integrated (N x 6 KiB per tile, dealt on first use) and from then on reads it back instead of re-filtering the LUT.
+   * Budget in MiB: 0 = default (8192, or RR_PROJ_CACHE_MB), TSDF_PROJ_CACHE_OFF = never.  Tiles beyond the budget keep the LUT path.
+   * Results are bit-identical either way. */
+  uint32_t proj_cache_mib;
 } tsdf_config;
+#define TSDF_PROJ_CACHE_OFF 0xffffffffu
 
 /* ---- lifetime / errors ------------------------------------------------------------------------- */
 int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out);
@@ -74,6 +81,11 @@ int32_t tsdf_destroy(tsdf_ctx* ctx);
 const char* tsdf_last_error(const tsdf_ctx* ctx);   /* ctx may be NULL: error of the last failed tsdf_create */
 /* sparse contexts: tiles the last integrate() needed / pool capacity (synchronises the stream) */
 int32_t tsdf_sparse_pool_stats(tsdf_ctx* ctx, uint32_t* tiles_needed, uint32_t* pool_tiles);
+/* what the last integrate() launch was made of (synchronises the stream; measurement only): out[0] work items (8^3-voxel tiles),
+ * out[1] of them served from the projection cache, out[2] (tile, stream) pairs of those evaluated per voxel (6 KiB of cached
+ * coordinates read each), out[3] tiles taken by the LUT kernel, out[4] cache slots in use, out[5] cache capacity in slots.
+ * All zero when the context does not use the cache. */
+int32_t tsdf_integrate_stats(tsdf_ctx* ctx, uint32_t out[6]);
 int32_t tsdf_set_stream(tsdf_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL: back to own) */
 /* adopt the process's NULL ("legacy default") stream, whose handle is 0 and therefore cannot be passed to tsdf_set_stream:
  * torch.cuda.default_stream().cuda_stream is 0, so this is how a context is ordered with work issued on torch's default

@@ -34,7 +34,7 @@ class TsdfConfig(C.Structure):
                 ("limit", C.c_float), ("num_streams", C.c_uint32), ("depth_w", C.c_uint32), ("depth_h", C.c_uint32),
                 ("color_w", C.c_uint32), ("color_h", C.c_uint32), ("view_w", C.c_uint32), ("view_h", C.c_uint32),
                 ("device", C.c_int32), ("slab_z0", C.c_uint32), ("slab_z1", C.c_uint32), ("slab_recompute_halo", C.c_uint32),
-                ("sparse_pool_tiles", C.c_uint32)]
+                ("sparse_pool_tiles", C.c_uint32), ("proj_cache_mib", C.c_uint32)]
 
 
 def build_library():
@@ -179,7 +179,7 @@ class ReconIntegrationHip:
     NetKinectArray hold in the reference (rgbd-recon_amd/scene.py layout)."""
 
     def __init__(self, scene, res=None, voxel_size=0.01, brick_size=0.1, limit=0.01, view=(1280, 720),
-                 device=0, slab=(0, 0), upload=True, recompute_halo=False, sparse_pool_tiles=0):
+                 device=0, slab=(0, 0), upload=True, recompute_halo=False, sparse_pool_tiles=0, proj_cache_mib=0):
         self._L = load_library()
         self._c = None
         cfg = TsdfConfig()
@@ -198,6 +198,7 @@ class ReconIntegrationHip:
         cfg.slab_z0, cfg.slab_z1 = slab
         cfg.slab_recompute_halo = int(bool(recompute_halo))
         cfg.sparse_pool_tiles = int(sparse_pool_tiles)
+        cfg.proj_cache_mib = 0xffffffff if proj_cache_mib is None else int(proj_cache_mib)   # 0: default budget, None: off
         ctx = C.c_void_p()
         rc = self._L.tsdf_create(C.byref(cfg), C.byref(ctx))
         if rc != 0:
@@ -482,6 +483,13 @@ class ReconIntegrationHip:
         need, cap = C.c_uint32(), C.c_uint32()
         self._ck(self._L.tsdf_sparse_pool_stats(self._c, C.byref(need), C.byref(cap)))
         return need.value, cap.value
+
+    def integrate_stats(self):
+        """dict of the last integrate() launch: work items (tiles), tiles served from the projection cache, (tile, stream) pairs of those
+        evaluated per voxel, tiles taken by the LUT kernel, cache slots in use / capacity (all 0 without the cache)"""
+        out = (C.c_uint32 * 6)()
+        self._ck(self._L.tsdf_integrate_stats(self._c, out))
+        return dict(zip(("items", "cached", "full_pairs", "lut_items", "slots_used", "slots"), [int(v) for v in out]))
 
     def timer_reserve(self, name, n): self._ck(self._L.tsdf_timer_reserve(self._c, name.encode(), int(n)))
 

@@ -66,8 +66,11 @@ struct tsdf_ctx {
   // the stream's per-tile LUT box against the integrate kernel's LDS budget: 0 = does not fit (global-memory kernel), 1 = the box fits
   // (direct 8-tap form), 2 = the separable passes' rows and planes fit as well (the fastest form)
   int lds_ok[TSDF_MAX_STREAMS]{};
-  int k1_form_cap = 2;           // RR_K1_FORM: 2 = separable form (default), 1 = direct 8-tap form, 0 = global-memory kernel, 3 = one wave per tile (separable passes, no workgroup barrier)
-  int ws_box[TSDF_MAX_STREAMS]{}, ws_row[TSDF_MAX_STREAMS]{};   // per stream: LDS float4 of the one-wave-per-tile form for the worst tile box
+  int k1_form_cap = 3;           // RR_K1_FORM: 3 = projection cache over the separable form (default), 2 = separable LDS form, 1 = direct 8-tap form, 0 = global-memory kernel
+  // projection cache (ProjCache, tsdf_common.hpp): pool + slot table allocated by the first integrate() that can use it, dropped with
+  // the volume, invalidated by tsdf_set_calibration
+  ProjCache proj{}; uint32_t* d_proj_words = nullptr; int proj_parity = 0; size_t proj_budget = 0; bool proj_failed = false; uint32_t* d_item_stats = nullptr;
+  bool last_integrate_cached = false;
   FrameImages frame{};           // the CURRENT frame slot's images (what mark / integrate / draw read)
   // Two frame slots (the reference's double PBO + texture arrays, NetKinectArray.cpp:225-236): while the path computes on slot
   // `cur_slot`, tsdf_upload_frame_async fills the other one on a copy stream; tsdf_select_frame_slot makes it current.
@@ -457,8 +460,11 @@ RayTarget ray_target(tsdf_ctx* c) {
 // setVoxelSize()'s device side, recon_integration.cpp:340-348: the volume for the current c->res (tile-major storage, slot table of a
 // sparse pool, per-tile state and work lists).  Called by tsdf_create and tsdf_set_voxel_size; everything it allocates is released first.
 void release_volume(tsdf_ctx* c) {
-   hipFree(c->tiles.stamp); hipFree(c->d_cls_all);
+  hipFree(c->vol.data); hipFree(c->vol.slot);                          // (both callers have synchronised the stream)
+  hipFree(c->tiles.stamp); hipFree(c->d_cls_all);
   hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts); hipFree(c->d_linear); hipFree(c->d_tile_bounds); hipFree(c->d_pair_masks); c->d_pair_masks = nullptr;
+  hipFree(c->proj.data); hipFree(c->proj.slot); hipFree(c->proj.items); hipFree(c->d_proj_words); hipFree(c->d_item_stats);
+  c->proj = ProjCache{}; c->d_proj_words = nullptr; c->d_item_stats = nullptr; c->proj_failed = false; c->last_integrate_cached = false;
   c->vol.data = nullptr; c->vol.slot = nullptr; c->tiles.stamp = nullptr; c->d_cls_all = nullptr;
   c->d_tile_list[0] = c->d_tile_list[1] = nullptr; c->d_tile_counts = nullptr; c->d_linear = nullptr; c->d_tile_bounds = nullptr;
   c->tile_bounds_valid = false; c->tile_parity = 0; c->full_classify = true; c->frame_stamp = 0;
@@ -536,8 +542,6 @@ void fit_lut_to_volume(tsdf_ctx* c, uint32_t i) {
     auto idx1 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k + 1, 0), n - 1); };
     for (int t = 0; t * 8 < c->res[a]; ++t) worst[a] = std::max(worst[a], idx1(std::min(t * 8 + 7, c->res[a] - 1)) - idx0(t * 8) + 1);
   }
-  c->ws_box[i] = std::max(worst[0] * worst[1] * worst[2], worst[2] * 64);
-  c->ws_row[i] = worst[1] * worst[2] * 8;
   c->lds_ok[i] = worst[0] * worst[1] * worst[2] > integrate_box_cap() ? 0 : ((worst[1] * worst[2] * 8 <= integrate_row_cap() && worst[2] * 64 <= integrate_box_cap()) ? 2 : 1);
 }
 
@@ -552,7 +556,9 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   *out = nullptr;
   // struct_size lets the struct grow: a caller built against the layout that ended at slab_recompute_halo is still accepted
   tsdf_config grown{};
-  if (cfg->struct_size == offsetof(tsdf_config, sparse_pool_tiles)) { memcpy(&grown, cfg, cfg->struct_size); grown.struct_size = sizeof(tsdf_config); cfg = &grown; }
+  if (cfg->struct_size == offsetof(tsdf_config, sparse_pool_tiles) || cfg->struct_size == offsetof(tsdf_config, proj_cache_mib)) {
+    memcpy(&grown, cfg, cfg->struct_size); grown.struct_size = sizeof(tsdf_config); cfg = &grown;
+  }
   if (cfg->struct_size != sizeof(tsdf_config)) { g_create_error = "tsdf_config.struct_size mismatch"; return TSDF_ERR_INVALID_ARGUMENT; }
   if (cfg->num_streams < 1 || cfg->num_streams > TSDF_MAX_STREAMS) { g_create_error = "num_streams out of range"; return TSDF_ERR_INVALID_ARGUMENT; }
   if (!(cfg->limit > 0.0f)) { g_create_error = "limit must be > 0"; return TSDF_ERR_INVALID_ARGUMENT; }
@@ -572,6 +578,11 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   c->stream = c->own_stream;
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
+  {
+    uint64_t mib = cfg->proj_cache_mib == 0 ? 8192 : cfg->proj_cache_mib;
+    if (cfg->proj_cache_mib == 0) if (const char* e = getenv("RR_PROJ_CACHE_MB")) mib = (uint64_t)atoll(e);
+    c->proj_budget = cfg->proj_cache_mib == TSDF_PROJ_CACHE_OFF ? 0 : (size_t)(mib << 20);
+  }
   if (const char* e = getenv("RR_K1_CULLED_RANGES")) c->culled_ranges = atoi(e) != 0;
   // setVoxelSize(), :340-347
   for (int a = 0; a < 3; ++a) {
@@ -649,6 +660,23 @@ int32_t tsdf_sparse_pool_stats(tsdf_ctx* c, uint32_t* need, uint32_t* cap) {
   if (cap) *cap = c->vol.pool_tiles;
   return TSDF_OK;
 }
+int32_t tsdf_integrate_stats(tsdf_ctx* c, uint32_t out[6]) {
+  CHECK_CTX(c);
+  if (!out) return TSDF_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < 6; ++k) out[k] = 0;
+  if (!c->last_integrate_cached || !c->proj.data) return TSDF_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->d_item_stats) HIP_TRY(c, hipMalloc((void**)&c->d_item_stats, 4 * sizeof(uint32_t)));
+  // (the tile list of the last integrate: tsdf_integrate has already flipped the parity)
+  TileState S = c->tiles;
+  if (c->use_bricks) { const int p = c->tile_parity ^ 1; S.list = c->d_tile_list[p]; S.count = c->d_tile_counts + p; }
+  launch_item_stats(c->stream, c->luts, S, c->use_bricks ? 1 : 0, c->d_pair_masks, c->proj, c->d_item_stats);
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_item_stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out + 4, c->proj.alloc, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out[4] = std::min(out[4], c->proj.cap); out[5] = c->proj.cap;
+  return TSDF_OK;
+}
 int32_t tsdf_set_stream(tsdf_ctx* c, void* s) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -687,27 +715,36 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
   // re-calibration of a stream: queued kernels may still read the old volumes; wait, then free what this call replaces
   if (c->have_calib[i]) HIP_TRY(c, hipStreamSynchronize(c->stream));
   auto replace = [&](int slot, void* fresh) { if (c->lut_alloc[i][slot]) hipFree(c->lut_alloc[i][slot]); c->lut_alloc[i][slot] = fresh; };
-  float4* d_inv = nullptr;
-  HIP_TRY(c, hipMalloc(&d_inv, vol_n(ri) * sizeof(float4)));
-  replace(0, d_inv);
-  HIP_TRY(c, hipMemcpy(d_inv, inv, vol_n(ri) * sizeof(float4), hipMemcpyHostToDevice));
-  L.inv = d_inv; for (int a = 0; a < 3; ++a) L.inv_res[a] = (int)ri[a];
+  // allocate, copy, and only then swap: a failed copy must leave the stream's old volume (and L.*) in place, never a freed pointer
+  auto upload = [&](void** fresh, const void* src, size_t bytes) -> int32_t {
+    *fresh = nullptr;
+    HIP_TRY(c, hipMalloc(fresh, bytes));
+    const hipError_t e = hipMemcpy(*fresh, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(*fresh); *fresh = nullptr; FAIL(c, TSDF_ERR_HIP, "hipMemcpy(calibration volume) failed: %s", hipGetErrorString(e)); }
+    return TSDF_OK;
+  };
+  void* fresh = nullptr;
+  if (int32_t rc = upload(&fresh, inv, vol_n(ri) * sizeof(float4))) return rc;
+  replace(0, fresh);
+  L.inv = (const float4*)fresh; for (int a = 0; a < 3; ++a) L.inv_res[a] = (int)ri[a];
+  fit_lut_to_volume(c, i);
+  c->tile_bounds_valid = false;                                          // the tiles' LUT-box bounds and cached projections belong to the old volume
+  if (c->proj.slot) {
+    HIP_TRY(c, hipMemsetAsync(c->proj.slot, 0xff, (size_t)c->vol.n_stored_tiles * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_proj_words, 0, 4 * sizeof(uint32_t), c->stream));
+  }
   if (uv) {
-    float2* d = nullptr;
-    HIP_TRY(c, hipMalloc(&d, vol_n(ru) * sizeof(float2)));
-    replace(1, d);
-    HIP_TRY(c, hipMemcpy(d, uv, vol_n(ru) * sizeof(float2), hipMemcpyHostToDevice));
-    L.uv = d; for (int a = 0; a < 3; ++a) L.uv_res[a] = (int)ru[a];
+    if (int32_t rc = upload(&fresh, uv, vol_n(ru) * sizeof(float2))) return rc;
+    replace(1, fresh);
+    L.uv = (const float2*)fresh; for (int a = 0; a < 3; ++a) L.uv_res[a] = (int)ru[a];
   }
   if (xyz) {
     const size_t n = vol_n(rx);
     std::vector<float> padded(n * 4);
     for (size_t k = 0; k < n; ++k) { padded[4 * k] = xyz[3 * k]; padded[4 * k + 1] = xyz[3 * k + 1]; padded[4 * k + 2] = xyz[3 * k + 2]; padded[4 * k + 3] = 0.0f; }
-    float4* d = nullptr;
-    HIP_TRY(c, hipMalloc(&d, n * sizeof(float4)));
-    replace(2, d);
-    HIP_TRY(c, hipMemcpy(d, padded.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-    L.xyz = d; for (int a = 0; a < 3; ++a) L.xyz_res[a] = (int)rx[a];
+    if (int32_t rc = upload(&fresh, padded.data(), n * sizeof(float4))) return rc;
+    replace(2, fresh);
+    L.xyz = (const float4*)fresh; for (int a = 0; a < 3; ++a) L.xyz_res[a] = (int)rx[a];
     // CalibVolumes::addVolume builds the sensor's frustum from this volume (CalibVolumes.cpp:122) and getCameraPositions()
     // (:224-230) feeds the quality pass: default camera position, until tsdf_set_camera_position overrides it
     float cam[3];
@@ -716,9 +753,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
       c->have_cam[i] = true;
     }
   }
-  fit_lut_to_volume(c, i);
   c->have_calib[i] = true;
-  c->tile_bounds_valid = false;                                          // the tiles' LUT-box bounds belong to the old volumes
   return TSDF_OK;
 }
 
@@ -1047,11 +1082,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   timer_begin(c, "2integrate");
   int lds = 2;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = std::min(lds, c->lds_ok[i]);
-  // the one-wave-per-tile form needs the separable form's preconditions and (box + rows) float4 of dynamic LDS per wave: within 24 KiB
-  // (at least six waves per CU)
-  int ws_box = 0, ws_row = 0;
-  for (uint32_t i = 0; i < c->cfg.num_streams; ++i) { ws_box = std::max(ws_box, c->ws_box[i]); ws_row = std::max(ws_row, c->ws_row[i]); }
-  if (lds == 2 && (size_t)(ws_box + ws_row) * 16 <= 24 * 1024) lds = 3;
+  const bool want_cache = lds == 2 && c->k1_form_cap >= 3 && c->proj_budget > 0 && !c->vol.slot && !c->proj_failed;
   lds = std::min(lds, c->k1_form_cap);
   if (c->use_bricks) {
     // this frame's list / count, the previous integrate()'s (trusted unless something else may have written the volume)
@@ -1075,7 +1106,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     pc.zero = c->d_counters[c->counters_cur ^ 1]; pc.zero_words = (uint32_t)c->counter_words;
     c->spare_clean = true;
   }
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc, ws_box, ws_row);
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
   // dense launches: the static half of the uniform-pair shortcut (k_integrate.hip), built once per calibration
   const float4* bounds = nullptr;
   const bool culled_ranges = c->use_bricks && c->culled_ranges && !c->vol.slot && (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 32 <= ((size_t)512 << 20);
@@ -1085,13 +1116,43 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     if (!c->tile_bounds_valid) { launch_tile_bounds(c->stream, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
     bounds = c->d_tile_bounds;
   }
-  if (bounds) {                                                        // this frame's (tile, stream) pair classes
+  // projection cache: the pool and its tables, on the first integrate() that can use them.  Capacity = the budget, at most one slot per
+  // stored tile; a failed allocation (another context holds the memory) just leaves this context on the LUT path
+  const ProjCache* proj = nullptr;
+  if (bounds && want_cache) {
+    if (!c->proj.data) {
+      const size_t slot_bytes = (size_t)c->cfg.num_streams * TILE_VOX * 3 * sizeof(float);
+      const size_t cap = std::min<size_t>((size_t)c->vol.n_stored_tiles, c->proj_budget / slot_bytes);
+      bool ok = cap > 0;
+      ok = ok && hipMalloc((void**)&c->proj.slot, (size_t)c->vol.n_stored_tiles * sizeof(uint32_t)) == hipSuccess;
+      ok = ok && hipMalloc((void**)&c->proj.items, (size_t)c->tiles.n * sizeof(uint32_t)) == hipSuccess;
+      ok = ok && hipMalloc((void**)&c->d_proj_words, 4 * sizeof(uint32_t)) == hipSuccess;
+      ok = ok && hipMalloc((void**)&c->proj.data, cap * slot_bytes) == hipSuccess;
+      if (!ok) {
+        (void)hipGetLastError();
+        hipFree(c->proj.slot); hipFree(c->proj.items); hipFree(c->d_proj_words); hipFree(c->proj.data);
+        c->proj = ProjCache{}; c->d_proj_words = nullptr; c->proj_failed = true;
+      } else {
+        HIP_TRY(c, hipMemsetAsync(c->proj.slot, 0xff, (size_t)c->vol.n_stored_tiles * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_proj_words, 0, 4 * sizeof(uint32_t), c->stream));
+        c->proj.cap = (uint32_t)cap; c->proj.slot_floats = (uint32_t)(slot_bytes / sizeof(float)); c->proj.alloc = c->d_proj_words;
+        c->proj_parity = 0;
+      }
+    }
+    if (c->proj.data) {
+      c->proj.n_slow = c->d_proj_words + 1 + c->proj_parity; c->proj.n_slow_next = c->d_proj_words + 1 + (c->proj_parity ^ 1);
+      c->proj_parity ^= 1;
+      proj = &c->proj;
+    }
+  }
+  c->last_integrate_cached = proj != nullptr;
+  if (bounds) {                                                        // this frame's (tile, stream) pair classes (+ which work items are cached)
     timer_begin(c, "k_pair_masks");
-    launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 3, nullptr, ws_box, ws_row, bounds, c->d_pair_masks);
+    launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 3, nullptr, bounds, c->d_pair_masks, proj);
     timer_end(c, "k_pair_masks");
   }
-  timer_begin(c, "k_integrate_tiles");                                // the kernel alone (bench.py's roofline)
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 4, nullptr, ws_box, ws_row, bounds, bounds ? c->d_pair_masks : nullptr);
+  timer_begin(c, "k_integrate_tiles");                                // the kernel(s) alone (bench.py's roofline)
+  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 4, nullptr, bounds, bounds ? c->d_pair_masks : nullptr, proj);
   timer_end(c, "k_integrate_tiles");
   if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
   else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them

@@ -391,10 +391,11 @@ extern "C" int32_t tsdf_debug_pair_stats(unsigned long long out[4], int reset) {
 #endif
 template <bool kList>
 __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
-                                                    const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks) {
+                                                    const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks, ProjCache PC) {
   const int ln = threadIdx.x & 63;
   const int n_work = kList ? (int)*S.count : S.n;
   const int n_waves = gridDim.x * 4;
+  if (PC.items && blockIdx.x == 0 && threadIdx.x == 0) *PC.n_slow_next = 0u;   // (last read by the LDS kernel of the previous frame)
   for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n_work; w += n_waves) {
     const int tile = work_tile<kList>(S, w);
     const uint32_t st = stored_tile_index(V, tile);
@@ -441,6 +442,20 @@ __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F
       if (all && T.n <= 15) pairs |= 0x80000000u;                       // (16 streams use all 32 bits for their classes)
     }
     if (ln == 0) masks[w] = pairs;
+    // projection cache: is the tile's (u, v, z) table in the pool?  No: deal it a slot (the LDS kernel fills it while it integrates the
+    // tile, this frame) -- or, pool exhausted, leave the tile to the LDS kernel for good
+    if (PC.items && ln == 0) {
+      uint32_t it = PC.slot[st];
+      if (it == kNoSlot) {
+        it = kItemNone;
+        if (*(volatile uint32_t*)PC.alloc < PC.cap) {                    // (saturating: an exhausted pool costs no atomic per tile and frame)
+          const uint32_t a = atomicAdd(PC.alloc, 1u);
+          if (a < PC.cap) { PC.slot[st] = a; it = kItemFresh | a; }
+        }
+        atomicAdd(PC.n_slow, 1u);
+      }
+      PC.items[w] = it;
+    }
 #ifdef RR_PAIR_STATS
     if (ln == 0) {
       int u = 0;
@@ -463,9 +478,12 @@ constexpr int kBoxCap = RR_K1_BOXCAP;   // LUT texels per stream held in LDS
 constexpr int kRowCap = 512;           // (separable form) x-pass results: dz * dy rows of 8
 static_assert(kBoxCap <= 1024, "phase B's division-free index decomposition is exact below 1024 only");
 
-template <bool kList, bool kSep, bool kRanges = false>
+// kCache: the launch shares its work items with k_integrate_cached (below): items whose projection is cached are skipped here, and an
+// item that was dealt a fresh slot evaluates EVERY stream per voxel (no uniform-pair shortcut) and writes each voxel's (u, v, z) through
+// to the slot -- the bits the cached kernel reads from the next frame on are the bits this kernel used
+template <bool kList, bool kSep, bool kRanges = false, bool kCache = false>
 __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
-                                                                             const uint32_t* __restrict__ pair_masks) {
+                                                                             const uint32_t* __restrict__ pair_masks, ProjCache PC) {
   __shared__ float4 s_box[kBoxCap];             // the stream's texel box, x fastest: ((z - mz) * dy + (y - my)) * dx + (x - mx)
   __shared__ float4 s_row[kSep ? kRowCap : 1];  // (separable form) x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
   __shared__ int s_i0a[TSDF_MAX_STREAMS][3][8], s_i1a[TSDF_MAX_STREAMS][3][8];   // per stream, axis and voxel coordinate of the tile: the two texel indices ...
@@ -475,7 +493,15 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
   const int n_work = kList ? (int)*S.count : S.n;
   const int tid = threadIdx.x;
   if (kList && blockIdx.x == 0 && tid == 0) *S.next_count = 0u;                    // the previous list was consumed by the classify launch
+  if (kCache && *PC.n_slow == 0u) return;                                          // steady state: every work item is cached
+  // INVARIANT of the tile loop: every exit from an iteration after phase A has touched s_* passes through store_tile_class(), whose
+  // workgroup barrier is what lets the next iteration overwrite s_* (there is no barrier at the head of the loop).  The `continue`s
+  // below are workgroup-uniform and sit in front of phase A.
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    uint32_t item = kItemNone;
+    if (kCache) { item = PC.items[w]; if (item < kItemFresh) continue; }           // cached: k_integrate_cached's
+    const bool fill = kCache && item != kItemNone;                                   // workgroup-uniform
+    float* __restrict__ const fill_base = fill ? PC.data + (size_t)(item & ~kItemFresh) * PC.slot_floats : nullptr;
     const int tile = work_tile<kList>(S, w);
     int t3[3];
     tile_coords(V, tile, t3[0], t3[1], t3[2]);
@@ -486,7 +512,8 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
     bool drawn[kVox];
     float tsd[kVox], wsum[kVox];
-    const uint32_t pairs = kRanges ? pair_masks[w] : 0u;                // (kRanges) from k_pair_masks: 2 bits per stream -- which streams treat every voxel of this tile alike --, bit 31: every brick reaching into the tile is occupied
+    uint32_t pairs = kRanges ? pair_masks[w] : 0u;                      // (kRanges) from k_pair_masks: 2 bits per stream -- which streams treat every voxel of this tile alike --, bit 31: every brick reaching into the tile is occupied
+    if (fill) pairs &= T.n <= 15 ? 0x80000000u : 0u;                    // a slot is filled for all streams: no shortcut this once
     const bool check_voxels = per_voxel_check && !(kRanges && T.n <= 15 && (pairs >> 31));
 #pragma unroll
     for (int h = 0; h < kVox; ++h) {
@@ -559,7 +586,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
       bool any_drawn = false;
 #pragma unroll
       for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
-      if (__ballot(any_drawn) != 0ull) {                                // phase Z
+      if (fill || __ballot(any_drawn) != 0ull) {                        // phase Z
         const int x0 = s_i0[0][lx] - mx, x1 = s_i1[0][lx] - mx;
         const int y0 = __mul24(s_i0[1][ly] - my, dx), y1 = __mul24(s_i1[1][ly] - my, dx);
         const int pl = __mul24(dx, dy);
@@ -575,6 +602,10 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
             const float3 c00 = lerp3(s_box[z0 + y0 + x0], s_box[z0 + y0 + x1], wx), c10 = lerp3(s_box[z0 + y1 + x0], s_box[z0 + y1 + x1], wx);
             const float3 c01 = lerp3(s_box[z1 + y0 + x0], s_box[z1 + y0 + x1], wx), c11 = lerp3(s_box[z1 + y1 + x0], s_box[z1 + y1 + x1], wx);
             pc = lerp3(lerp3(c00, c10, wy), lerp3(c01, c11, wy), s_w[2][kz]);
+          }
+          if (fill) {                                                   // write-through: voxel tid + 256 h of stream i
+            float* __restrict__ const e = fill_base + (uint32_t)(__mul24(i, 512) + tid + 256 * h) * 3u;
+            e[0] = pc.x; e[1] = pc.y; e[2] = pc.z;
           }
           // the gather and the fusion rule are two branches on purpose: in one branch the compiler keeps voxel 1's loads behind
           // voxel 0's arithmetic; apart, the unrolled loop has both voxels' gathers in flight together
@@ -609,194 +640,153 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
 }
 
 
-// One wave per tile (round 2).  The forms above give a tile to a 256-thread workgroup: four waves that meet at ~4 workgroup barriers
-// per stream, each of which repeats the tile's set-up, and a machine that holds 2048 tiles at a time (8 waves per SIMD) -- a culled
-// launch of ~5000 tiles is 2.6 rounds of a ~18 us chain.  Here a tile belongs to ONE wave: lane (lx, ly) owns the column of 8 voxels
-// along z.  Nothing is shared between waves, so there is no workgroup barrier at all -- the LDS operations of one wave are processed
-// in order, the phases only need the compiler kept from reordering them (wave_barrier) -- the set-up is done once per tile instead of
-// four times, and every tile of a culled launch is resident at once (6 waves per SIMD = 6144 tiles), each wave's round trips hidden
-// behind five others at different phases.  Per voxel the operands and the order of operations are those of the separable form: the
-// results are bit-identical.  A wave-per-stream variant (four waves per tile, one stream each, the four image gathers of a voxel in
-// flight together) was built first and measured slower (c2 65.8 vs 53.2 us: 24-43 KB of LDS and 128 VGPRs per workgroup); removed.
-// Dynamic LDS per wave: box + row float4 (the context's worst tile box: box = max(dx dy dz, 64 dz), row = 8 dy dz).
-struct WsCaps { int box, row; };
-#ifndef RR_K1W_WAVES
-#define RR_K1W_WAVES 6
+// Cached form (round 3): the work items whose projection (u, v, z) is in the pool (ProjCache, tsdf_common.hpp).  One voxel per thread,
+// 512 threads per tile.  Per tile: the streams' (u, v, z) as coalesced 12-byte loads (768 contiguous bytes per wave and stream; only
+// the streams the pair-mask pass left to per-voxel evaluation are read), then the 2x2 image footprints of kChunk streams in flight
+// together, then the fusion rule in stream order on registers, one coalesced 2 KiB store.  No LUT texel, no LDS, one workgroup
+// barrier (the tile class).  Operands and operation order per voxel are those of k_integrate_tiles_lds: the cached (u, v, z) are the
+// bits that kernel computed, so the volume is bit-identical.
+// HBM per tile: 2 KiB stored + 6 KiB x (streams evaluated per voxel) read + the image footprints (L2 / MALL resident).
+#ifndef RR_K1C_CHUNK
+#define RR_K1C_CHUNK 2
 #endif
-#ifndef RR_K1W_BATCH
-#define RR_K1W_BATCH 1      // voxels of a lane whose image gathers are in flight together (2: 10 spilled VGPRs at 6 waves/SIMD, c2 52.8 instead of 50.5 us)
+#ifndef RR_K1C_BOUNDS
+#define RR_K1C_BOUNDS 8
 #endif
-template <bool kList, bool kRanges>
-__global__ __launch_bounds__(64, RR_K1W_WAVES) void k_integrate_tiles_w1(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
-                                                                         const uint32_t* __restrict__ pair_masks, WsCaps C) {
-  extern __shared__ float4 s_dyn[];
-  float4* const s_box = s_dyn;                   // the stream's texel box, later its y-lerped planes: ((z - mz) * 8 + y) * 8 + x
-  float4* const s_row = s_dyn + C.box;           // its x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
-  __shared__ int s_i0[3][8], s_i1[3][8];         // per axis and voxel coordinate of the tile: the two texel indices ...
-  __shared__ float s_w[3][8];                    // ... and the weight of the GL LINEAR filter (current stream)
-  const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
+__device__ __forceinline__ float3 load_f3(const float* __restrict__ p) { return make_float3(p[0], p[1], p[2]); }
+template <bool kList, int kChunk>
+__global__ __launch_bounds__(512, RR_K1C_BOUNDS) void k_integrate_cached(int n_streams, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
+                                                                          const uint32_t* __restrict__ pair_masks, ProjCache PC) {
+  struct { int n; } T{n_streams};                                       // (the kernel reads no LUT: the stream table stays on the host)
   const float limit = V.limit;
   const int n_work = kList ? (int)*S.count : S.n;
-  const int ln = threadIdx.x, lx = ln & 7, ly = ln >> 3;
-  if (kList && blockIdx.x == 0 && ln == 0) *S.next_count = 0u;                     // the previous list was consumed by the classify launch
+  const int tid = threadIdx.x;
+  const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const uint32_t item = PC.items[w];
+    if (item >= kItemFresh) continue;                                   // not cached (yet): the LDS kernel's (workgroup-uniform)
+    const uint32_t pairs = pair_masks[w];                               // 2 bits per stream (k_pair_masks), bit 31: every brick reaching into the tile is occupied
     const int tile = work_tile<kList>(S, w);
     int t3[3];
     tile_coords(V, tile, t3[0], t3[1], t3[2]);
-    if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
-    float* __restrict__ out = V.slot ? V.data + ((size_t)w << 9) : V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
-    const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
-    uint32_t drawn = 0;                                                 // bit kz: voxel (x, y, 8 tz + kz) is integrated
-    float tsd[8], wsum[8];
+    float* __restrict__ out = V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
+    const float* __restrict__ const base = PC.data + (size_t)item * PC.slot_floats + (uint32_t)tid * 3u;
+    const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly, z = t3[2] * 8 + lz;
+    bool drawn = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+    const bool check_voxels = per_voxel_check && !(T.n <= 15 && (pairs >> 31));
+    if (drawn && check_voxels) drawn = voxel_drawn(B, x, y, z);
+    float tsd = limit, wsum = 0.0f;                                     // tsdf_integration.vs:28-29
+    for (int c0 = 0; c0 < T.n; c0 += kChunk) {
+      float3 pc[kChunk];
+      Dqs q[kChunk];
 #pragma unroll
-    for (int kz = 0; kz < 8; ++kz) {
-      const int z = t3[2] * 8 + kz;
-      bool d = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
-      if (d && per_voxel_check) d = voxel_drawn(B, x, y, z);
-      drawn |= (d ? 1u : 0u) << kz;
-      tsd[kz] = limit;                                                  // tsdf_integration.vs:28-29
-      wsum[kz] = 0.0f;
-    }
-    const uint32_t pairs = kRanges ? pair_masks[w] : 0u;                // (kRanges) 2 bits per stream: kPairFull / Carve / Neg / Nop (k_pair_masks)
-    const bool any_drawn = __ballot(drawn != 0u) != 0ull;
-    for (int i = 0; i < T.n; ++i) {
-      if (kRanges) {
-        const int pair = (int)((pairs >> (2 * i)) & 3u);                // wave-uniform
-        if (pair != kPairFull) {                                        // the branch is the same for every voxel of the tile: no box, no passes, no gathers
+      for (int k = 0; k < kChunk; ++k) {                                // texture(cv_xyz_inv[i], position).xyz, :31 -- from the pool
+        const int i = c0 + k;
+        if (i < T.n && ((pairs >> (2 * i)) & 3u) == (uint32_t)kPairFull) pc[k] = load_f3(base + (uint32_t)i * 1536u);
+      }
 #pragma unroll
-          for (int kz = 0; kz < 8; ++kz)
-            if (drawn & (1u << kz)) {
-              if (pair == kPairNeg) tsd[kz] = -limit;
-              else if (pair == kPairCarve && tsd[kz] >= limit) tsd[kz] = -limit;
-            }
+      for (int k = 0; k < kChunk; ++k) {                                // every lane gathers (the cached coordinates of padding / undrawn voxels are valid ones)
+        const int i = c0 + k;
+        if (i < T.n && ((pairs >> (2 * i)) & 3u) == (uint32_t)kPairFull) q[k] = dqs_fetch(F, i, pc[k].x, pc[k].y);
+      }
+#pragma unroll
+      for (int k = 0; k < kChunk; ++k) {
+        const int i = c0 + k;
+        if (i >= T.n) break;
+        const int pair = (int)((pairs >> (2 * i)) & 3u);                // workgroup-uniform
+        if (pair != kPairFull) {                                        // the branch is the same for every voxel of the tile
+          if (pair == kPairNeg) tsd = -limit;
+          else if (pair == kPairCarve && tsd >= limit) tsd = -limit;
           continue;
         }
-      }
-      const StreamLut& L = T.s[i];
-      __builtin_amdgcn_wave_barrier();                                  // (the previous stream's reads of the tables are issued)
-      if (ln < 24) {                                                    // phase A: GL LINEAR set-up of the tile's 8 coordinates per axis
-        const int a = ln >> 3, k = ln & 7;
-        const int coord = min(t3[a] * 8 + k, V.res[a] - 1);             // padding voxels reuse the last real coordinate
-        const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], L.inv_res[a]);
-        s_i0[a][k] = ax.i0; s_i1[a][k] = ax.i1; s_w[a][k] = ax.a;
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int mx = s_i0[0][0], my = s_i0[1][0], mz = s_i0[2][0];
-      const int dx = s_i1[0][7] - mx + 1, dy = s_i1[1][7] - my + 1, dz = s_i1[2][7] - mz + 1;
-      {                                                                 // phase B: the stream's texel box, independent 16-byte loads
-        const int n = min(__mul24(__mul24(dx, dy), dz), C.box);
-        const float rdx = __builtin_amdgcn_rcpf((float)dx), rdy = __builtin_amdgcn_rcpf((float)dy);   // division-free e -> (bx, by, bz), see above
-        for (int e = ln; e < n; e += 64) {
-          const int row = (int)(((float)e + 0.5f) * rdx);
-          const int bz = (int)(((float)row + 0.5f) * rdy);
-          const int bx = e - __mul24(row, dx), by = row - __mul24(bz, dy);
-          s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
+        float weighted_tsd = tsd, total_weight = wsum;                  // tsdf_integration.vs:30-55, in stream order
+        bool skip = false;
+        if (dqs_silhouette(q[k]) < 1.0f) {
+          if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
         }
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int n1 = min(__mul24(__mul24(dy, dz), 8), C.row);           // pass X
-      for (int e = ln; e < n1; e += 64) {
-        const int k = e & 7, rb = __mul24(e >> 3, dx);
-        const float3 r = lerp3(s_box[rb + (s_i0[0][k] - mx)], s_box[rb + (s_i1[0][k] - mx)], s_w[0][k]);
-        s_row[e] = make_float4(r.x, r.y, r.z, 0.0f);
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int n2 = min(dz << 6, C.box);                               // pass Y: the y-lerped planes overwrite the box
-      for (int e = ln; e < n2; e += 64) {
-        const int k = e & 7, j = (e >> 3) & 7, zb = __mul24(e >> 6, dy);
-        const float3 r = lerp3(s_row[((zb + (s_i0[1][j] - my)) << 3) + k], s_row[((zb + (s_i1[1][j] - my)) << 3) + k], s_w[1][j]);
-        s_box[e] = make_float4(r.x, r.y, r.z, 0.0f);
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (!any_drawn) continue;
-      constexpr int kB = RR_K1W_BATCH;
-#pragma unroll
-      for (int kb = 0; kb < 8; kb += kB) {                              // phase Z: the lane's column, kB voxels' gathers in flight together
-        float3 pc[kB];
-        Dqs q[kB];
-#pragma unroll
-        for (int h = 0; h < kB; ++h) {                                  // texture(cv_xyz_inv[i], position).xyz, :31
-          const int kz = kb + h;
-          pc[h] = lerp3(s_box[(((s_i0[2][kz] - mz) << 3) + ly) * 8 + lx], s_box[(((s_i1[2][kz] - mz) << 3) + ly) * 8 + lx], s_w[2][kz]);
-        }
-        // the gathers and the fusion rule are separate loops on purpose: both voxels' loads are issued before either is consumed
-#pragma unroll
-        for (int h = 0; h < kB; ++h)
-          if (drawn & (1u << (kb + h))) q[h] = dqs_fetch(F, i, pc[h].x, pc[h].y);
-#pragma unroll
-        for (int h = 0; h < kB; ++h) {
-          const int kz = kb + h;
-          if (drawn & (1u << kz)) {
-            float weighted_tsd = tsd[kz], total_weight = wsum[kz];      // tsdf_integration.vs:30-55, in stream order
-            bool skip = false;
-            if (dqs_silhouette(q[h]) < 1.0f) {
-              if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
-            }
-            if (!skip) {
-              const float sdist = pc[h].z - dqs_depth(q[h]);
-              if (sdist <= -limit) {
-                weighted_tsd = -limit;
-              } else if (sdist >= limit) {
-              } else {
-                const float weight = dqs_quality(q[h]);
-                weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
-                total_weight += weight;
-              }
-            }
-            tsd[kz] = weighted_tsd; wsum[kz] = total_weight;
+        if (!skip) {
+          const float sdist = pc[k].z - dqs_depth(q[k]);
+          if (sdist <= -limit) {
+            weighted_tsd = -limit;
+          } else if (sdist >= limit) {
+          } else {
+            const float weight = dqs_quality(q[k]);
+            weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
+            total_weight += weight;
           }
         }
+        tsd = weighted_tsd; wsum = total_weight;
       }
     }
-    bool all_clear = true;
-#pragma unroll
-    for (int kz = 0; kz < 8; ++kz) {                                    // clearImage(-limit), :249-250
-      const float v = (drawn & (1u << kz)) ? tsd[kz] : -limit;
-      out[kz * 64 + ln] = v;
-      all_clear = all_clear && (v == -limit);
-    }
-    const bool tile_clear = __ballot(!all_clear) == 0ull;               // exact class: every stored voxel is the clear value
-    if (ln == 0) S.cls[tile] = tile_clear ? kTileMinus : kTileMixed;
+    tsd = drawn ? tsd : -limit;                                         // clearImage(-limit), :249-250
+    out[tid] = tsd;
+    store_tile_class(S, tile, tsd == -limit);
   }
 }
 
+// counts of the last launch's work items, for bench.py's algorithmic byte count (never in the frame path)
+template <bool kList>
+__global__ __launch_bounds__(256) void k_item_stats(StreamTable T, TileState S, const uint32_t* __restrict__ masks, ProjCache PC, uint32_t* __restrict__ out) {
+  const int n_work = kList ? (int)*S.count : S.n;
+  uint32_t cached = 0, full = 0, slow = 0;
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n_work; w += gridDim.x * blockDim.x) {
+    const uint32_t it = PC.items[w];
+    if (it >= kItemFresh) { ++slow; continue; }
+    ++cached;
+    const uint32_t m = masks[w];
+    for (int i = 0; i < T.n; ++i) full += ((m >> (2 * i)) & 3u) == (uint32_t)kPairFull;
+  }
+  atomicAdd(&out[1], cached); atomicAdd(&out[2], full); atomicAdd(&out[3], slow);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (uint32_t)n_work;
+}
+void launch_item_stats(hipStream_t st, const StreamTable& T, const TileState& S, int use_bricks, const uint32_t* pair_masks, const ProjCache& PC, uint32_t* out) {
+  hipMemsetAsync(out, 0, 4 * sizeof(uint32_t), st);
+  if (use_bricks) hipLaunchKernelGGL(k_item_stats<true>, dim3(64), dim3(256), 0, st, T, S, pair_masks, PC, out);
+  else hipLaunchKernelGGL(k_item_stats<false>, dim3(64), dim3(256), 0, st, T, S, pair_masks, PC, out);
+}
+
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, int ws_box, int ws_row, const float4* tile_bounds, uint32_t* pair_masks) {
-  const WsCaps wc{ws_box, ws_row};
-  const size_t ws_lds = (size_t)(ws_box + ws_row) * sizeof(float4);
-  // phase 1: tile classification + stale-tile clear; 2: pair-mask pass + integrate kernel; 3: the pair-mask pass alone; 4: the integrate
-  // kernel alone; 0: everything (the split lets the caller time the kernels separately)
-  if (use_bricks) {
-    if (phase < 2) {
-      if (full_classify) hipLaunchKernelGGL(k_classify_clear_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
-      else {
-        PeelClear none{};
-        const PeelClear& P = pc ? *pc : none;
-        const int extra = P.peels ? (P.n_tiles + 3) / 4 : 0;
-        hipLaunchKernelGGL(k_classify_lists, dim3(kScatterBlocks + kStaleBlocks + kZeroBlocks + extra), dim3(256), 0, st, V, B, S, frame_stamp, P);
-      }
+                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, const float4* tile_bounds, uint32_t* pair_masks, const ProjCache* proj) {
+  // phase 1: tile classification + stale-tile clear; 2: pair-mask pass + integrate kernel(s); 3: the pair-mask pass alone; 4: the integrate
+  // kernel(s) alone; 0: everything (the split lets the caller time the kernels separately)
+  const ProjCache none_pc{};
+  const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
+  const bool cached = ranges && proj && proj->data;
+  const ProjCache& PC = cached ? *proj : none_pc;
+  const int pvc = use_bricks ? (S.uniform ? 0 : 1) : 0;
+  if (use_bricks && phase < 2) {
+    if (full_classify) hipLaunchKernelGGL(k_classify_clear_tiles, dim3((S.n + 255) / 256), dim3(256), 0, st, V, B, S);
+    else {
+      PeelClear none{};
+      const PeelClear& P = pc ? *pc : none;
+      const int extra = P.peels ? (P.n_tiles + 3) / 4 : 0;
+      hipLaunchKernelGGL(k_classify_lists, dim3(kScatterBlocks + kStaleBlocks + kZeroBlocks + extra), dim3(256), 0, st, V, B, S, frame_stamp, P);
     }
-    if (phase == 1) return;
-    const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
-    if (ranges && phase != 4) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, tile_bounds, pair_masks);
-    if (phase == 3) return;
+  }
+  if (phase == 1) return;
+  if (ranges && phase != 4) {
+    if (use_bricks) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, B, S, pvc, tile_bounds, pair_masks, PC);
+    else hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds, pair_masks, PC);
+  }
+  if (phase == 3) return;
+  if (use_bricks) {
     const dim3 grid(S.n < 4096 ? S.n : 4096);
-    if (lds_ok == 3 && ranges) hipLaunchKernelGGL((k_integrate_tiles_w1<true, true>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, pair_masks, wc);
-    else if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<true, false>), dim3(S.n < 8192 ? S.n : 8192), dim3(64), ws_lds, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr, wc);
-    else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, pair_masks);
-    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
-    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1, nullptr);
-    else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, S.uniform ? 0 : 1);
+    if (cached) {
+      hipLaunchKernelGGL((k_integrate_cached<true, RR_K1C_CHUNK>), grid, dim3(512), 0, st, T.n, F, V, B, S, pvc, pair_masks, PC);
+      hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
+    }
+    else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
+    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
+    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
+    else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, pvc);
   } else {
-    if (phase == 1) return;
-    const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
-    if (ranges && phase != 4) hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds, pair_masks);
-    if (phase == 3) return;
-    if (lds_ok == 3 && ranges) hipLaunchKernelGGL((k_integrate_tiles_w1<false, true>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, pair_masks, wc);
-    else if (lds_ok == 3) hipLaunchKernelGGL((k_integrate_tiles_w1<false, false>), dim3(S.n), dim3(64), ws_lds, st, T, F, V, B, S, 0, nullptr, wc);
-    else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, pair_masks);
-    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr);
-    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr);
+    if (cached) {
+      hipLaunchKernelGGL((k_integrate_cached<false, RR_K1C_CHUNK>), dim3(S.n), dim3(512), 0, st, T.n, F, V, B, S, 0, pair_masks, PC);
+      hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);
+    }
+    else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);
+    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr, PC);
+    else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr, PC);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
   }
 }

@@ -100,6 +100,27 @@ struct Bricks {
   float bbox_min[3];
 };
 
+// Projection cache (round 3).  texture(cv_xyz_inv[i], voxel centre).xyz -- the (u, v, z) a voxel projects to in stream i,
+// tsdf_integration.vs:31 -- depends on the calibration volume and the voxel grid only, never on the frame.  The LDS form of the
+// integrate kernel recomputes it every frame (texel box -> LDS -> X / Y passes -> z lerp: ~8 dependent round trips and ~17 workgroup
+// barriers per tile); with 288 GB of HBM it is cheaper to keep it: a pool of slots, one per cached tile, each [stream][voxel 0..511]
+// x 12 bytes (the tile's own voxel order: one coalesced 768-byte read per wave and stream), dealt on first use (slot[stored tile]).
+// A tile's slot is filled by the LDS form itself the first time the tile is integrated (write-through: the same bits), so a cached
+// tile integrates as: coalesced loads of (u, v, z) -> image gathers -> fusion rule in stream order -> store.  No LUT box, no passes,
+// no workgroup barrier.
+constexpr uint32_t kItemFresh = 0x80000000u;   // items[w] >= kItemFresh: not (yet) cached -- the LDS kernel's work; kItemFresh | slot: ... and it fills `slot`
+constexpr uint32_t kItemNone = 0xffffffffu;    // no slot (pool exhausted)
+struct ProjCache {
+  float* data;             // pool: slot s at s * slot_floats
+  uint32_t* slot;          // per STORED tile: its slot, or kNoSlot
+  uint32_t* alloc;         // device scalar: slots handed out so far
+  uint32_t cap;            // pool capacity in slots
+  uint32_t slot_floats;    // N * 512 * 3
+  uint32_t* items;         // per work item of this frame's launch: slot (cached), kItemFresh | slot (to be filled now), kItemNone
+  uint32_t* n_slow;        // device scalar: work items of this frame the LDS kernel must take (0: it returns at once)
+  uint32_t* n_slow_next;   // the other of the two alternating words, zeroed by this frame's pair-mask pass for the next frame
+};
+
 struct Mat4 { float m[16]; };   // column-major
 struct ViewParams {
   Mat4 mv, proj, mv_inv, v2w_inv, img_to_eye, normal, mv_v2w, glnormal_inv;
@@ -194,9 +215,12 @@ void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels
 // ... and so does the zeroing of the spare brick-counter buffer (`zero`, in 16-byte units of zero_words / 4)
 struct PeelClear { uint4* peels; const uint8_t* touched_prev; int w, h, ntx, n_tiles; uint32_t* zero; uint32_t zero_words; };   // null pointers: nothing to do
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr, int ws_box = 0, int ws_row = 0,
+                      int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr,
                       const float4* tile_bounds = nullptr,   // per (stored tile, stream) 2 x float4 LUT-box bounds (launch_tile_bounds), or null
-                      uint32_t* pair_masks = nullptr);        // per work item: the frame's pair classes (written by the launch itself), or null
+                      uint32_t* pair_masks = nullptr,         // per work item: the frame's pair classes (written by the launch itself), or null
+                      const ProjCache* proj = nullptr);       // projection cache (needs tile_bounds / pair_masks: its work items are classified by the pair-mask pass), or null
+// [work items, cached items, (tile, stream) pairs of cached items evaluated per voxel, items taken by the LDS kernel] of the last launch -> out[4] (device)
+void launch_item_stats(hipStream_t st, const StreamTable& T, const TileState& S, int use_bricks, const uint32_t* pair_masks, const ProjCache& PC, uint32_t* out);
 void launch_tile_bounds(hipStream_t st, const StreamTable& T, const Volume& V, float4* bounds);
 int integrate_box_cap();
 int integrate_row_cap();
