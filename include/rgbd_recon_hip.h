@@ -66,14 +66,14 @@ typedef struct tsdf_config {
    * possible (4096^3 = 256 GiB dense).  Needs brick culling (setUseBricks(true)); with a slab, slab_recompute_halo = 1.
    * A frame that needs more tiles than the pool holds drops the excess (they read -limit): tsdf_sparse_pool_stats. 0: dense. */
   uint32_t sparse_pool_tiles;
-  /* Projection cache (dense storage, culled or dense integrate): texture(cv_xyz_inv[i], voxel centre).xyz of tsdf_integration.vs:31
-   * depends on the calibration and the voxel grid only, so the integrate kernel keeps it in HBM per 8^3-voxel tile once the tile has
-   * been integrated (N x 6 KiB per tile, dealt on first use) and from then on reads it back instead of re-filtering the LUT.
-   * Budget in MiB: 0 = default (8192, or RR_PROJ_CACHE_MB), TSDF_PROJ_CACHE_OFF = never.  Tiles beyond the budget keep the LUT path.
-   * Results are bit-identical either way. */
+  /* Projection cache, OPT-IN (dense storage, culled or dense integrate): texture(cv_xyz_inv[i], voxel centre).xyz of
+   * tsdf_integration.vs:31 depends on the calibration and the voxel grid only, so the integrate kernel can keep the x/y-filtered
+   * LUT planes of every 8^3-voxel tile in HBM once the tile has been integrated (N x dz x 768 B per tile, dealt on first use) and
+   * from then on read them back instead of re-filtering the LUT.  Budget in MiB; 0 = off (default: on MI355X the cached kernel
+   * is bound by the same image gathers as the LUT kernel and measured slower).  Tiles beyond the budget keep
+   * the LUT path.  Results are bit-identical either way. */
   uint32_t proj_cache_mib;
 } tsdf_config;
-#define TSDF_PROJ_CACHE_OFF 0xffffffffu
 
 /* ---- lifetime / errors ------------------------------------------------------------------------- */
 int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out);

@@ -198,7 +198,7 @@ class ReconIntegrationHip:
         cfg.slab_z0, cfg.slab_z1 = slab
         cfg.slab_recompute_halo = int(bool(recompute_halo))
         cfg.sparse_pool_tiles = int(sparse_pool_tiles)
-        cfg.proj_cache_mib = 0xffffffff if proj_cache_mib is None else int(proj_cache_mib)   # 0: default budget, None: off
+        cfg.proj_cache_mib = int(proj_cache_mib or 0)   # opt-in projection cache of the integrate kernel, MiB (0 / None: off)
         ctx = C.c_void_p()
         rc = self._L.tsdf_create(C.byref(cfg), C.byref(ctx))
         if rc != 0:

@@ -65,8 +65,9 @@ struct tsdf_ctx {
   bool have_calib[TSDF_MAX_STREAMS]{};
   // the stream's per-tile LUT box against the integrate kernel's LDS budget: 0 = does not fit (global-memory kernel), 1 = the box fits
   // (direct 8-tap form), 2 = the separable passes' rows and planes fit as well (the fastest form)
+  int lut_dz[TSDF_MAX_STREAMS]{};   // the most z-planes of the stream's inverse LUT any 8^3 tile of the volume touches
   int lds_ok[TSDF_MAX_STREAMS]{};
-  int k1_form_cap = 3;           // RR_K1_FORM: 3 = projection cache over the separable form (default), 2 = separable LDS form, 1 = direct 8-tap form, 0 = global-memory kernel
+  int k1_form_cap = 3;           // RR_K1_FORM: 3 = no cap (separable LDS form; + the projection cache where a budget was given), 2 = separable LDS form, 1 = direct 8-tap form, 0 = global-memory kernel
   // projection cache (ProjCache, tsdf_common.hpp): pool + slot table allocated by the first integrate() that can use it, dropped with
   // the volume, invalidated by tsdf_set_calibration
   ProjCache proj{}; uint32_t* d_proj_words = nullptr; int proj_parity = 0; size_t proj_budget = 0; bool proj_failed = false; uint32_t* d_item_stats = nullptr;
@@ -542,6 +543,7 @@ void fit_lut_to_volume(tsdf_ctx* c, uint32_t i) {
     auto idx1 = [&](int v) { float f = ((float)v + 0.5f) * step * (float)n - 0.5f; int k = (int)fminf(fmaxf(floorf(f), -1.0f), (float)n); return std::min(std::max(k + 1, 0), n - 1); };
     for (int t = 0; t * 8 < c->res[a]; ++t) worst[a] = std::max(worst[a], idx1(std::min(t * 8 + 7, c->res[a] - 1)) - idx0(t * 8) + 1);
   }
+  c->lut_dz[i] = worst[2];
   c->lds_ok[i] = worst[0] * worst[1] * worst[2] > integrate_box_cap() ? 0 : ((worst[1] * worst[2] * 8 <= integrate_row_cap() && worst[2] * 64 <= integrate_box_cap()) ? 2 : 1);
 }
 
@@ -579,9 +581,9 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   c->stream = c->own_stream;
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
   {
-    uint64_t mib = cfg->proj_cache_mib == 0 ? 8192 : cfg->proj_cache_mib;
-    if (cfg->proj_cache_mib == 0) if (const char* e = getenv("RR_PROJ_CACHE_MB")) mib = (uint64_t)atoll(e);
-    c->proj_budget = cfg->proj_cache_mib == TSDF_PROJ_CACHE_OFF ? 0 : (size_t)(mib << 20);
+    uint64_t mib = cfg->proj_cache_mib;                                   // 0: off (the default: measured slower than the LUT kernel)
+    if (mib == 0) if (const char* e = getenv("RR_PROJ_CACHE_MB")) mib = (uint64_t)atoll(e);   // A/B and test hook
+    c->proj_budget = (size_t)(mib << 20);
   }
   if (const char* e = getenv("RR_K1_CULLED_RANGES")) c->culled_ranges = atoi(e) != 0;
   // setVoxelSize(), :340-347
@@ -729,10 +731,11 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
   L.inv = (const float4*)fresh; for (int a = 0; a < 3; ++a) L.inv_res[a] = (int)ri[a];
   fit_lut_to_volume(c, i);
   c->tile_bounds_valid = false;                                          // the tiles' LUT-box bounds and cached projections belong to the old volume
-  if (c->proj.slot) {
-    HIP_TRY(c, hipMemsetAsync(c->proj.slot, 0xff, (size_t)c->vol.n_stored_tiles * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_proj_words, 0, 4 * sizeof(uint32_t), c->stream));
+  if (c->proj.data) {                                                    // (the stream is idle: synchronised above) the pool's slot size follows the LUTs: re-made by the next integrate()
+    hipFree(c->proj.data); hipFree(c->proj.slot); hipFree(c->proj.items); hipFree(c->d_proj_words);
+    c->proj = ProjCache{}; c->d_proj_words = nullptr; c->last_integrate_cached = false;
   }
+  c->proj_failed = false;
   if (uv) {
     if (int32_t rc = upload(&fresh, uv, vol_n(ru) * sizeof(float2))) return rc;
     replace(1, fresh);
@@ -1121,7 +1124,9 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   const ProjCache* proj = nullptr;
   if (bounds && want_cache) {
     if (!c->proj.data) {
-      const size_t slot_bytes = (size_t)c->cfg.num_streams * TILE_VOX * 3 * sizeof(float);
+      int dz_max = 1;
+      for (uint32_t i = 0; i < c->cfg.num_streams; ++i) dz_max = std::max(dz_max, c->lut_dz[i]);
+      const size_t slot_bytes = (size_t)c->cfg.num_streams * dz_max * 64 * 3 * sizeof(float);
       const size_t cap = std::min<size_t>((size_t)c->vol.n_stored_tiles, c->proj_budget / slot_bytes);
       bool ok = cap > 0;
       ok = ok && hipMalloc((void**)&c->proj.slot, (size_t)c->vol.n_stored_tiles * sizeof(uint32_t)) == hipSuccess;
@@ -1135,11 +1140,12 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
       } else {
         HIP_TRY(c, hipMemsetAsync(c->proj.slot, 0xff, (size_t)c->vol.n_stored_tiles * sizeof(uint32_t), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_proj_words, 0, 4 * sizeof(uint32_t), c->stream));
-        c->proj.cap = (uint32_t)cap; c->proj.slot_floats = (uint32_t)(slot_bytes / sizeof(float)); c->proj.alloc = c->d_proj_words;
+        c->proj.cap = (uint32_t)cap; c->proj.slot_floats = (uint32_t)(slot_bytes / sizeof(float)); c->proj.alloc = c->d_proj_words; c->proj.dz_max = (uint32_t)dz_max;
         c->proj_parity = 0;
       }
     }
     if (c->proj.data) {
+      for (uint32_t i = 0; i < c->cfg.num_streams; ++i) c->proj.inv_rz[i] = c->luts.s[i].inv_res[2];
       c->proj.n_slow = c->d_proj_words + 1 + c->proj_parity; c->proj.n_slow_next = c->d_proj_words + 1 + (c->proj_parity ^ 1);
       c->proj_parity ^= 1;
       proj = &c->proj;

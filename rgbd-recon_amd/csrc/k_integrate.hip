@@ -580,13 +580,17 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
           const int k = e & 7, j = (e >> 3) & 7, zb = __mul24(e >> 6, dy);
           const float3 r = lerp3(s_row[((zb + (s_i0[1][j] - my)) << 3) + k], s_row[((zb + (s_i1[1][j] - my)) << 3) + k], s_w[1][j]);
           s_box[e] = make_float4(r.x, r.y, r.z, 0.0f);
+          if (fill) {                                                   // write-through: plane e >> 6 of stream i, voxel column e & 63
+            float* __restrict__ const o = fill_base + (uint32_t)(__mul24(__mul24(i, (int)PC.dz_max), 64) + e) * 3u;
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+          }
         }
         __syncthreads();
       }
       bool any_drawn = false;
 #pragma unroll
       for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
-      if (fill || __ballot(any_drawn) != 0ull) {                        // phase Z
+      if (__ballot(any_drawn) != 0ull) {                                // phase Z
         const int x0 = s_i0[0][lx] - mx, x1 = s_i1[0][lx] - mx;
         const int y0 = __mul24(s_i0[1][ly] - my, dx), y1 = __mul24(s_i1[1][ly] - my, dx);
         const int pl = __mul24(dx, dy);
@@ -602,10 +606,6 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
             const float3 c00 = lerp3(s_box[z0 + y0 + x0], s_box[z0 + y0 + x1], wx), c10 = lerp3(s_box[z0 + y1 + x0], s_box[z0 + y1 + x1], wx);
             const float3 c01 = lerp3(s_box[z1 + y0 + x0], s_box[z1 + y0 + x1], wx), c11 = lerp3(s_box[z1 + y1 + x0], s_box[z1 + y1 + x1], wx);
             pc = lerp3(lerp3(c00, c10, wy), lerp3(c01, c11, wy), s_w[2][kz]);
-          }
-          if (fill) {                                                   // write-through: voxel tid + 256 h of stream i
-            float* __restrict__ const e = fill_base + (uint32_t)(__mul24(i, 512) + tid + 256 * h) * 3u;
-            e[0] = pc.x; e[1] = pc.y; e[2] = pc.z;
           }
           // the gather and the fusion rule are two branches on purpose: in one branch the compiler keeps voxel 1's loads behind
           // voxel 0's arithmetic; apart, the unrolled loop has both voxels' gathers in flight together
@@ -640,87 +640,167 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
 }
 
 
-// Cached form (round 3): the work items whose projection (u, v, z) is in the pool (ProjCache, tsdf_common.hpp).  One voxel per thread,
-// 512 threads per tile.  Per tile: the streams' (u, v, z) as coalesced 12-byte loads (768 contiguous bytes per wave and stream; only
-// the streams the pair-mask pass left to per-voxel evaluation are read), then the 2x2 image footprints of kChunk streams in flight
-// together, then the fusion rule in stream order on registers, one coalesced 2 KiB store.  No LUT texel, no LDS, one workgroup
-// barrier (the tile class).  Operands and operation order per voxel are those of k_integrate_tiles_lds: the cached (u, v, z) are the
-// bits that kernel computed, so the volume is bit-identical.
-// HBM per tile: 2 KiB stored + 6 KiB x (streams evaluated per voxel) read + the image footprints (L2 / MALL resident).
+// Cached form (round 3): the work items whose x/y-filtered LUT planes are in the pool (ProjCache, tsdf_common.hpp).  One WAVE per
+// z-plane of a tile (64 voxels, lane = x + 8 y), nothing shared between waves: no LDS, no barrier.  Per plane: for each stream the
+// pair-mask pass left to per-voxel evaluation, the two cached planes the voxels' z filter taps (two coalesced 768-byte reads; the filter
+// set-up of the plane's one z coordinate is wave-uniform) and one lerp give texture(cv_xyz_inv[i], position).xyz -- the same operands and
+// operation as the last step of k_integrate_tiles_lds, hence the same bits --, then the 2x2 image footprints of kChunk streams in
+// flight together, the fusion rule in stream order on registers, one 256-byte store.
+// Unit u -> (work item, plane): the eight planes of a tile go to blocks of equal blockIdx % 8, i.e. (round-robin dispatch) to ONE XCD,
+// whose L2 then fetches each cached plane from HBM once although up to three waves read it.  Speed only, never correctness.
+// HBM per tile: 2 KiB stored + dz x 768 B x (streams evaluated per voxel) read + the image footprints (L2 / MALL resident).
+// The loop is software-pipelined by hand, because a wave's vector-memory operations complete IN ORDER (one vmcnt counter for loads
+// and stores): a persistent wave that stores its plane and then loads the next unit's meta data, planes and footprints one after the
+// other pays four dependent round trips per unit plus the store's acknowledgement (measured: 44 us per launch at c2, 23 us of it
+// with the plane loads and the gathers compiled out).  So
+//   * the meta data of a unit (cache slot, pair classes, tile id) are SCALAR loads -- the kernel arguments they come through are
+//     `const __restrict__`, the index is wave-uniform --, counted by lgkmcnt, and they are issued one unit ahead;
+//   * the cached planes of the NEXT unit (its first kPre streams) are requested after the fusion rule of the current unit and BEFORE
+//     its stores: when the next iteration waits for them, the stores behind them in the queue do not hold it up, and they have had the
+//     current unit's whole gather phase to arrive.
+// What is left on a unit's critical path is its footprint gathers.
 #ifndef RR_K1C_CHUNK
-#define RR_K1C_CHUNK 2
+#define RR_K1C_CHUNK 1      // streams whose footprints are gathered together (2 needs more than the 64 VGPRs of 8 waves per SIMD: spills)
+#endif
+#ifndef RR_K1C_PRE
+#define RR_K1C_PRE 1        // streams of the NEXT unit whose planes are prefetched
+#endif
+#ifndef RR_K1C_GRID
+#define RR_K1C_GRID 8192
 #endif
 #ifndef RR_K1C_BOUNDS
 #define RR_K1C_BOUNDS 8
 #endif
 __device__ __forceinline__ float3 load_f3(const float* __restrict__ p) { return make_float3(p[0], p[1], p[2]); }
+struct CachedUnit {                                                     // everything wave-uniform
+  uint32_t item, pairs;
+  int tile, kz;
+  bool live;
+};
+struct CachedPlanes { float3 a[RR_K1C_PRE], b[RR_K1C_PRE]; float w[RR_K1C_PRE]; };
+template <bool kList>
+__device__ __forceinline__ CachedUnit cached_unit(int u, int n_work, const uint32_t* __restrict__ items, const uint32_t* __restrict__ pair_masks,
+                                                  const uint32_t* __restrict__ list, const TileState& S) {
+  CachedUnit c;
+  const int w = ((u >> 6) << 3) + (u & 7);
+  c.kz = (u >> 3) & 7;
+  c.live = w < n_work;
+  const int wc = c.live ? w : 0;
+  c.item = items[wc];
+  c.pairs = pair_masks[wc];                                             // 2 bits per stream (k_pair_masks), bit 31: every brick reaching into the tile is occupied
+  c.tile = kList ? (int)list[wc] : work_tile<false>(S, wc);
+  c.live = c.live && c.item < kItemFresh;                               // else not cached (yet): the LDS kernel's
+  return c;
+}
+// the two cached planes the z filter of plane kz taps in stream i, and its weight (wave-uniform indices; phase A of the LDS kernel: padding
+// voxels reuse the last real coordinate)
+__device__ __forceinline__ void cached_planes(const ProjCache& PC, const Volume& V, const CachedUnit& c, int tz, int i, int ln, float3& pa, float3& pb, float& wz) {
+  const float step_z = 1.0f / (float)V.res[2];                          // volume_sampler.cpp:36-38
+  const float cz = ((float)min(tz * 8 + c.kz, V.res[2] - 1) + 0.5f) * step_z, cz0 = ((float)min(tz * 8, V.res[2] - 1) + 0.5f) * step_z;
+  const Axis az = axis_linear(cz, PC.inv_rz[i]);
+  const int mz = axis_linear(cz0, PC.inv_rz[i]).i0;
+  const float* __restrict__ const bi = PC.data + (size_t)c.item * PC.slot_floats + (uint32_t)__mul24(i, (int)PC.dz_max) * 192u + (uint32_t)ln * 3u;
+  pa = load_f3(bi + (uint32_t)(az.i0 - mz) * 192u);
+  pb = load_f3(bi + (uint32_t)(az.i1 - mz) * 192u);
+  wz = az.a;
+}
 template <bool kList, int kChunk>
-__global__ __launch_bounds__(512, RR_K1C_BOUNDS) void k_integrate_cached(int n_streams, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
-                                                                          const uint32_t* __restrict__ pair_masks, ProjCache PC) {
-  struct { int n; } T{n_streams};                                       // (the kernel reads no LUT: the stream table stays on the host)
+__global__ __launch_bounds__(64, RR_K1C_BOUNDS) void k_integrate_cached(int n_streams, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
+                                                                         const uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
+                                                                         const uint32_t* __restrict__ pair_masks, const uint32_t* __restrict__ items, ProjCache PC) {
+  constexpr int kPre = RR_K1C_PRE;
+  static_assert(kPre % kChunk == 0, "whole chunks are prefetched");
   const float limit = V.limit;
-  const int n_work = kList ? (int)*S.count : S.n;
-  const int tid = threadIdx.x;
-  const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
-  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
-    const uint32_t item = PC.items[w];
-    if (item >= kItemFresh) continue;                                   // not cached (yet): the LDS kernel's (workgroup-uniform)
-    const uint32_t pairs = pair_masks[w];                               // 2 bits per stream (k_pair_masks), bit 31: every brick reaching into the tile is occupied
-    const int tile = work_tile<kList>(S, w);
-    int t3[3];
-    tile_coords(V, tile, t3[0], t3[1], t3[2]);
-    float* __restrict__ out = V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9);
-    const float* __restrict__ const base = PC.data + (size_t)item * PC.slot_floats + (uint32_t)tid * 3u;
-    const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly, z = t3[2] * 8 + lz;
-    bool drawn = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
-    const bool check_voxels = per_voxel_check && !(T.n <= 15 && (pairs >> 31));
-    if (drawn && check_voxels) drawn = voxel_drawn(B, x, y, z);
+  const int n_work = kList ? (int)*count : S.n;
+  const int n_units = ((n_work + 7) >> 3) << 6;                         // 8 planes x work items, padded to whole groups of 8 items
+  const int ln = threadIdx.x, lx = ln & 7, ly = ln >> 3;
+  int u = blockIdx.x;
+  if (u >= n_units) return;
+  CachedUnit cur = cached_unit<kList>(u, n_work, items, pair_masks, list, S);
+  int t3[3];
+  tile_coords(V, cur.tile, t3[0], t3[1], t3[2]);
+  CachedPlanes P;
+#pragma unroll
+  for (int i = 0; i < kPre; ++i)
+    if (cur.live && i < n_streams && ((cur.pairs >> (2 * i)) & 3u) == (uint32_t)kPairFull) cached_planes(PC, V, cur, t3[2], i, ln, P.a[i], P.b[i], P.w[i]);
+  for (;;) {
+    const int un = u + (int)gridDim.x;
+    const bool more = un < n_units;
+    const CachedUnit nxt = cached_unit<kList>(more ? un : u, n_work, items, pair_masks, list, S);   // scalar loads, in flight while this unit is worked
     float tsd = limit, wsum = 0.0f;                                     // tsdf_integration.vs:28-29
-    for (int c0 = 0; c0 < T.n; c0 += kChunk) {
-      float3 pc[kChunk];
-      Dqs q[kChunk];
+    if (cur.live) {
+      const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly, z = t3[2] * 8 + cur.kz;
+      bool drawn = (x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]);
+      const bool check_voxels = per_voxel_check && !(n_streams <= 15 && (cur.pairs >> 31));
+      if (drawn && check_voxels) drawn = voxel_drawn(B, x, y, z);
+      for (int c0 = 0; c0 < n_streams; c0 += kChunk) {
+        float3 pa[kChunk], pb[kChunk], pc[kChunk];
+        float wz[kChunk];
+        Dqs q[kChunk];
 #pragma unroll
-      for (int k = 0; k < kChunk; ++k) {                                // texture(cv_xyz_inv[i], position).xyz, :31 -- from the pool
-        const int i = c0 + k;
-        if (i < T.n && ((pairs >> (2 * i)) & 3u) == (uint32_t)kPairFull) pc[k] = load_f3(base + (uint32_t)i * 1536u);
-      }
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k) {                                // every lane gathers (the cached coordinates of padding / undrawn voxels are valid ones)
-        const int i = c0 + k;
-        if (i < T.n && ((pairs >> (2 * i)) & 3u) == (uint32_t)kPairFull) q[k] = dqs_fetch(F, i, pc[k].x, pc[k].y);
-      }
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k) {
-        const int i = c0 + k;
-        if (i >= T.n) break;
-        const int pair = (int)((pairs >> (2 * i)) & 3u);                // workgroup-uniform
-        if (pair != kPairFull) {                                        // the branch is the same for every voxel of the tile
-          if (pair == kPairNeg) tsd = -limit;
-          else if (pair == kPairCarve && tsd >= limit) tsd = -limit;
-          continue;
-        }
-        float weighted_tsd = tsd, total_weight = wsum;                  // tsdf_integration.vs:30-55, in stream order
-        bool skip = false;
-        if (dqs_silhouette(q[k]) < 1.0f) {
-          if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
-        }
-        if (!skip) {
-          const float sdist = pc[k].z - dqs_depth(q[k]);
-          if (sdist <= -limit) {
-            weighted_tsd = -limit;
-          } else if (sdist >= limit) {
-          } else {
-            const float weight = dqs_quality(q[k]);
-            weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
-            total_weight += weight;
+        for (int k = 0; k < kChunk; ++k) {
+          const int i = c0 + k;
+          if (i < n_streams && ((cur.pairs >> (2 * i)) & 3u) == (uint32_t)kPairFull) {
+            if (c0 < kPre) { pa[k] = P.a[(c0 + k) % kPre]; pb[k] = P.b[(c0 + k) % kPre]; wz[k] = P.w[(c0 + k) % kPre]; }   // (c0 is a multiple of kChunk: the test is per chunk)
+            else cached_planes(PC, V, cur, t3[2], i, ln, pa[k], pb[k], wz[k]);
           }
         }
-        tsd = weighted_tsd; wsum = total_weight;
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {                              // every lane gathers (the coordinates of padding / undrawn voxels are valid ones)
+          const int i = c0 + k;
+          if (i < n_streams && ((cur.pairs >> (2 * i)) & 3u) == (uint32_t)kPairFull) {
+            pc[k] = lerp3(pa[k], pb[k], wz[k]);                         // texture(cv_xyz_inv[i], position).xyz, :31
+            q[k] = dqs_fetch(F, i, pc[k].x, pc[k].y);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+          const int i = c0 + k;
+          if (i >= n_streams) break;
+          const int pair = (int)((cur.pairs >> (2 * i)) & 3u);          // wave-uniform
+          if (pair != kPairFull) {                                      // the branch is the same for every voxel of the tile
+            if (pair == kPairNeg) tsd = -limit;
+            else if (pair == kPairCarve && tsd >= limit) tsd = -limit;
+            continue;
+          }
+          float weighted_tsd = tsd, total_weight = wsum;                // tsdf_integration.vs:30-55, in stream order
+          bool skip = false;
+          if (dqs_silhouette(q[k]) < 1.0f) {
+            if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
+          }
+          if (!skip) {
+            const float sdist = pc[k].z - dqs_depth(q[k]);
+            if (sdist <= -limit) {
+              weighted_tsd = -limit;
+            } else if (sdist >= limit) {
+            } else {
+              const float weight = dqs_quality(q[k]);
+              weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
+              total_weight += weight;
+            }
+          }
+          tsd = weighted_tsd; wsum = total_weight;
+        }
       }
+      tsd = drawn ? tsd : -limit;                                       // clearImage(-limit), :249-250
     }
-    tsd = drawn ? tsd : -limit;                                         // clearImage(-limit), :249-250
-    out[tid] = tsd;
-    store_tile_class(S, tile, tsd == -limit);
+    // the next unit's planes, requested before this unit's stores (see above)
+    int n3[3];
+    tile_coords(V, nxt.tile, n3[0], n3[1], n3[2]);
+#pragma unroll
+    for (int i = 0; i < kPre; ++i)
+      if (more && nxt.live && i < n_streams && ((nxt.pairs >> (2 * i)) & 3u) == (uint32_t)kPairFull) cached_planes(PC, V, nxt, n3[2], i, ln, P.a[i], P.b[i], P.w[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (cur.live) {
+      float* __restrict__ out = V.data + ((((size_t)(t3[2] - V.tz0) * V.nty + t3[1]) * V.ntx + t3[0]) << 9) + (cur.kz << 6);
+      out[ln] = tsd;
+      // tile class: the waves of a tile share nothing, so none of them can say "all 512 voxels are the clear value"; kTileMixed is always
+      // safe (an exact class only saves the reset of the tile when it leaves the active set, and lets the DENSE march leap over it)
+      if (ln == 0 && cur.kz == 0) S.cls[cur.tile] = kTileMixed;
+    }
+    if (!more) break;
+    cur = nxt; u = un;
+    t3[0] = n3[0]; t3[1] = n3[1]; t3[2] = n3[2];
   }
 }
 
@@ -772,7 +852,7 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
   if (use_bricks) {
     const dim3 grid(S.n < 4096 ? S.n : 4096);
     if (cached) {
-      hipLaunchKernelGGL((k_integrate_cached<true, RR_K1C_CHUNK>), grid, dim3(512), 0, st, T.n, F, V, B, S, pvc, pair_masks, PC);
+      hipLaunchKernelGGL((k_integrate_cached<true, RR_K1C_CHUNK>), dim3(RR_K1C_GRID), dim3(64), 0, st, T.n, F, V, B, S, pvc, S.count, S.list, pair_masks, PC.items, PC);
       hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
     }
     else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
@@ -781,7 +861,7 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, pvc);
   } else {
     if (cached) {
-      hipLaunchKernelGGL((k_integrate_cached<false, RR_K1C_CHUNK>), dim3(S.n), dim3(512), 0, st, T.n, F, V, B, S, 0, pair_masks, PC);
+      hipLaunchKernelGGL((k_integrate_cached<false, RR_K1C_CHUNK>), dim3((unsigned)(((S.n + 7) >> 3) << 6)), dim3(64), 0, st, T.n, F, V, B, S, 0, S.count, S.list, pair_masks, PC.items, PC);
       hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);
     }
     else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);

@@ -102,23 +102,27 @@ struct Bricks {
 
 // Projection cache (round 3).  texture(cv_xyz_inv[i], voxel centre).xyz -- the (u, v, z) a voxel projects to in stream i,
 // tsdf_integration.vs:31 -- depends on the calibration volume and the voxel grid only, never on the frame.  The LDS form of the
-// integrate kernel recomputes it every frame (texel box -> LDS -> X / Y passes -> z lerp: ~8 dependent round trips and ~17 workgroup
-// barriers per tile); with 288 GB of HBM it is cheaper to keep it: a pool of slots, one per cached tile, each [stream][voxel 0..511]
-// x 12 bytes (the tile's own voxel order: one coalesced 768-byte read per wave and stream), dealt on first use (slot[stored tile]).
-// A tile's slot is filled by the LDS form itself the first time the tile is integrated (write-through: the same bits), so a cached
-// tile integrates as: coalesced loads of (u, v, z) -> image gathers -> fusion rule in stream order -> store.  No LUT box, no passes,
-// no workgroup barrier.
+// integrate kernel recomputes it every frame (texel box -> LDS -> X pass -> Y pass -> z lerp: ~8 dependent round trips and ~17
+// workgroup barriers per tile); with 288 GB of HBM it is cheaper to keep most of it.  What is kept per (tile, stream) is the state
+// after the Y pass: the tile's x- and y-filtered LUT planes, dz_max planes of 8 x 8 float3 (the z filter of a voxel then is ONE lerp
+// of two of them -- the same operands, the same operation as the LDS form's last step, so the same bits).  dz planes instead of 8
+// voxel planes: 2.2 - 3.7 KiB instead of 6 KiB per tile and stream at the BASELINE sizes.  Slots are dealt on first use
+// (slot[stored tile]) and filled by the LDS kernel itself while it integrates the tile (write-through); from then on the tile is the
+// cached kernel's: per wave one z-plane of 64 voxels -- coalesced 768-byte plane reads, image gathers, fusion rule, 256-byte store.
+// No LUT texel, no LDS, no barrier.
 constexpr uint32_t kItemFresh = 0x80000000u;   // items[w] >= kItemFresh: not (yet) cached -- the LDS kernel's work; kItemFresh | slot: ... and it fills `slot`
 constexpr uint32_t kItemNone = 0xffffffffu;    // no slot (pool exhausted)
 struct ProjCache {
-  float* data;             // pool: slot s at s * slot_floats
+  float* data;             // pool: slot s at s * slot_floats; inside: [stream][plane < dz_max][8 x 8 voxels (x fastest)][3]
   uint32_t* slot;          // per STORED tile: its slot, or kNoSlot
   uint32_t* alloc;         // device scalar: slots handed out so far
   uint32_t cap;            // pool capacity in slots
-  uint32_t slot_floats;    // N * 512 * 3
+  uint32_t slot_floats;    // N * dz_max * 192
+  uint32_t dz_max;         // the most LUT z-planes any tile of the volume touches in any stream (fit_lut_to_volume, abi.cpp)
   uint32_t* items;         // per work item of this frame's launch: slot (cached), kItemFresh | slot (to be filled now), kItemNone
   uint32_t* n_slow;        // device scalar: work items of this frame the LDS kernel must take (0: it returns at once)
   uint32_t* n_slow_next;   // the other of the two alternating words, zeroed by this frame's pair-mask pass for the next frame
+  int inv_rz[TSDF_MAX_STREAMS];   // z resolution of each stream's inverse LUT (the cached kernel's only use of the calibration)
 };
 
 struct Mat4 { float m[16]; };   // column-major

@@ -65,9 +65,13 @@ def test_lds_box_near_its_capacity(rr, res, inv_res):
 
 @pytest.mark.parametrize("form", ["3", "2", "1", "0"])
 def test_all_three_integrate_kernels_give_the_same_volume(rr, small_scene, form, monkeypatch):
-    """RR_K1_FORM caps the kernel choice when a context is created: 3 = separable passes with one wave per tile and no workgroup
-    barrier (opt-in), 2 = separable LDS passes stream by stream (the default), 1 = direct 8-tap LDS form, 0 = every tap from global memory.  The choice is normally made from the LUT box size; each must be bit-identical."""
+    """RR_K1_FORM caps the kernel choice when a context is created: 3 = no cap, here with the opt-in projection cache on (RR_PROJ_CACHE_MB:
+    tiles integrated before are read back from the pool by k_integrate_cached), 2 = separable LDS passes stream by stream (the default
+    form), 1 = direct 8-tap LDS form, 0 = every tap from global memory.  The choice is normally made from the LUT box size; each must be
+    bit-identical."""
     monkeypatch.setenv("RR_K1_FORM", form)
+    if form == "3":
+        monkeypatch.setenv("RR_PROJ_CACHE_MB", "64")
     hip, orc = rr.ReconIntegrationHip(small_scene, **KW), OracleRecon(small_scene, **KW)
     for use_bricks in (True, False):
         for o in (hip, orc):
@@ -92,12 +96,16 @@ def test_nan_and_out_of_range_lut_coordinates_sample_like_the_oracle(rr):
     mv, pr = rr.scene.default_view(*KW["view"])
     for form in ("3", "2", "1", "0"):
         os.environ["RR_K1_FORM"] = form
+        if form == "3":
+            os.environ["RR_PROJ_CACHE_MB"] = "64"            # the opt-in projection cache: the second integrate() reads the pool
         try:
             hip, orc = rr.ReconIntegrationHip(sc, **KW), OracleRecon(sc, **KW)
         finally:
             del os.environ["RR_K1_FORM"]
+            os.environ.pop("RR_PROJ_CACHE_MB", None)
         for o in (hip, orc):
             o.setUseBricks(False)
+            o.integrate()
             o.integrate()
             o.drawF(mv, pr)
         assert_same(hip.tsdf(), orc.tsdf(), f"tsdf (form {form})")
@@ -222,3 +230,26 @@ def test_integrate_without_update_uses_the_last_occupied_list(rr):
     for o in (hip, orc):
         o.updateOccupiedBricks(); o.integrate(); o.drawF(mv, pr)         # now b's list
     compare(hip, orc)
+
+
+def test_contexts_release_their_device_memory(rr, small_scene):
+    """tsdf_destroy and setVoxelSize must give the TSDF volume back (a 512^3 volume is 512 MiB: a client that re-creates
+    contexts or changes the voxel size would run the device out of memory).  Free device memory after a create / integrate /
+    setVoxelSize / destroy loop equals what it was after the first such cycle."""
+    import torch
+
+    def cycle():
+        h = rr.ReconIntegrationHip(small_scene, res=(160, 160, 160), brick_size=0.2, limit=0.04, view=(64, 36), proj_cache_mib=32)
+        h.clearOccupiedBricks(); h.markBricks(); h.updateOccupiedBricks(); h.integrate(); h.integrate()
+        h.setVoxelSize(0.0125)                       # 160 x 176 x 160: a second, larger volume replaces the first
+        h.clearOccupiedBricks(); h.markBricks(); h.updateOccupiedBricks(); h.integrate()
+        h.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 20} MiB of device memory lost over 6 context cycles"

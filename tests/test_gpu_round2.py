@@ -356,7 +356,9 @@ def test_dense_integrate_uniform_pair_shortcut_equals_per_voxel_evaluation(rr, m
     frame, that every voxel takes the same branch of the fusion rule, and then skips the per-voxel gathers.  Against the same kernel
     with the shortcut off (RR_K1_RANGES=0) and against the oracle: plain frames, a frame with NaN / infinite / out-of-range LUT
     texels, NaN and negative depths, silhouettes that are neither 0 nor 1, zero quality (NaN voxels), and the raw-frame path."""
-    monkeypatch.setenv("RR_K1_FORM", form)      # 2: workgroup per tile, a wave classifies a stream; 3: wave per tile, a half wave classifies a stream
+    monkeypatch.setenv("RR_K1_FORM", form)      # 2: the LDS form; 3: + the opt-in projection cache (the second integrate() of a context reads the pool)
+    if form == "3":
+        monkeypatch.setenv("RR_PROJ_CACHE_MB", "64")
     base = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
     rng = np.random.default_rng(11)
     scenes = [base, rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2))]
@@ -383,6 +385,7 @@ def test_dense_integrate_uniform_pair_shortcut_equals_per_voxel_evaluation(rr, m
             for o in (fast, slow, orc):
                 o.setUseBricks(False)
                 o.integrate()
+            fast.integrate()
             a, b, c = fast.tsdf(), slow.tsdf(), orc.tsdf()
             assert same(a, b).all(), f"res {res} scene {k}: shortcut vs per-voxel"
             assert same(a, c).all(), f"res {res} scene {k}: shortcut vs oracle"
