@@ -8,10 +8,13 @@ A "step" is one frame of the reference's per-frame call order (source/kinect_cli
 clearOccupiedBricks -> mark_brick (K6) -> updateOccupiedBricks -> integrate (K0+K1) -> drawF
 (K5 depth limits, K2 raymarch, K3/K4 hole filling), with the frame images already resident in HBM.
 
-Scene.  Two frames of the same rig are resident (two device frame slots): A = the scene of SURVEY.md §8d, B = the same
-objects moved.  The timed region ALTERNATES them, so every step pays what a moving scene costs the incremental bookkeeping
-(every active tile of the previous frame goes stale and is reset, the image-space dirty tiles change); `value` is that
-moving-scene rate.  The static rate (the same frame every step: the best case) is reported beside it as `static`.
+Scene.  Two frames of the same rig -- A = the scene of SURVEY.md §8d, B = the same objects moved -- lie in HBM as the arrays the
+producer delivers (depth RG32F, quality, silhouette, colour RGB8).  Every timed step takes the OTHER one as a NEW frame, as the
+reference integrates only new frames (kinect_client.cpp:586-599): tsdf_upload_frame_dev re-lays it out for the kernels (one launch)
+and the frame is computed; the scene moves, so the incremental bookkeeping pays its worst case (every active tile of the previous
+frame goes stale and is reset, the image-space dirty tiles change).  `value` is that rate.  Beside it: `static` (frame A arrives
+every step: nothing moves) and `resident_frames` (round 1 / 2's definition: two already re-laid-out frames alternate, no
+per-frame re-layout).
 
 N > 1: the north-star partition -- ONE volume split into Z-slabs over the ranks (strong scaling: `value` = frames of the one
 volume per second), halo tile layers recomputed locally (default) or RCCL all-gathered, nearest-hit gather of one 32-byte record
@@ -76,7 +79,7 @@ def culled_integrate_bytes(np, hip, scenes, res, n_streams):
     averaged over the frames of the timed region.  (the dense formula only applies with use_bricks off.)"""
     tot, tiles_n = 0.0, []
     for k, sc in enumerate(scenes):
-        hip.select_frame_slot(k)
+        hip.select_frame_slot(k); hip.upload_frame(sc)       # (the timed loop re-lays new frames out into the current slot: put the scene back)
         hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate()
         tiles, _ = hip.active_tiles()
         touched = np.zeros((LUT, LUT, LUT), bool)
@@ -98,28 +101,35 @@ def culled_integrate_bytes(np, hip, scenes, res, n_streams):
 
 
 def cpu_baseline(scene, cfg, limit, brick):
-    """The oracle (kind "port": the reference has no CPU path) on the same workload at full size: three frames of
-    clear/mark/update bricks + integrate() + drawF() at the bench view, the fastest one reported (the first frame pays the
-    first touch of the volume)."""
-    from oracle.oracle import OracleRecon
+    """The oracle (kind "port": the reference has no CPU path) on the same workload at full size, with all host cores
+    and with ONE thread: clear/mark/update bricks + integrate() + drawF() at the bench view; all cores: the fastest of
+    three frames (the first pays the first touch of the volume), one thread: one frame after that."""
+    from oracle.oracle import OracleRecon, set_threads
     import rgbd_recon_amd as rr
     cores = os.cpu_count() or 1
     o = OracleRecon(scene, res=cfg["res"], brick_size=brick, limit=limit, view=VIEW)
     o.setUseBricks(cfg["use_bricks"]); o.setSpaceSkip(cfg["skip_space"]); o.setColorFilling(cfg["fill_holes"])
     mv, pr = rr.scene.default_view(*VIEW)
-    best = None
-    for _ in range(3):
+
+    def one():
         t0 = time.perf_counter()
         o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks()
         o.integrate()
         t1 = time.perf_counter()
         o.drawF(mv, pr)
         t2 = time.perf_counter()
-        if best is None or t2 - t0 < best[0]:
-            best = (t2 - t0, t1 - t0, t2 - t1)
-    return {"value": 1.0 / best[0], "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/libtsdf_oracle.so, OpenMP {cores} threads, fastest of 3 full-size frames of scene A: bricks+integrate {best[1]:.2f} s, "
-                      f"drawF at {VIEW[0]}x{VIEW[1]} {best[2]:.2f} s"}
+        return (t2 - t0, t1 - t0, t2 - t1)
+
+    threads = set_threads(0)                             # what OpenMP uses by default on this box
+    best = min(one() for _ in range(3))
+    set_threads(1)
+    single = one()
+    set_threads(threads)
+    return {"value": 1.0 / best[0], "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/libtsdf_oracle.so, OpenMP {threads} threads ({cores} logical CPUs), fastest of 3 full-size frames of scene A: bricks+integrate {best[1]:.2f} s, "
+                      f"drawF at {VIEW[0]}x{VIEW[1]} {best[2]:.2f} s",
+            "one_thread": {"value": 1.0 / single[0], "unit": "frames/s", "cores": 1,
+                           "sample": f"the same frame with one thread: bricks+integrate {single[1]:.2f} s, drawF {single[2]:.2f} s"}}
 
 
 def same(np, a, b):
@@ -268,8 +278,20 @@ def main():
                         preprocess=args.preprocess, exchange_when_alone=alone, stream=stream, compositor="dedicated" if dedicated else "shared")
     mv, pr = rr.scene.default_view(*VIEW)
     nsc = len(scenes)
+    # the frames as they arrive, resident in HBM before anything is timed: every step re-lays one of them out (tsdf_upload_frame_dev) --
+    # except in the pre-processing / ingest modes (they produce the images themselves) and the frames-in-flight throughput mode
+    repack = not (args.preprocess or args.frames_in_flight > 1)
+    raw = []
+    if repack:
+        for sc in scenes:
+            ts = [torch.from_numpy(np.ascontiguousarray(sc[k])).to(f"cuda:{local}") for k in ("depth", "quality", "silhouette", "color")]
+            raw.append((ts, tuple(t.data_ptr() for t in ts)))
+        torch.cuda.synchronize()
 
     def step(d, i):
+        if repack:
+            d.frame(mv, pr, new_frame=raw[i % nsc][1])
+            return
         if nsc > 1:
             d.b.select_frame_slot(i % nsc)
         d.frame(mv, pr)
@@ -337,6 +359,7 @@ def main():
         hip.upload_frame(scene)
     hip.sync()
     upload_ms = (time.perf_counter() - tu0) / 5 * 1e3
+    warmup_effective = max(800, args.warmup)
     for i in range(args.warmup):
         step(drv, i)
     # The HIP runtime has a one-time stall of ~18 ms a few thousand launches into a process (measured: 600 timed steps after 20
@@ -358,7 +381,7 @@ def main():
             step(drv, i)
         barrier()
         hip.enable_timers(False)
-        for name in ("0ingest", "1preprocess", "bricks", "2integrate", "k_pair_masks", "k_integrate_tiles", "brickdraw", "draw", "k_march", "holefill", "3recon"):
+        for name in ("0ingest", "0repack", "1preprocess", "bricks", "2integrate", "k_pair_masks", "k_integrate_tiles", "brickdraw", "draw", "k_march", "holefill", "3recon"):
             n, ms = hip.timer_stats(name)
             if n:
                 stages[name] = ms / n
@@ -409,13 +432,28 @@ def main():
 
     # the static scene (best case of the incremental bookkeeping: nothing churns), same number of steps
     static = None
+    resident = None
     if nsc > 1:
         def st(i):
-            drv.frame(mv, pr)
+            drv.frame(mv, pr, new_frame=raw[0][1] if repack else None)
         hip.select_frame_slot(0)
         timed(20, st)
         ds = timed(args.steps, st)
-        static = {"value": args.steps / ds, "ms_per_step": ds / args.steps * 1e3, "note": "frame A every step: no tile goes stale, the dirty-tile history is a no-op"}
+        static = {"value": args.steps / ds, "ms_per_step": ds / args.steps * 1e3,
+                  "note": "frame A arrives every step (re-laid out every time): no tile goes stale, the dirty-tile history is a no-op"}
+    if nsc > 1 and repack:
+        # rounds 1 / 2 defined `value` without the per-frame re-layout: two already re-laid-out frames in the two frame slots alternate
+        for k, sc in enumerate(scenes):
+            hip.select_frame_slot(k); hip.upload_frame(sc)
+
+        def rs(i):
+            hip.select_frame_slot(i % nsc)
+            drv.frame(mv, pr)
+        timed(20, rs)
+        dr = timed(args.steps, rs)
+        hip.select_frame_slot(0)
+        resident = {"value": args.steps / dr, "ms_per_step": dr / args.steps * 1e3,
+                    "note": "two frames already in the kernels' layout alternate (tsdf_select_frame_slot): the definition of `value` in rounds 1 and 2"}
     long_run = None
     if args.long_steps and args.frames_in_flight == 1:
         dl = timed(args.long_steps, lambda i: step(drv, i))
@@ -428,9 +466,9 @@ def main():
         hip.set_timer_filter(["frame"])
         hip.enable_timers(True)
         for i in range(100):
-            if nsc > 1:
+            if nsc > 1 and not repack:
                 hip.select_frame_slot(i % nsc)
-            hip.timer_begin("frame"); drv.frame(mv, pr); hip.timer_end("frame")
+            hip.timer_begin("frame"); step(drv, i); hip.timer_end("frame")
         barrier()
         hip.enable_timers(False)
         hip.set_timer_filter(None)
@@ -447,23 +485,28 @@ def main():
         stages_rank0, stages, ratio = stages, infos[1]["stage_ms"], infos[1]["ratio"]
     out = {
         "metric": "frames/sec (integrate+raymarch) at %d^3 x %d streams" % (cfg["res"][0], n_streams),
-        "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_effective": warmup_effective,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "config": args.config, "streams": n_streams, "res": list(cfg["res"]),
                    "view": list(VIEW), "limit": LIMIT, "occupied_brick_ratio": ratio, "preprocess": bool(args.preprocess),
-                   "scene": "two resident frames alternating every step (objects moved: every active tile churns)" if nsc > 1 else "one static frame",
+                   "scene": (("a NEW frame every step (two frames resident in HBM as delivered -- depth RG32F, quality, silhouette, RGB8 -- alternate; each is re-laid "
+                              "out by tsdf_upload_frame_dev inside the step); objects moved: every active tile churns") if repack else
+                             "two resident frames alternating every step (objects moved: every active tile churns)") if nsc > 1 else "one static frame",
                    "frames_in_flight": args.frames_in_flight,
                    "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
                    "parallelism": ((f"single GPU holding slab {alone_slab} of the volume, " if alone_slab else "single GPU, ") + "slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else
                                   (f"ONE volume in {world - 1} Z-slab(s) on ranks 1..{world - 1} + rank 0 as dedicated compositor (receive, composite, hole filling)" if dedicated else
                                    f"ONE volume in {world} Z-slabs") + f" (strong scaling; slab boundaries {partition_note}; this rank's voxel planes {list(slab)}), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame"},
         "static": static,
+        "resident_frames": resident,
         "long_run": long_run,
         "stage_ms": stages,
         **({"stage_ms_compositor": stages_rank0} if stages_rank0 is not None else {}),
         "frame_device_ms": frame_ms,
-        "stage_ms_note": "per-stage device time from a separate all-timers pass before the timed region (not part of `value`)",
+        "stage_ms_note": "per-stage device time from a separate all-timers pass before the timed region (every recorded event costs ~1 us of stream time, so their sum "
+                         "exceeds ms_per_step a little): 0repack + bricks + 2integrate + 3recon = the frame; k_pair_masks / k_integrate_tiles lie inside 2integrate, "
+                         "brickdraw / draw / k_march / holefill inside 3recon",
         "upload_ms_per_frame": upload_ms,
         "pcie_inclusive_frames_per_s": 1e3 / (upload_ms + dt / args.steps * 1e3),
     }
@@ -514,10 +557,30 @@ def main():
             alg, note = db["integrate"], "dense launch: 4V + N*16*L + N*16*P (BASELINE.md section 3)"
         else:
             alg, note = db["march"], "dense march: 4V + 24R (BASELINE.md section 3); with depth limits the rays sample only inside occupied bricks, so this is an upper figure"
-        if dom == "k_integrate_tiles" and "k_pair_masks" in stages:
-            note += (f"; the launch reads its (tile, stream) pair classes from the pair-mask pass that runs right before it (k_pair_masks, {stages['k_pair_masks'] * 1e3:.1f} us, "
-                     "timed on its own: stage_ms)")
         out["roofline"] = roofline(dom, alg, dom_ms, args.config, note)
+        if dom == "k_integrate_tiles" and "k_pair_masks" in stages:
+            # the launch reads its (tile, stream) pair classes from the pair-mask pass that runs right before it: kernel + helper together
+            both = dom_ms + stages["k_pair_masks"]
+            out["roofline"]["with_helper"] = {"kernels": "k_pair_masks + k_integrate_tiles_lds", "ms": both, "frac": alg / (both * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "note": f"k_pair_masks {stages['k_pair_masks'] * 1e3:.1f} us from the all-timers pass (its two events included)"}
+        if cfg["use_bricks"] and cfg["fill_holes"] and args.frames_in_flight == 1:
+            # the whole frame: algorithmic bytes of every stage (with the culled launches counted by the units they process)
+            if dom != "k_integrate_tiles":
+                alg_i, tiles_n = culled_integrate_bytes(np, hip, scenes, cfg["res"], n_streams)
+            else:
+                alg_i = alg
+            P, Pc, R = 640 * 480, 640 * 480, VIEW[0] * VIEW[1]
+            T = sum(tiles_n) / len(tiles_n)
+            parts = {"repack": ((16 * P + 3 * Pc) + (20 * P + 4 * Pc)) * n_streams if repack else 0,      # arrays in, packed texel + depth plane + RGBA8 out
+                     "bricks": 4 * n_streams * P,                                                        # K6 reads the depth plane
+                     "integrate": alg_i,
+                     "raymarch": 2048 * T + 24 * R + 15 * n_streams * P,                                 # 4V of SURVEY 8d -> the active tiles' 2 KiB
+                     "inpaint_colorfill": 67 * R}
+            fb = float(sum(parts.values()))
+            ms = dt / args.steps * 1e3
+            out["roofline_frame"] = {"bound": "hbm", "bytes": fb, "stage_bytes": parts, "ms_per_step": ms, "achieved": fb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "note": "sum of the stages' algorithmic bytes (SURVEY.md section 8d; culled launches by the units they process) / the timed step"}
     if world > 1:
         # N > 1: the same object for the slowest slab launch (every rank that owns a slab measures its own; counters -- `traffic` -- were
         # only collected on one GPU).  Only culled integrate launches: the units are the slab's active tiles (halo layers it recomputes included)

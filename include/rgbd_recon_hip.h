@@ -108,6 +108,12 @@ int32_t tsdf_set_calibration(tsdf_ctx* ctx, uint32_t stream,
 int32_t tsdf_upload_frame(tsdf_ctx* ctx, const float* depth_rg, const float* quality,
                           const float* silhouette, const uint8_t* colour_rgb);
 
+/* The same frame from DEVICE memory (arrays produced on the GPU, or staged there by the caller): no copy, one re-layout launch on the
+ * context's stream into the current frame slot -- what a new frame costs the path itself; integrate() is handed a new frame every
+ * time in the reference (kinect_client.cpp:586-599, NetKinectArray.cpp:225-236).  Pointers aligned to their element size. */
+int32_t tsdf_upload_frame_dev(tsdf_ctx* ctx, const float* depth_rg_dev, const float* quality_dev,
+                              const float* silhouette_dev, const uint8_t* colour_rgb_dev);
+
 /* Asynchronous upload: NetKinectArray keeps the incoming frame in a double-buffered, mapped PBO (framework/double_pixel_buffer.cpp:18-81:
  * the reader thread memcpy's into the back buffer, NetKinectArray.cpp:516-520; update() swaps and starts the PBO -> texture
  * DMA, :225-236).  Here: two device frame slots, a pinned host staging ring and a copy stream.

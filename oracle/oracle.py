@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libtsdf_oracle.so")
+_LIB = os.environ.get("RGBDR_ORACLE_LIB", os.path.join(_HERE, "libtsdf_oracle.so"))   # override: the sanitizer build (tests/test_oracle_sanitizers.py)
 
 
 class OrcConfig(C.Structure):
@@ -46,6 +46,11 @@ def lib():
         L.orc_tex2d_nearest.restype = C.c_float
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the oracle's parallel loops from now on (bench.py: 1-thread and all-cores CPU baselines); returns the previous maximum"""
+    return int(lib().orc_set_threads(int(n)))
 
 
 def _p(a, t=C.c_float):

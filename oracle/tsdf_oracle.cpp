@@ -28,6 +28,9 @@
 #include <cstring>
 #include <limits>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace {
 
@@ -531,6 +534,38 @@ static void depth_limits(orc_ctx* c, const view_mats& V) {
         faces.push_back(f);
       }
   }
+  // Which faces can a pixel see at all?  A face whose four corners lie in front of the eye projects into the bounding box of its projected
+  // corners (the rectangle is convex, the projection of its points is then inside the projected corners' hull); bin the faces into
+  // 16x16-pixel screen tiles by that box (two pixels of margin for the rounding of the projection; a face with a corner at or behind the
+  // eye plane goes into every tile).  The per-pixel, per-face arithmetic below is unchanged and MIN blending is order independent: the
+  // peels are the same bits as with every pixel testing every face -- a rasteriser does not do that either.
+  constexpr uint32_t kBin = 16;
+  const uint32_t btx = (w + kBin - 1) / kBin, bty = (h + kBin - 1) / kBin;
+  std::vector<std::vector<uint32_t>> bins((size_t)btx * bty);
+  for (uint32_t fi = 0; fi < faces.size(); ++fi) {
+    const face& f = faces[fi];
+    const int a = f.axis, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+    float x0 = 1e30f, y0 = 1e30f, x1 = -1e30f, y1 = -1e30f;
+    bool all_front = true;
+    for (int k = 0; k < 4; ++k) {
+      float cp[3]; cp[a] = f.coord; cp[a1] = (k & 1) ? f.hi[a1] : f.lo[a1]; cp[a2] = (k & 2) ? f.hi[a2] : f.lo[a2];
+      const vec4 e = mul(V.mv, {cp[0], cp[1], cp[2], 1.0f});
+      const vec4 cl = mul(V.proj, e);
+      if (!(cl.w > 1e-4f)) { all_front = false; break; }
+      const float sx = (cl.x / cl.w * 0.5f + 0.5f) * (float)w, sy = (cl.y / cl.w * 0.5f + 0.5f) * (float)h;
+      x0 = fminf(x0, sx); x1 = fmaxf(x1, sx); y0 = fminf(y0, sy); y1 = fmaxf(y1, sy);
+    }
+    long bx0 = 0, by0 = 0, bx1 = (long)btx - 1, by1 = (long)bty - 1;
+    if (all_front && x0 == x0 && x1 == x1 && y0 == y0 && y1 == y1) {
+      if (x1 < -2.0f || y1 < -2.0f || x0 > (float)w + 2.0f || y0 > (float)h + 2.0f) continue;          // off screen
+      bx0 = std::max(0L, (long)floorf(x0 - 2.0f) / (long)kBin); by0 = std::max(0L, (long)floorf(y0 - 2.0f) / (long)kBin);
+      bx1 = std::min((long)btx - 1, (long)floorf(x1 + 2.0f) / (long)kBin); by1 = std::min((long)bty - 1, (long)floorf(y1 + 2.0f) / (long)kBin);
+      if (x0 - 2.0f < 0.0f) bx0 = 0;
+      if (y0 - 2.0f < 0.0f) by0 = 0;
+    }
+    for (long by = by0; by <= by1; ++by)
+      for (long bx = bx0; bx <= bx1; ++bx) bins[(size_t)by * btx + bx].push_back(fi);
+  }
 #pragma omp parallel for schedule(dynamic, 4)
   for (long py = 0; py < (long)h; ++py)
     for (uint32_t px = 0; px < w; ++px) {
@@ -539,7 +574,8 @@ static void depth_limits(orc_ctx* c, const view_mats& V) {
       vec4 ed = {p.x / p.w, p.y / p.w, p.z / p.w, 0.0f};
       vec4 wd = mul(V.mv_inv, ed);
       const float o[3] = {V.cam_world.x, V.cam_world.y, V.cam_world.z}, d[3] = {wd.x, wd.y, wd.z};
-      for (const face& f : faces) {
+      for (const uint32_t fi : bins[(size_t)(py / kBin) * btx + px / kBin]) {
+        const face& f = faces[fi];
         const int a = f.axis, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
         float t = (f.coord - o[a]) / d[a];
         if (!(t > 0.0f)) continue;
@@ -886,6 +922,16 @@ void orc_set_raw_frame(orc_ctx* c, const float* raw_depth, const uint8_t* color_
 void orc_set_depth_limits(orc_ctx* c, uint32_t i, float mn, float mx) { c->cv_min_d[i] = mn; c->cv_max_d[i] = mx; }
 void orc_set_camera_position(orc_ctx* c, uint32_t i, const float* p) { c->cam_pos[i] = {p[0], p[1], p[2]}; }
 // NetKinectArray.cpp:343-349: compress = isCompressedDepth(); scale = far - near; scaled_near = scale / 255.0f
+// OpenMP threads of every parallel region from now on (bench.py's 1-thread and all-cores CPU baselines); returns the previous maximum
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  const int old = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  return old;
+#else
+  (void)n; return 1;
+#endif
+}
 void orc_set_depth_compression(orc_ctx* c, uint32_t i, int compress, float near_, float far_) {
   const float scale = far_ - near_;
   c->compress[i] = compress != 0; c->dc_near[i] = near_; c->dc_scale[i] = scale; c->dc_scaled_near[i] = scale / 255.0f;

@@ -769,12 +769,28 @@ int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quali
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_depth, depth_rg, np * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_q, quality, np * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_s, silhouette, np * 4, hipMemcpyHostToDevice, c->stream));
-  launch_pack_frame(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, (float*)c->frame.depth, np);
-  launch_frame_ranges(c->stream, F.dqs, (int)c->cfg.num_streams, F.w, F.h, c->slots[c->cur_slot].ranges);
-  if (colour) {
-    HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
-    launch_pack_color(c->stream, c->d_stage_col, (uchar4*)F.color, nc);
-  }
+  if (colour) HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
+  launch_pack_frame_fused(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, (float*)c->frame.depth, c->slots[c->cur_slot].ranges,
+                          (int)c->cfg.num_streams, F.w, F.h, colour ? c->d_stage_col : nullptr, (uchar4*)F.color, nc);
+  HIP_TRY(c, hipGetLastError());
+  c->slots[c->cur_slot].have = true;
+  return TSDF_OK;
+}
+// The same with the four arrays already in device memory (a producer on the GPU: the pre-processing of another library, a decoder, a
+// staging buffer the caller DMA'd himself): no copy, one re-layout launch on the context's stream into the current frame slot.  This is
+// what a NEW frame costs the path itself (NetKinectArray hands integrate() a new frame every time, kinect_client.cpp:586-599).
+int32_t tsdf_upload_frame_dev(tsdf_ctx* c, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour) {
+  CHECK_CTX(c);
+  if (!depth_rg || !quality || !silhouette) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "depth, quality and silhouette are required");
+  if (((uintptr_t)depth_rg & 7u) || ((uintptr_t)quality & 3u) || ((uintptr_t)silhouette & 3u) || ((uintptr_t)colour & 3u))
+    FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "device arrays must be aligned to their element size (depth 8 bytes, the others 4)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const FrameImages& F = c->frame;
+  const size_t nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
+  timer_begin(c, "0repack");
+  launch_pack_frame_fused(c->stream, depth_rg, quality, silhouette, (float4*)F.dqs, (float*)c->frame.depth, c->slots[c->cur_slot].ranges,
+                          (int)c->cfg.num_streams, F.w, F.h, colour, (uchar4*)F.color, nc);
+  timer_end(c, "0repack");
   HIP_TRY(c, hipGetLastError());
   c->slots[c->cur_slot].have = true;
   return TSDF_OK;
@@ -830,9 +846,8 @@ int32_t tsdf_upload_frame_async(tsdf_ctx* c, const float* depth_rg, const float*
   HIP_TRY(c, hipMemcpyAsync(c->d_astage, c->h_stage[k], bytes, hipMemcpyHostToDevice, c->copy_stream));
   HIP_TRY(c, hipEventRecord(c->stage_done[k], c->copy_stream));
   c->stage_busy[k] = true; c->stage_k ^= 1;
-  launch_pack_frame(c->copy_stream, (const float*)c->d_astage, (const float*)(c->d_astage + np * 8), (const float*)(c->d_astage + np * 12), S.dqs, S.depth, np);
-  launch_frame_ranges(c->copy_stream, S.dqs, (int)c->cfg.num_streams, c->frame.w, c->frame.h, S.ranges);
-  if (with_colour) launch_pack_color(c->copy_stream, c->d_astage + np * 16, S.color, nc);
+  launch_pack_frame_fused(c->copy_stream, (const float*)c->d_astage, (const float*)(c->d_astage + np * 8), (const float*)(c->d_astage + np * 12), S.dqs, S.depth, S.ranges,
+                          (int)c->cfg.num_streams, c->frame.w, c->frame.h, with_colour ? c->d_astage + np * 16 : nullptr, S.color, nc);
   HIP_TRY(c, hipEventRecord(S.ready, c->copy_stream));
   S.pending = true; S.have = true;
   HIP_TRY(c, hipGetLastError());

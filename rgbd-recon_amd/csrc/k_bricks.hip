@@ -1,5 +1,5 @@
 // Frame packing + brick occupancy kernels (gfx950).
-//   pack_frame / pack_color : upload-side re-layout into the HBM-resident image formats
+//   pack_frame_fused / pack_color / frame_ranges : upload-side re-layout into the HBM-resident image formats
 //   mark_bricks             : pre_normal.fs:22-33 call site of mark_brick(), inc_bricks.glsl:40-58
 //   update_occupied         : updateOccupiedBricks(), recon_integration.cpp:430-445, without the host round trip
 #include "sampling.hpp"
@@ -7,14 +7,6 @@
 
 namespace rr {
 
-__global__ __launch_bounds__(256) void k_pack_frame(const float2* __restrict__ depth_rg, const float* __restrict__ quality,
-                                                    const float* __restrict__ silhouette, float4* __restrict__ dqs, float* __restrict__ depth, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float d = depth_rg[i].x;
-    dqs[i] = make_float4(d, quality[i], silhouette[i], 0.0f);
-    depth[i] = d;
-  }
-}
 // Per 8x8-pixel cell of the packed {depth, quality, silhouette} image: {min depth, max depth, min silhouette, max silhouette}.  One wave per
 // cell (a lane per pixel), four cells per workgroup.  A NaN anywhere in a cell poisons its range to (-inf, +inf): the consumer's tests
 // then fail and it falls back to the per-voxel evaluation.
@@ -46,6 +38,57 @@ __global__ __launch_bounds__(256) void k_pack_color(const uint8_t* __restrict__ 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     rgba[i] = make_uchar4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 255);
 }
+// The three of them in ONE launch (round 3): what has to happen to a NEW frame before the path can read it -- NetKinectArray hands the
+// path a new frame per integrate(), kinect_client.cpp:586-599 -- is its re-layout, and as three dependent launches (11.5 + 8.4 + 5.0 us at
+// 4 x 640 x 480) it cost an eighth of the frame.  Blocks [0, cell_blocks): one wave per 8x8-pixel cell reads its 64 pixels of the three
+// source arrays, writes the packed texel and the depth plane and reduces the cell's range (DPP); the remaining blocks turn RGB8 into RGBA8,
+// four pixels per thread (12 bytes in, 16 out).  HBM bound: 23.4 MB in, 29.8 MB out at c2.
+__global__ __launch_bounds__(256) void k_pack_frame_fused(const float2* __restrict__ depth_rg, const float* __restrict__ quality, const float* __restrict__ silhouette,
+                                                          float4* __restrict__ dqs, float* __restrict__ depth, float4* __restrict__ ranges, int n_streams, int w, int h,
+                                                          int rcw, int rch, int cell_blocks, const uint8_t* __restrict__ rgb, uchar4* __restrict__ rgba, uint32_t n_quads, uint32_t n_px) {
+  if ((int)blockIdx.x >= cell_blocks) {                                  // ---- colour (rgb == nullptr: the grid has no such blocks)
+    const uint32_t q = (blockIdx.x - (uint32_t)cell_blocks) * blockDim.x + threadIdx.x;   // pixels 4q .. 4q + 3
+    if (q >= n_quads) return;
+    if (4u * q + 4u > n_px) {                                            // the last, partial quad: byte by byte
+      for (uint32_t k = 4u * q; k < n_px; ++k) rgba[k] = make_uchar4(rgb[3 * k], rgb[3 * k + 1], rgb[3 * k + 2], 255);
+      return;
+    }
+    const uint3 s = ((const uint3*)rgb)[q];                              // bytes r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+    uint4 o;
+    o.x = (s.x & 0x00ffffffu) | 0xff000000u;
+    o.y = (s.x >> 24) | ((s.y & 0x0000ffffu) << 8) | 0xff000000u;
+    o.z = (s.y >> 16) | ((s.z & 0x000000ffu) << 16) | 0xff000000u;
+    o.w = (s.z >> 8) | 0xff000000u;
+    ((uint4*)rgba)[q] = o;
+    return;
+  }
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+  if (cell >= n_streams * rcw * rch) return;
+  // four cells of a workgroup lie side by side in x: a row of the block is 32 consecutive pixels
+  const int i = cell / (rcw * rch), r = cell % (rcw * rch), cy = r / rcw, cx = r % rcw;
+  const int px = cx * 8 + (ln & 7), py = cy * 8 + (ln >> 3);
+  const float inf = __builtin_inff();
+  float d0 = inf, d1 = -inf, s0 = inf, s1 = -inf;
+  bool nan = false;
+  if (px < w && py < h) {
+    const size_t p = ((size_t)i * h + py) * w + px;
+    const float d = depth_rg[p].x, q = quality[p], s = silhouette[p];
+    dqs[p] = make_float4(d, q, s, 0.0f);
+    depth[p] = d;
+    d0 = d1 = d; s0 = s1 = s;
+    nan = (d != d) || (s != s);
+  }
+  d0 = wave_min_f32(d0); d1 = wave_max_f32(d1); s0 = wave_min_f32(s0); s1 = wave_max_f32(s1);
+  if (__ballot(nan) != 0ull) { d0 = s0 = -inf; d1 = s1 = inf; }          // a NaN anywhere poisons the cell's range (k_frame_ranges)
+  if (ln == 0) ranges[cell] = make_float4(d0, d1, s0, s1);
+}
+void launch_pack_frame_fused(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, float4* ranges,
+                             int n_streams, int w, int h, const uint8_t* rgb, uchar4* rgba, size_t n_color_px) {
+  const int rcw = (w + 7) / 8, rch = (h + 7) / 8, cells = n_streams * rcw * rch, cell_blocks = (cells + 3) / 4;
+  const uint32_t n_quads = rgb ? (uint32_t)((n_color_px + 3) / 4) : 0u;
+  hipLaunchKernelGGL(k_pack_frame_fused, dim3((unsigned)cell_blocks + (n_quads + 255) / 256), dim3(256), 0, st, (const float2*)depth_rg, quality, silhouette, dqs, depth, ranges,
+                     n_streams, w, h, rcw, rch, cell_blocks, rgb, rgba, n_quads, (uint32_t)n_color_px);
+}
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* __restrict__ p, uint32_t v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -53,9 +96,6 @@ __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* __restrict__ p, uint
 static inline int grid_for(size_t n, int block = 256, int cap = 2048) {
   size_t g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
-}
-void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, size_t n) {
-  hipLaunchKernelGGL(k_pack_frame, dim3(grid_for(n)), dim3(256), 0, st, (const float2*)depth_rg, quality, silhouette, dqs, depth, n);
 }
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n) {
   hipLaunchKernelGGL(k_pack_color, dim3(grid_for(n)), dim3(256), 0, st, rgb, rgba, n);

@@ -282,14 +282,6 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 // The classes of a launch are worked out by a pass of its own (k_pair_masks, below) and read by the integrate kernels with one scalar
 // load per work item.
 constexpr int kPairFull = 0, kPairCarve = 1, kPairNeg = 2, kPairNop = 3;
-__device__ __forceinline__ float wave_min_f32(float v) {          // DPP row shifts + row broadcasts, result wave-uniform (see k_raymarch.hip)
-#define RR_DPP_MIN(ctrl, rm, bm) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rm, bm, false)))
-  RR_DPP_MIN(0x111, 0xf, 0xf); RR_DPP_MIN(0x112, 0xf, 0xf); RR_DPP_MIN(0x114, 0xf, 0xe); RR_DPP_MIN(0x118, 0xf, 0xc);
-  RR_DPP_MIN(0x142, 0xa, 0xf); RR_DPP_MIN(0x143, 0xc, 0xf);
-#undef RR_DPP_MIN
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
 // Per (tile, stream) the (u, v, z) range over the tile's LUT texel box -- static: it depends on the calibration volume and the voxel
 // grid only -- is computed once (k_tile_bounds, below) as two float4 {u0, u1, v0, v1}, {z0, z1, -, -}; NaN marks a box with a
 // non-finite or far-away texel.  The class of (tile, stream) for THIS frame is worked out by a half wave (two streams per call, up to

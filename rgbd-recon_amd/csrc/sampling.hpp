@@ -153,6 +153,17 @@ __device__ __forceinline__ float tsdf_fetch(const Volume& V, const TsdfTaps& t) 
 template <bool kSparse, bool kWhole = false>
 __device__ __forceinline__ float tex3d_tsdf(const Volume& V, float u, float v, float w) { return tsdf_fetch<kSparse>(V, tsdf_taps<kWhole>(V, u, v, w)); }
 
+// wave-wide min / max of a float: DPP row shifts + row broadcasts (8 VALU + 1 v_readlane), result wave-uniform.  fminf semantics: a NaN
+// operand is ignored.
+__device__ __forceinline__ float wave_min_f32(float v) {          // DPP row shifts + row broadcasts, result wave-uniform (see k_raymarch.hip)
+#define RR_DPP_MIN(ctrl, rm, bm) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rm, bm, false)))
+  RR_DPP_MIN(0x111, 0xf, 0xf); RR_DPP_MIN(0x112, 0xf, 0xf); RR_DPP_MIN(0x114, 0xf, 0xe); RR_DPP_MIN(0x118, 0xf, 0xc);
+  RR_DPP_MIN(0x142, 0xa, 0xf); RR_DPP_MIN(0x143, 0xc, 0xf);
+#undef RR_DPP_MIN
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
+
 __device__ __forceinline__ float4 mat_mul(const Mat4& a, float x, float y, float z, float w) {
   return make_float4(a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w,
                      a.m[1] * x + a.m[5] * y + a.m[9] * z + a.m[13] * w,

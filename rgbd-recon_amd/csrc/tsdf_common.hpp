@@ -207,9 +207,11 @@ void launch_wire_unpack(hipStream_t st, const WireLayout& L, uchar4* rgba, float
 void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR);
 
 // launchers (one per kernel family, defined in the .hip files)
-void launch_pack_frame(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, size_t n);
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);
 void launch_frame_ranges(hipStream_t st, const float4* dqs, int n_streams, int w, int h, float4* ranges);
+// pack_frame + frame_ranges (+ pack_color when rgb != nullptr) as one launch; rgb / rgba must be readable / writable up to a multiple of 4 pixels
+void launch_pack_frame_fused(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, float4* ranges,
+                             int n_streams, int w, int h, const uint8_t* rgb, uchar4* rgba, size_t n_color_px);
 void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
 void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B);
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, uint32_t* next_count);

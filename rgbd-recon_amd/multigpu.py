@@ -223,12 +223,16 @@ class SlabDriver:
             b.fillColors()
 
     # ------------------------------------------------------------------ per frame
-    def frame(self, mv, proj):
+    def frame(self, mv, proj, new_frame=None):
+        """new_frame: device pointers (depth_rg, quality, silhouette, colour) of a frame that has just arrived in device memory -- the
+        ranks that own a slab re-lay it out first (tsdf_upload_frame_dev: what a new frame costs the path itself)"""
         with self._on_stream():
-            self._frame(mv, proj)
+            self._frame(mv, proj, new_frame)
 
-    def _frame(self, mv, proj):
+    def _frame(self, mv, proj, new_frame=None):
         b = self.b
+        if self.is_worker and new_frame is not None:
+            b.upload_frame_dev(*new_frame)
         if self.is_worker:
             b.clearOccupiedBricks()
             if self.preprocess:
