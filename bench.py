@@ -371,9 +371,18 @@ def main():
 
     # Stage breakdown, OUTSIDE the timed region: every recorded HIP event costs a few microseconds of stream time, so the full set
     # of timers runs on its own short pass ...
+    # The stage and kernel timers -- and with them the roofline -- come from NON-overlapped passes: by default fillColors() of frame f runs on
+    # its own stream beside the brick passes and the integrate of frame f + 1 (stage overlap), which stretches every kernel it shares the
+    # machine with; tsdf_set_stage_overlap(0) queues everything on the one stream for these passes, the timed region runs as shipped
+    overlap = os.environ.get("RR_OVERLAP_FILL", "1") != "0" and cfg["fill_holes"] and args.frames_in_flight == 1
+    every = slots if not slabs_mode else [drv]
     stages = {}
     dom = None
+    serial = None
+    dom_ms_serial = None
     if not args.no_timers:
+        for d in every:
+            d.b.set_stage_overlap(False)
         hip.set_timer_filter(None)
         hip.enable_timers(True)
         nb = max(10, min(50, args.steps))
@@ -389,10 +398,31 @@ def main():
         dom = max(cands, key=lambda k: stages[k]) if cands else None
         if world > 1 and "k_integrate_tiles" in stages:
             dom = "k_integrate_tiles"       # N > 1: every slab rank times the same kernel (a thin slab's march can outlast its integrate launch)
-        # ... and the timed region records only the dominant kernel's two events per frame (the roofline's live measurement)
+        # ... the dominant kernel alone (two events per frame) over args.steps non-overlapped frames: the roofline's measurement, and the
+        # rate of the frame without stage overlap ...
         if dom:
-            hip.timer_reserve(dom, args.steps)       # no hipEventCreate inside the timed loop
+            hip.timer_reserve(dom, 2 * args.steps)       # no hipEventCreate inside the timed loops
             hip.set_timer_filter([dom])
+        barrier()
+        stride_s = max(1, args.steps // 200)
+        ts0 = time.perf_counter()
+        for i in range(args.steps):
+            hip.enable_timers(bool(dom) and i % stride_s == 0)
+            step(drv, i)
+        barrier()
+        dts = time.perf_counter() - ts0
+        hip.enable_timers(False)
+        if dom:
+            n, ms = hip.timer_stats(dom)
+            dom_ms_serial = ms / n if n else None
+        serial = {"value": args.steps / dts, "ms_per_step": dts / args.steps * 1e3,
+                  "note": "stage overlap off (tsdf_set_stage_overlap(0)): every kernel of the frame on one stream, as in rounds 1 and 2; the roofline's kernel time comes from this pass"}
+        for d in every:
+            d.b.set_stage_overlap(overlap)
+        for i in range(20):                               # back into the overlapped steady state
+            step(drv, i)
+        # ... and the timed region records the same two events per frame in situ
+        if dom:
             hip.enable_timers(True)
     barrier()
     # at most ~200 event pairs in flight: many hundreds of un-synchronised events slow the launch path down (600 steps with an
@@ -418,9 +448,11 @@ def main():
 
     dt = max_over_ranks(dt)
     dom_ms = None
+    dom_ms_insitu = None
     if dom:
         n, ms = hip.timer_stats(dom)
-        dom_ms = ms / n if n else None
+        dom_ms_insitu = ms / n if n else None
+        dom_ms = dom_ms_serial if dom_ms_serial else dom_ms_insitu
 
     def timed(n_steps, sel):
         barrier()
@@ -468,14 +500,16 @@ def main():
         for i in range(100):
             if nsc > 1 and not repack:
                 hip.select_frame_slot(i % nsc)
-            hip.timer_begin("frame"); step(drv, i); hip.timer_end("frame")
+            hip.timer_begin("frame"); step(drv, i); hip.timer_end_after_fill("frame")
         barrier()
         hip.enable_timers(False)
         hip.set_timer_filter(None)
         smp = np.sort(hip.timer_samples("frame"))
         if smp.size:
             frame_ms = {"frames": int(smp.size), "median": float(np.median(smp)), "p95": float(smp[min(smp.size - 1, int(0.95 * smp.size))]),
-                        "min": float(smp[0]), "max": float(smp[-1]), "note": "HIP events around whole frames on rank 0, separate pass after the timed region"}
+                        "min": float(smp[0]), "max": float(smp[-1]),
+                        "note": "a frame's LATENCY on rank 0: HIP events from its first kernel to the end of its hole filling (which, with stage overlap, runs on its own stream "
+                                "beside the next frame's brick passes and integrate: latency > 1 / rate); separate pass after the timed region"}
     ratio = hip.occupiedRatio()
     stages_rank0 = None
     if dedicated:
@@ -498,6 +532,8 @@ def main():
                    "parallelism": ((f"single GPU holding slab {alone_slab} of the volume, " if alone_slab else "single GPU, ") + "slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else
                                   (f"ONE volume in {world - 1} Z-slab(s) on ranks 1..{world - 1} + rank 0 as dedicated compositor (receive, composite, hole filling)" if dedicated else
                                    f"ONE volume in {world} Z-slabs") + f" (strong scaling; slab boundaries {partition_note}; this rank's voxel planes {list(slab)}), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame"},
+        "stage_overlap": bool(overlap),
+        "serial": serial,
         "static": static,
         "resident_frames": resident,
         "long_run": long_run,
@@ -545,7 +581,7 @@ def main():
                 # share of the SIMDs' vector issue capacity: a SIMD-32 issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md,
                 # "Wave scheduling"), 1024 SIMDs at 2.4 GHz
                 "valu_issue_frac": (valu * 2.0 / (1024 * 2.4e9 * ms * 1e-3)) if valu else None,
-                "timing": "HIP events around this kernel alone, recorded on the launch stream", "note": note}
+                "timing": "HIP events around this kernel alone, recorded on the launch stream, over --steps frames with stage overlap off", "note": note}
 
     db = dense_bytes(cfg["res"], n_streams)
     if dom_ms and world == 1 and not alone:
@@ -558,6 +594,7 @@ def main():
         else:
             alg, note = db["march"], "dense march: 4V + 24R (BASELINE.md section 3); with depth limits the rays sample only inside occupied bricks, so this is an upper figure"
         out["roofline"] = roofline(dom, alg, dom_ms, args.config, note)
+        out["roofline"]["avg_launch_ms_in_timed_region"] = dom_ms_insitu      # in situ: beside the previous frame's hole filling when stage overlap is on
         if dom == "k_integrate_tiles" and "k_pair_masks" in stages:
             # the launch reads its (tile, stream) pair classes from the pair-mask pass that runs right before it: kernel + helper together
             both = dom_ms + stages["k_pair_masks"]

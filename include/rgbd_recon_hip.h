@@ -318,6 +318,13 @@ int32_t tsdf_set_timer_filter(tsdf_ctx* ctx, const char* names);
 int32_t tsdf_timer_reserve(tsdf_ctx* ctx, const char* name, uint32_t n);   /* create n event pairs now instead of on first use */
 int32_t tsdf_timer_begin(tsdf_ctx* ctx, const char* name);
 int32_t tsdf_timer_end(tsdf_ctx* ctx, const char* name);
+/* Stage overlap (default on; RR_OVERLAP_FILL=0 in the environment turns it off at creation): fillColors() of a draw runs on a second
+ * HIP stream of the context, beside whatever is queued next on the context's stream (the brick passes and integrate() of the next
+ * frame touch neither the pyramid nor the framebuffer); the next draw, every download and tsdf_sync() wait for it.  Results are
+ * identical either way.  tsdf_set_stage_overlap(ctx, 0) puts everything back on the one stream (synchronises first);
+ * tsdf_timer_end_after_fill records a caller timer's end behind the hole filling in flight (a frame's latency). */
+int32_t tsdf_set_stage_overlap(tsdf_ctx* ctx, int32_t on);
+int32_t tsdf_timer_end_after_fill(tsdf_ctx* ctx, const char* name);
 int32_t tsdf_timer_samples(tsdf_ctx* ctx, const char* name, float* out_ms, uint32_t capacity, uint32_t* count);
 int32_t tsdf_timer_ms(tsdf_ctx* ctx, const char* name, float* last_ms);   /* synchronises on that timer */
 /* every invocation since the previous call: count and summed device time; resets the timer */

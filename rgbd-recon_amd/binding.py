@@ -500,6 +500,8 @@ class ReconIntegrationHip:
 
     def timer_begin(self, name): self._ck(self._L.tsdf_timer_begin(self._c, name.encode()))
     def timer_end(self, name): self._ck(self._L.tsdf_timer_end(self._c, name.encode()))
+    def timer_end_after_fill(self, name): self._ck(self._L.tsdf_timer_end_after_fill(self._c, name.encode()))
+    def set_stage_overlap(self, on): self._ck(self._L.tsdf_set_stage_overlap(self._c, int(bool(on))))
 
     def timer_samples(self, name, capacity=8192):
         out, n = np.zeros(capacity, np.float32), C.c_uint32()

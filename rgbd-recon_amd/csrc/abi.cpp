@@ -121,6 +121,11 @@ struct tsdf_ctx {
   // colour mask + "colour buffer not cleared before this draw" (anaglyph)
   int vp_org[2]{}; float vp_off[2]{};
   uint32_t color_mask_mode = 0; bool keep_color = false;
+  // Stage overlap (round 3): the hole filling of draw f runs on a stream of its own beside whatever the caller queues next -- the brick
+  // passes and the integrate of frame f + 1 do not touch the pyramid or the framebuffer --, tied to the context's stream by two events:
+  // march_done (the fill waits for the march) and fill_done (the next writer / reader of the pyramid or the framebuffer waits for it).
+  hipStream_t fill_stream = nullptr; hipEvent_t march_done = nullptr, fill_done = nullptr; bool fill_pending = false;
+  bool overlap_fill = true;      // RR_OVERLAP_FILL=0 / tsdf_set_stage_overlap(ctx, 0): everything on the one stream, as in rounds 1 and 2
   bool timers_on = false;
   std::string timer_filter;      // ",name,name," or empty = all
   std::map<std::string, Timer> timers;
@@ -370,6 +375,22 @@ void timer_end(tsdf_ctx* c, const char* name) {
   t.open = false;
 }
 
+void timer_begin_on(tsdf_ctx* c, const char* name, hipStream_t st) { hipStream_t keep = c->stream; c->stream = st; timer_begin(c, name); c->stream = keep; }
+void timer_end_on(tsdf_ctx* c, const char* name, hipStream_t st) { hipStream_t keep = c->stream; c->stream = st; timer_end(c, name); c->stream = keep; }
+
+// stage overlap: GPU-side join (the context's stream waits for the hole filling that is still in flight) and host-side sync of both streams
+hipError_t join_fill(tsdf_ctx* c) {
+  if (!c->fill_pending) return hipSuccess;
+  c->fill_pending = false;
+  return hipStreamWaitEvent(c->stream, c->fill_done, 0);
+}
+hipError_t sync_ctx(tsdf_ctx* c) {
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (c->fill_stream) { const hipError_t f = hipStreamSynchronize(c->fill_stream); if (e == hipSuccess) e = f; }
+  c->fill_pending = false;
+  return e;
+}
+
 // draw() matrix block, recon_integration.cpp:182-205 (+ vol_to_world :66-72)
 // The matrices alone (no context): shared by make_view_params and the host-only tsdf_view_matrices.
 bool view_matrices(const float* bbox_min, const float* bbox_max, int vw, int vh, const float* mv16, const float* pr16, ViewParams* P, Mat4* v2w_out) {
@@ -580,6 +601,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   c->stream = c->own_stream;
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
+  if (const char* e = getenv("RR_OVERLAP_FILL")) c->overlap_fill = atoi(e) != 0;
   {
     uint64_t mib = cfg->proj_cache_mib;                                   // 0: off (the default: measured slower than the LUT kernel)
     if (mib == 0) if (const char* e = getenv("RR_PROJ_CACHE_MB")) mib = (uint64_t)atoll(e);   // A/B and test hook
@@ -622,7 +644,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   c->luts.n = (int)cfg->num_streams;
   c->pre.filter_textures = 1; c->pre.refine = 1;                      // NetKinectArray.cpp:63-69
   if ((rc = setup_view(c, cfg->view_w, cfg->view_h))) return fail(rc);
-  if ((rc = tryhip(hipStreamSynchronize(c->stream), "hipStreamSynchronize"))) return fail(rc);
+  if ((rc = tryhip(sync_ctx(c), "hipStreamSynchronize"))) return fail(rc);
   *out = c;
   return TSDF_OK;
 }
@@ -630,7 +652,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
 int32_t tsdf_destroy(tsdf_ctx* c) {
   CHECK_CTX(c);
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);          // (a null handle is the NULL stream: tsdf_adopt_null_stream)
+  sync_ctx(c);          // (a null handle is the NULL stream: tsdf_adopt_null_stream)
   if (c->copy_stream) hipStreamSynchronize(c->copy_stream);   // an asynchronous upload may still be writing a frame slot
   release_view(c); release_bricks(c);
   release_volume(c);
@@ -646,6 +668,9 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   for (int k = 0; k < 2; ++k) { if (c->h_wire[k]) hipHostFree(c->h_wire[k]); if (c->wire_done[k]) hipEventDestroy(c->wire_done[k]); }
   hipFree(c->d_wire);
   for (auto& kv : c->timers) for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  if (c->fill_stream) hipStreamDestroy(c->fill_stream);
+  if (c->march_done) hipEventDestroy(c->march_done);
+  if (c->fill_done) hipEventDestroy(c->fill_done);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
   return TSDF_OK;
@@ -657,7 +682,7 @@ int32_t tsdf_sparse_pool_stats(tsdf_ctx* c, uint32_t* need, uint32_t* cap) {
   HIP_TRY(c, hipSetDevice(c->device));
   uint32_t n = 0;
   HIP_TRY(c, hipMemcpyAsync(&n, c->tiles.count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   if (need) *need = n;
   if (cap) *cap = c->vol.pool_tiles;
   return TSDF_OK;
@@ -675,14 +700,14 @@ int32_t tsdf_integrate_stats(tsdf_ctx* c, uint32_t out[6]) {
   launch_item_stats(c->stream, c->luts, S, c->use_bricks ? 1 : 0, c->d_pair_masks, c->proj, c->d_item_stats);
   HIP_TRY(c, hipMemcpyAsync(out, c->d_item_stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(out + 4, c->proj.alloc, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   out[4] = std::min(out[4], c->proj.cap); out[5] = c->proj.cap;
   return TSDF_OK;
 }
 int32_t tsdf_set_stream(tsdf_ctx* c, void* s) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return TSDF_OK;
 }
@@ -692,11 +717,11 @@ int32_t tsdf_set_stream(tsdf_ctx* c, void* s) {
 int32_t tsdf_adopt_null_stream(tsdf_ctx* c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   c->stream = nullptr;                         // hipStream_t 0: every launch / copy / event record below goes to the NULL stream
   return TSDF_OK;
 }
-int32_t tsdf_sync(tsdf_ctx* c) { CHECK_CTX(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return TSDF_OK; }
+int32_t tsdf_sync(tsdf_ctx* c) { CHECK_CTX(c); HIP_TRY(c, sync_ctx(c)); return TSDF_OK; }
 
 int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const uint32_t ri[3], const float* uv, const uint32_t ru[3], const float* xyz, const uint32_t rx[3]) {
   CHECK_CTX(c);
@@ -715,7 +740,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
   if (uv) { if (!ru) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_uv resolution missing"); if (int32_t rc = check_res(ru, "cv_uv")) return rc; }
   if (xyz) { if (!rx) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "cv_xyz resolution missing"); if (int32_t rc = check_res(rx, "cv_xyz")) return rc; }
   // re-calibration of a stream: queued kernels may still read the old volumes; wait, then free what this call replaces
-  if (c->have_calib[i]) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->have_calib[i]) HIP_TRY(c, sync_ctx(c));
   auto replace = [&](int slot, void* fresh) { if (c->lut_alloc[i][slot]) hipFree(c->lut_alloc[i][slot]); c->lut_alloc[i][slot] = fresh; };
   // allocate, copy, and only then swap: a failed copy must leave the stream's old volume (and L.*) in place, never a freed pointer
   auto upload = [&](void** fresh, const void* src, size_t bytes) -> int32_t {
@@ -810,7 +835,7 @@ static int32_t ensure_async_upload(tsdf_ctx* c) {
   if (!c->d_astage) HIP_TRY(c, hipMalloc((void**)&c->d_astage, bytes));
   if (int32_t rc = alloc_frame_slot(c, 0)) return rc;
   if (int32_t rc = alloc_frame_slot(c, 1)) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));                             // the new slot's colour memset
+  HIP_TRY(c, sync_ctx(c));                             // the new slot's colour memset
   HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   return TSDF_OK;
 }
@@ -954,7 +979,7 @@ int32_t tsdf_upload_wire_frame(tsdf_ctx* c, const void* message, uint64_t bytes,
   HIP_TRY(c, hipSetDevice(c->device));
   if (int32_t rc = ensure_pre_buffers(c)) return rc;
   if (c->wire_capacity < want) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_ctx(c));
     for (int k = 0; k < 2; ++k) {
       if (c->h_wire[k]) HIP_TRY(c, hipHostFree(c->h_wire[k]));
       c->h_wire[k] = nullptr; c->wire_pending[k] = false;
@@ -988,7 +1013,7 @@ int32_t tsdf_download_raw_frame(tsdf_ctx* c, float* depth_raw, uint8_t* colour_r
   CHECK_CTX(c);
   if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "no raw frame uploaded");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h, nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
   if (depth_raw) HIP_TRY(c, hipMemcpy(depth_raw, c->d_raw, np * 4, hipMemcpyDeviceToHost));
   if (colour_rgba) HIP_TRY(c, hipMemcpy(colour_rgba, c->frame.color, nc * 4, hipMemcpyDeviceToHost));
@@ -1026,7 +1051,7 @@ int32_t tsdf_download_preprocessed(tsdf_ctx* c, float* depth2, float* depth_rg, 
   CHECK_CTX(c);
   if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "nothing was pre-processed yet");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h;
   if (depth2) HIP_TRY(c, hipMemcpy(depth2, c->d_depth2, np * 4, hipMemcpyDeviceToHost));
   if (depth_rg) HIP_TRY(c, hipMemcpy(depth_rg, c->d_depth_rg, np * 8, hipMemcpyDeviceToHost));
@@ -1086,7 +1111,7 @@ int32_t tsdf_occupied_ratio(tsdf_ctx* c, float* ratio) {
   if (!ratio) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemcpyAsync(c->h_num_occupied, c->br.num_occupied, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   *ratio = (float)*c->h_num_occupied / (float)c->br.n;                 // :440
   return TSDF_OK;
 }
@@ -1216,6 +1241,7 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
     c->touched_parity ^= 1;
     c->tile_history = true;
   } else c->tile_history = false;
+  HIP_TRY(c, join_fill(c));                                              // the previous draw's hole filling still reads level 0 / writes the framebuffer
   timer_begin(c, "draw");
   timer_begin(c, "k_march");
   launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
@@ -1238,7 +1264,7 @@ int32_t tsdf_upload_normals(tsdf_ctx* c, const float* normals_rgb) {
   if (!c->d_normal) HIP_TRY(c, hipMalloc(&c->d_normal, np * sizeof(float4)));
   std::vector<float4> padded(np);
   for (size_t i = 0; i < np; ++i) padded[i] = make_float4(normals_rgb[3 * i], normals_rgb[3 * i + 1], normals_rgb[3 * i + 2], 0.0f);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   HIP_TRY(c, hipMemcpy(c->d_normal, padded.data(), np * sizeof(float4), hipMemcpyHostToDevice));
   return TSDF_OK;
 }
@@ -1271,6 +1297,7 @@ int32_t tsdf_draw_points(tsdf_ctx* c, const float* mv, const float* pr) {
   FrameImages F = c->frame;
   F.depth = (float*)c->frame.depth;
   timer_begin(c, "points");
+  HIP_TRY(c, join_fill(c));
   launch_draw_points(c->stream, P, Q, c->luts, F, c->d_comp_key, c->d_fb_c, c->d_fb_d);
   timer_end(c, "points");
   HIP_TRY(c, hipGetLastError());
@@ -1295,6 +1322,7 @@ int32_t tsdf_draw_trigrid(tsdf_ctx* c, const float* mv, const float* pr) {
   const size_t nv = (size_t)c->vw * c->vh;
   if (!c->d_tri_z) { HIP_TRY(c, hipMalloc(&c->d_tri_z, nv * sizeof(uint32_t))); HIP_TRY(c, hipMalloc(&c->d_tri_acc, nv * sizeof(float4))); }
   timer_begin(c, "trigrid");
+  HIP_TRY(c, join_fill(c));
   launch_draw_trigrid(c->stream, P, Q, c->luts, c->frame, c->min_length, c->d_tri_z, c->d_tri_acc, c->d_fb_c, c->d_fb_d);
   timer_end(c, "trigrid");
   HIP_TRY(c, hipGetLastError());
@@ -1306,23 +1334,48 @@ int32_t tsdf_raymarch(tsdf_ctx* c, const float* mv, const float* pr) {
   if (rc == TSDF_OK) timer_end(c, "3recon");
   return rc;
 }
+// fillColors(): with stage overlap on its own stream behind an event of the context's stream; *used = the stream it was queued on
+static int32_t fill_colors_impl(tsdf_ctx* c, hipStream_t* used) {
+  hipStream_t fs = c->stream;
+  if (c->overlap_fill) {
+    if (!c->fill_stream) {
+      HIP_TRY(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking));
+      HIP_TRY(c, hipEventCreateWithFlags(&c->march_done, hipEventDisableTiming));
+      HIP_TRY(c, hipEventCreateWithFlags(&c->fill_done, hipEventDisableTiming));
+    }
+    HIP_TRY(c, hipEventRecord(c->march_done, c->stream));                 // everything the caller queued so far: the march / composite into level 0
+    HIP_TRY(c, hipStreamWaitEvent(c->fill_stream, c->march_done, 0));
+    fs = c->fill_stream;
+  }
+  timer_begin_on(c, "holefill", fs);
+  launch_inpaint_pyramid(fs, c->atlas);
+  launch_colorfill(fs, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
+  timer_end_on(c, "holefill", fs);
+  if (c->overlap_fill) { HIP_TRY(c, hipEventRecord(c->fill_done, fs)); c->fill_pending = true; }
+  HIP_TRY(c, hipGetLastError());
+  if (used) *used = fs;
+  return TSDF_OK;
+}
 int32_t tsdf_fill_colors(tsdf_ctx* c) {
   CHECK_CTX(c);
   if (!c->fill_holes) FAIL(c, TSDF_ERR_STATE, "colour filling is off: the raymarch did not render into the pyramid");
   HIP_TRY(c, hipSetDevice(c->device));
-  timer_begin(c, "holefill");
-  launch_inpaint_pyramid(c->stream, c->atlas);
-  launch_colorfill(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
-  timer_end(c, "holefill");
-  HIP_TRY(c, hipGetLastError());
-  return TSDF_OK;
+  return fill_colors_impl(c, nullptr);
 }
 int32_t tsdf_draw_f(tsdf_ctx* c, const float* mv, const float* pr) {
   CHECK_CTX(c);
   int32_t rc = raymarch_impl(c, mv, pr, true);
   if (rc) return rc;
-  if (c->fill_holes && (rc = tsdf_fill_colors(c))) return rc;
-  timer_end(c, "3recon");
+  hipStream_t last = c->stream;
+  if (c->fill_holes && (rc = fill_colors_impl(c, &last))) return rc;
+  timer_end_on(c, "3recon", last);
+  return TSDF_OK;
+}
+int32_t tsdf_set_stage_overlap(tsdf_ctx* c, int32_t on) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_ctx(c));
+  c->overlap_fill = on != 0;
   return TSDF_OK;
 }
 
@@ -1349,7 +1402,7 @@ int32_t tsdf_set_voxel_size(tsdf_ctx* c, float size) {
     if (res[a] < 1 || res[a] > 4096) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "volume resolution out of range [1, 4096]");
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   const int old_res[3] = {c->res[0], c->res[1], c->res[2]};
   const float old_vox[3] = {c->vox[0], c->vox[1], c->vox[2]};
   const float brick[3] = {c->br.size[0], c->br.size[1], c->br.size[2]};
@@ -1364,7 +1417,7 @@ int32_t tsdf_set_voxel_size(tsdf_ctx* c, float size) {
     return rc;
   }
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) if (c->have_calib[i]) fit_lut_to_volume(c, i);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   return TSDF_OK;
 }
 int32_t tsdf_set_use_bricks(tsdf_ctx* c, int32_t a) { CHECK_CTX(c); c->use_bricks = a != 0; return TSDF_OK; }
@@ -1400,16 +1453,16 @@ int32_t tsdf_set_brick_size(tsdf_ctx* c, const float size[3]) {
   CHECK_CTX(c);
   if (!size) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   return setup_bricks(c, size);
 }
 int32_t tsdf_resize(tsdf_ctx* c, uint32_t w, uint32_t h) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   int32_t rc = setup_view(c, w, h);
   if (rc) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   return TSDF_OK;
 }
 
@@ -1435,7 +1488,7 @@ int32_t tsdf_download_volume(tsdf_ctx* c, float* out) {
   if (rc) return rc;
   launch_volume_to_linear(c->stream, c->vol, c->d_linear);
   HIP_TRY(c, hipMemcpyAsync(out, c->d_linear, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   return TSDF_OK;
 }
 int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
@@ -1449,7 +1502,7 @@ int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
   launch_volume_from_linear(c->stream, c->vol, c->d_linear);
   launch_mark_all_mixed(c->stream, c->tiles);
   c->full_classify = true;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   return TSDF_OK;
 }
 // the storage tiles the last culled integrate() computed (its compacted work list): ids are x-fastest tile indices relative to
@@ -1458,7 +1511,7 @@ int32_t tsdf_download_active_tiles(tsdf_ctx* c, uint32_t* ids, uint32_t capacity
   CHECK_CTX(c);
   if (!count) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   const int p = c->tile_parity ^ 1;                                       // integrate() flipped the parity after its launches
   uint32_t n = 0;
   HIP_TRY(c, hipMemcpy(&n, c->d_tile_counts + p, sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1470,7 +1523,7 @@ int32_t tsdf_download_active_tiles(tsdf_ctx* c, uint32_t* ids, uint32_t capacity
 int32_t tsdf_download_bricks(tsdf_ctx* c, uint32_t* counters, uint8_t* flags) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   if (counters) HIP_TRY(c, hipMemcpy(counters, c->br.counters, (size_t)c->br.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (flags) HIP_TRY(c, hipMemcpy(flags, c->br.flags, (size_t)c->br.n, hipMemcpyDeviceToHost));
   return TSDF_OK;
@@ -1479,14 +1532,14 @@ int32_t tsdf_upload_brick_counters(tsdf_ctx* c, const uint32_t* counters) {
   CHECK_CTX(c);
   if (!counters) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   HIP_TRY(c, hipMemcpy(c->br.counters, counters, (size_t)c->br.n * sizeof(uint32_t), hipMemcpyHostToDevice));
   return TSDF_OK;
 }
 int32_t tsdf_download_image(tsdf_ctx* c, float* rgba, float* depth, float* ns, float* peels) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   const RayTarget R = ray_target(c);
   const size_t w = (size_t)c->vw, h = (size_t)c->vh;
   if (rgba) HIP_TRY(c, hipMemcpy2D(rgba, w * 16, R.color, (size_t)R.stride * 16, w * 16, h, hipMemcpyDeviceToHost));
@@ -1502,7 +1555,7 @@ int32_t tsdf_upload_image(tsdf_ctx* c, const float* rgba, const float* depth) {
   CHECK_CTX(c);
   if (!rgba || !depth) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   const RayTarget R = ray_target(c);
   const size_t w = (size_t)c->vw, h = (size_t)c->vh;
   HIP_TRY(c, hipMemcpy2D(R.color, (size_t)R.stride * 16, rgba, w * 16, w * 16, h, hipMemcpyHostToDevice));
@@ -1513,7 +1566,7 @@ int32_t tsdf_upload_image(tsdf_ctx* c, const float* rgba, const float* depth) {
 int32_t tsdf_download_framebuffer(tsdf_ctx* c, float* rgba, float* depth) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   const size_t n = (size_t)c->vw * c->vh;
   if (rgba) HIP_TRY(c, hipMemcpy(rgba, c->d_fb_c, n * 16, hipMemcpyDeviceToHost));
   if (depth) HIP_TRY(c, hipMemcpy(depth, c->d_fb_d, n * 4, hipMemcpyDeviceToHost));
@@ -1522,7 +1575,7 @@ int32_t tsdf_download_framebuffer(tsdf_ctx* c, float* rgba, float* depth) {
 int32_t tsdf_download_atlas(tsdf_ctx* c, float* rgba, float* depth) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, sync_ctx(c));
   const size_t n = (size_t)c->atlas.aw * c->atlas.h;
   if (rgba) HIP_TRY(c, hipMemcpy(rgba, c->atlas.color, n * 16, hipMemcpyDeviceToHost));
   if (depth) HIP_TRY(c, hipMemcpy(depth, c->atlas.depth, n * 4, hipMemcpyDeviceToHost));
@@ -1566,6 +1619,7 @@ int32_t tsdf_export_partial_dev(tsdf_ctx* c, void* dst) {
   CHECK_CTX(c);
   if (!dst) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, join_fill(c));
   launch_export_partial(c->stream, ray_target(c), c->vw, c->vh, dst);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -1574,6 +1628,7 @@ int32_t tsdf_composite_dev(tsdf_ctx* c, const void* gathered, uint32_t n) {
   CHECK_CTX(c);
   if (!gathered || n < 1) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, join_fill(c));
   launch_composite(c->stream, gathered, (int)n, ray_target(c), c->vw, c->vh);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -1585,6 +1640,7 @@ int32_t tsdf_export_hits_dev(tsdf_ctx* c, void* dst, uint32_t capacity) {
   HIP_TRY(c, hipSetDevice(c->device));
   // the raymarch that just ran used counter (hit_parity ^ 1): raymarch_impl flips the parity after its launch
   const int p = c->hit_parity ^ 1;
+  HIP_TRY(c, join_fill(c));
   launch_export_hits(c->stream, ray_target(c), c->vw, c->d_hits, c->d_hit_counters + p, c->last_two_pass ? c->d_long : nullptr, c->d_hit_counters + 2 + p, dst, capacity);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -1595,6 +1651,7 @@ int32_t tsdf_composite_hits_dev(tsdf_ctx* c, const void* gathered, uint32_t n, u
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->d_comp_key) HIP_TRY(c, hipMalloc(&c->d_comp_key, (size_t)c->vw * c->vh * sizeof(unsigned long long)));
   // a compositing context that did not march this frame (dedicated compositor, multigpu.py) has no miss counts of its own: 0 then
+  HIP_TRY(c, join_fill(c));
   launch_composite_hits(c->stream, gathered, (size_t)stride_bytes, (int)n, ray_target(c), c->vw, c->vh, c->d_comp_key, c->own_miss_counts ? 1 : 0);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -1635,6 +1692,14 @@ int32_t tsdf_timer_reserve(tsdf_ctx* c, const char* name, uint32_t n) {
 // caller-defined intervals on the context's stream (bench.py brackets whole frames with them)
 int32_t tsdf_timer_begin(tsdf_ctx* c, const char* name) { CHECK_CTX(c); if (!name) return TSDF_ERR_INVALID_ARGUMENT; HIP_TRY(c, hipSetDevice(c->device)); timer_begin(c, name); return TSDF_OK; }
 int32_t tsdf_timer_end(tsdf_ctx* c, const char* name) { CHECK_CTX(c); if (!name) return TSDF_ERR_INVALID_ARGUMENT; timer_end(c, name); return TSDF_OK; }
+// the end event behind the hole filling that is still in flight on its own stream (stage overlap): begin ... end_after_fill spans a whole
+// frame from its first kernel to its framebuffer -- the frame's latency, where tsdf_timer_end would stop at the march
+int32_t tsdf_timer_end_after_fill(tsdf_ctx* c, const char* name) {
+  CHECK_CTX(c);
+  if (!name) return TSDF_ERR_INVALID_ARGUMENT;
+  timer_end_on(c, name, c->fill_pending ? c->fill_stream : c->stream);
+  return TSDF_OK;
+}
 // the individual samples recorded since the last tsdf_timer_stats / tsdf_timer_samples of this timer (and resets it)
 int32_t tsdf_timer_samples(tsdf_ctx* c, const char* name, float* out_ms, uint32_t capacity, uint32_t* count) {
   CHECK_CTX(c);
