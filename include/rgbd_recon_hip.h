@@ -301,6 +301,33 @@ int32_t tsdf_composite_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n);
 int32_t tsdf_export_hits_dev(tsdf_ctx* ctx, void* dst_dev, uint32_t capacity);
 /* n record buffers, stride_bytes apart, composited into this context's raymarch target (rank 0) */
 int32_t tsdf_composite_hits_dev(tsdf_ctx* ctx, const void* gathered_dev, uint32_t n, uint64_t stride_bytes);
+/* ---- native multi-GPU exchange: one context per rank, one RCCL communicator, every collective on the context's
+ * stream.  The reference's caller is C++ (source/kinect_client.cpp:569-614); with these it drives N GPUs without Python:
+ *   rank 0: tsdf_comm_unique_id(id) -> the caller carries the 128 bytes to the other ranks (its own channel: the ZMQ socket, MPI, a file)
+ *   every rank: tsdf_create(slab ...) ; tsdf_comm_init(ctx, id, rank, world, flags)
+ *   per frame: tsdf_broadcast_frame(ctx, root, ...)   the frame arrives in ONE process (NetKinectArray.cpp:482-529)
+ *              clear / mark / update bricks, integrate   (every rank that owns a slab)
+ *              tsdf_halo_exchange(ctx)                   unless the contexts recompute their halo layers (slab_recompute_halo)
+ *              tsdf_raymarch(ctx, mv, proj)
+ *              tsdf_composite_gather(ctx)                hit records -> rank 0: nearest hit per pixel + fillColors(); no host sync
+ *   before reading the frame: tsdf_composite_finish(ctx, &regathered)
+ * TSDF_COMM_DEDICATED_COMPOSITOR: rank 0 holds no slab (its context only needs the view): it takes part in the collectives with empty
+ * buffers, composites and fills holes while ranks 1 .. N-1 already work on the next frame.
+ * RCCL is bound at run time (dlopen; a copy already loaded by the process -- torch's -- is reused). */
+#define TSDF_COMM_ID_BYTES 128
+#define TSDF_COMM_DEDICATED_COMPOSITOR 1u
+int32_t tsdf_comm_unique_id(uint8_t id[TSDF_COMM_ID_BYTES]);
+int32_t tsdf_comm_init(tsdf_ctx* ctx, const uint8_t id[TSDF_COMM_ID_BYTES], uint32_t rank, uint32_t world, uint32_t flags);
+int32_t tsdf_comm_destroy(tsdf_ctx* ctx);
+int32_t tsdf_broadcast_frame(tsdf_ctx* ctx, uint32_t root, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour_rgb);
+int32_t tsdf_halo_exchange(tsdf_ctx* ctx);
+int32_t tsdf_composite_gather(tsdf_ctx* ctx);
+int32_t tsdf_composite_finish(tsdf_ctx* ctx, uint32_t* regathered);
+/* gathers that tsdf_composite_finish had to repeat / frames that were composited from truncated record lists (0 in a healthy run) */
+int32_t tsdf_comm_stats(tsdf_ctx* ctx, uint32_t* regathers, uint32_t* overflowed_frames);
+/* smallest number of hit records gathered per rank and frame (default 4096) */
+int32_t tsdf_comm_set_min_capacity(tsdf_ctx* ctx, uint32_t records);
+
 /* A whole-volume context marches in two passes: rays still running after `samples` samples are finished and shaded by a
  * wave-per-ray pass (0 switches the second pass off; the default is 24, or RR_MARCH_CAP).  A tuning knob: results do not depend on the
  * value, and tsdf_export_hits_dev ships the second pass's rays as well. */

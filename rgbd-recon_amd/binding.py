@@ -513,6 +513,47 @@ class ReconIntegrationHip:
         self._ck(self._L.tsdf_timer_stats(self._c, name.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    # ------------------------------------------------------------------ native RCCL exchange (comm.cpp): one communicator per context
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes made by rank 0 (ncclGetUniqueId); the caller carries them to the other ranks"""
+        L = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = L.tsdf_comm_unique_id(buf)
+        if rc != 0:
+            raise TsdfError(rc, "RCCL is not available in this process")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world, dedicated_compositor=False):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._ck(self._L.tsdf_comm_init(self._c, buf, int(rank), int(world), 1 if dedicated_compositor else 0))
+
+    def comm_destroy(self): self._ck(self._L.tsdf_comm_destroy(self._c))
+
+    def broadcast_frame(self, root, scene=None):
+        """scene: on the root the frame as it arrived (host arrays), elsewhere None"""
+        if scene is None:
+            self._ck(self._L.tsdf_broadcast_frame(self._c, int(root), None, None, None, None))
+            return
+        col = np.ascontiguousarray(scene["color"], np.uint8)
+        self._ck(self._L.tsdf_broadcast_frame(self._c, int(root), _fp(_f32(scene["depth"])), _fp(_f32(scene["quality"])), _fp(_f32(scene["silhouette"])),
+                                              col.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def halo_exchange(self): self._ck(self._L.tsdf_halo_exchange(self._c))
+    def composite_gather(self): self._ck(self._L.tsdf_composite_gather(self._c))
+
+    def composite_finish(self):
+        r = C.c_uint32()
+        self._ck(self._L.tsdf_composite_finish(self._c, C.byref(r)))
+        return bool(r.value)
+
+    def comm_set_min_capacity(self, records): self._ck(self._L.tsdf_comm_set_min_capacity(self._c, int(records)))
+
+    def comm_stats(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.tsdf_comm_stats(self._c, C.byref(a), C.byref(b)))
+        return {"regathers": a.value, "overflowed_frames": b.value}
+
     def halo_info(self):
         layers, nbytes = C.c_uint32(), C.c_uint64()
         self._ck(self._L.tsdf_halo_info(self._c, C.byref(layers), C.byref(nbytes)))

@@ -16,126 +16,11 @@
 
 using namespace rr;
 
-namespace {
+#include "ctx.hpp"
+
 thread_local std::string g_create_error;
 
-// One named timer = a pool of event pairs, one pair per invocation since the last tsdf_timer_stats()
-struct Timer { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; bool open = false; };
-constexpr size_t kMaxTimerPairs = 8192;
-
-struct BrickRange { uint32_t lo[3], hi[3]; };
-}  // namespace
-
-struct tsdf_ctx {
-  tsdf_config cfg{};
-  std::string err;
-  int device = 0;
-  hipStream_t own_stream = nullptr, stream = nullptr;
-  // volume
-  int res[3]{};
-  float vox[3]{};
-  Volume vol{};
-  TileState tiles{};
-  uint8_t* d_cls_all = nullptr;      // tile class of every stored tile (owned + halo)
-  int halo_layers = 0;
-  // bricks
-  float brick_req[3]{};          // requested size (setBrickSize argument)
-  Bricks br{};
-  std::vector<BrickRange> ranges;
-  uint16_t* d_vox_first[3]{};
-  uint8_t* d_vox_count[3]{};
-  uint16_t* d_tile_b0[3]{};
-  uint16_t* d_tile_b1[3]{};
-  uint8_t* d_tile_full[3]{};
-  uint16_t* d_brick_t0[3]{};
-  uint16_t* d_brick_t1[3]{};
-  // active-tile lists of this and the previous integrate() (k_classify_lists), their two device counts, and what decides
-  // whether the next integrate() may trust the previous list
-  uint32_t* d_tile_list[2]{}; uint32_t* d_tile_counts = nullptr; int tile_parity = 0; bool full_classify = true; uint32_t frame_stamp = 0;
-  uint32_t* d_occ_counts = nullptr; int occ_parity = 0;   // two occupied-brick counts used alternately (see Bricks::num_occupied)
-  uint32_t min_voxels = 10;      // recon_integration.cpp:59
-  size_t counter_words = 0;
-  // two counter buffers: while frame f uses one, integrate(f)'s classify launch zeroes the other (part D of k_classify_lists), and
-  // clearOccupiedBricks() of frame f + 1 is a pointer swap instead of a fill launch; spare_clean says whether that happened
-  uint32_t* d_counters[2]{}; int counters_cur = 0; bool spare_clean = false;
-  uint32_t* h_num_occupied = nullptr;   // pinned
-  // calibration + frame
-  StreamTable luts{};
-  void* lut_alloc[TSDF_MAX_STREAMS][3]{};   // per stream: cv_xyz_inv, cv_uv, cv_xyz device copies (freed when the stream is re-calibrated)
-  bool have_calib[TSDF_MAX_STREAMS]{};
-  // the stream's per-tile LUT box against the integrate kernel's LDS budget: 0 = does not fit (global-memory kernel), 1 = the box fits
-  // (direct 8-tap form), 2 = the separable passes' rows and planes fit as well (the fastest form)
-  int lut_dz[TSDF_MAX_STREAMS]{};   // the most z-planes of the stream's inverse LUT any 8^3 tile of the volume touches
-  int lds_ok[TSDF_MAX_STREAMS]{};
-  int k1_form_cap = 3;           // RR_K1_FORM: 3 = no cap (separable LDS form; + the projection cache where a budget was given), 2 = separable LDS form, 1 = direct 8-tap form, 0 = global-memory kernel
-  // projection cache (ProjCache, tsdf_common.hpp): pool + slot table allocated by the first integrate() that can use it, dropped with
-  // the volume, invalidated by tsdf_set_calibration
-  ProjCache proj{}; uint32_t* d_proj_words = nullptr; int proj_parity = 0; size_t proj_budget = 0; bool proj_failed = false; uint32_t* d_item_stats = nullptr;
-  bool last_integrate_cached = false;
-  FrameImages frame{};           // the CURRENT frame slot's images (what mark / integrate / draw read)
-  // Two frame slots (the reference's double PBO + texture arrays, NetKinectArray.cpp:225-236): while the path computes on slot
-  // `cur_slot`, tsdf_upload_frame_async fills the other one on a copy stream; tsdf_select_frame_slot makes it current.
-  struct FrameSlot { float4* dqs = nullptr; float* depth = nullptr; uchar4* color = nullptr; float4* ranges = nullptr; bool have = false;
-                     hipEvent_t ready = nullptr; bool pending = false;      // recorded on the copy stream after the slot's upload + pack
-                     hipEvent_t released = nullptr; bool in_use = false; }; // recorded on the compute stream when the slot stopped being current
-  FrameSlot slots[2];
-  int cur_slot = 0;
-  hipStream_t copy_stream = nullptr;
-  uint8_t* h_stage[2]{}; hipEvent_t stage_done[2]{}; bool stage_busy[2]{}; int stage_k = 0;   // pinned host staging ring of the async upload
-  float* d_stage_depth = nullptr; float* d_stage_q = nullptr; float* d_stage_s = nullptr; uint8_t* d_stage_col = nullptr;
-  uint8_t* d_astage = nullptr;   // device staging of the async upload (its own: the copy stream runs beside the compute stream)
-  // pre-processing state (NetKinectArray side)
-  PreParams pre{};
-  float* d_raw = nullptr; float* d_depth2 = nullptr; float2* d_depth_rg = nullptr; float4* d_lab = nullptr; float2* d_depth_b = nullptr; float4* d_normal = nullptr;
-  bool have_raw = false, use_processed_depth = true;
-  bool have_limits[TSDF_MAX_STREAMS]{}, have_cam[TSDF_MAX_STREAMS]{};
-  // frame ingest (readLoop / update): wire formats, pinned double buffer (the reference's double_pbo), device copy of the message
-  uint32_t color_format = TSDF_COLOR_RGB8, depth_format = TSDF_DEPTH_F32;
-  uint8_t* h_wire[2]{}; hipEvent_t wire_done[2]{}; bool wire_pending[2]{}; int wire_slot = 0;
-  uint8_t* d_wire = nullptr; size_t wire_capacity = 0;
-  // view
-  int vw = 0, vh = 0;
-  Atlas atlas{};
-  float4* d_peels = nullptr; float* d_nsamples = nullptr;
-  void* d_hits = nullptr; uint32_t* d_hit_counters = nullptr; int hit_parity = 0;
-  uint8_t* d_touched[2]{}; int touched_parity = 0; bool tile_history = false;   // image-space dirty tiles (k_raymarch.hip); history is dropped
-                                                                                // whenever something else writes the march target
-  uint32_t* d_tri_z = nullptr; float4* d_tri_acc = nullptr; float min_length = 0.0125f;   // triangle-grid back-end; KinectCalibrationFile.cpp:96 default
-  bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
-  bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)
-  uint32_t* d_pair_masks = nullptr;   // per work item of the integrate launch: this frame's (tile, stream) pair classes (k_pair_masks)
-  float4* d_tile_bounds = nullptr; bool tile_bounds_valid = false;   // static per (stored tile, stream) LUT-box bounds, built on the first dense integrate after a calibration
-  bool culled_ranges = true;      // RR_K1_CULLED_RANGES=0: no uniform-pair shortcut in culled launches (A/B hook; dense storage with a bounds table of at most 512 MiB only)
-  bool use_ranges = true;         // RR_K1_RANGES=0: the dense integrate evaluates every voxel of every stream (A/B and test hook, read at creation)
-  bool march_box = true;          // RR_MARCH_BOX=0: the dense march gathers from global memory as in round 1 (A/B and test hook, read at creation)
-  void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
-  bool last_two_pass = false;     // the last march handed its long rays to the wave-per-ray pass (they are not on the hit list)
-  bool own_miss_counts = false;   // this context has marched at this view size: its sample-count image holds the miss counts (-count, or count after a composite)
-  unsigned long long* d_comp_key = nullptr;   // per-pixel bid of the compact composite (rank 0, allocated on first use)   // raymarch hit list (k_march -> k_shade)
-  float4* d_fb_c = nullptr; float* d_fb_d = nullptr;
-  float* d_linear = nullptr;     // scratch for volume up/download
-  // flags (recon_integration.cpp:54-57)
-  bool fill_holes = true, use_bricks = true, skip_space = true;
-  int shade_mode = 0;
-  // stereo modes of the client (source/kinect_client.cpp:616-669): viewport origin + viewport_offset uniform (side by side),
-  // colour mask + "colour buffer not cleared before this draw" (anaglyph)
-  int vp_org[2]{}; float vp_off[2]{};
-  uint32_t color_mask_mode = 0; bool keep_color = false;
-  // Stage overlap (round 3): the hole filling of draw f runs on a stream of its own beside whatever the caller queues next -- the brick
-  // passes and the integrate of frame f + 1 do not touch the pyramid or the framebuffer --, tied to the context's stream by two events:
-  // march_done (the fill waits for the march) and fill_done (the next writer / reader of the pyramid or the framebuffer waits for it).
-  hipStream_t fill_stream = nullptr; hipEvent_t march_done = nullptr, fill_done = nullptr; bool fill_pending = false;
-  bool overlap_fill = true;      // RR_OVERLAP_FILL=0 / tsdf_set_stage_overlap(ctx, 0): everything on the one stream, as in rounds 1 and 2
-  bool timers_on = false;
-  std::string timer_filter;      // ",name,name," or empty = all
-  std::map<std::string, Timer> timers;
-};
-
-#define CHECK_CTX(c) do { if (!(c)) return TSDF_ERR_INVALID_ARGUMENT; } while (0)
-#define FAIL(c, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (c)->err = _b; return (code); } while (0)
-#define HIP_TRY(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { FAIL(c, _e == hipErrorOutOfMemory ? TSDF_ERR_OUT_OF_MEMORY : TSDF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } } while (0)
-
-namespace {
+namespace rrhost {       // host-side helpers (shared with comm.cpp through ctx.hpp where declared there)
 
 // n / d == (n * m) >> k for every n < 2^27: with l = ceil(log2 d), k = 27 + l and m = floor(2^k / d) + 1 = (2^k + e) / d, 0 < e <= d <= 2^l,
 // the product is n / d + n e / (d 2^k) with n e < 2^27 2^l = 2^k, i.e. less than 1 / d above the true quotient: the floor is the same.
@@ -568,7 +453,8 @@ void fit_lut_to_volume(tsdf_ctx* c, uint32_t i) {
   c->lds_ok[i] = worst[0] * worst[1] * worst[2] > integrate_box_cap() ? 0 : ((worst[1] * worst[2] * 8 <= integrate_row_cap() && worst[2] * 64 <= integrate_box_cap()) ? 2 : 1);
 }
 
-}  // namespace
+}  // namespace rrhost
+using namespace rrhost;
 
 extern "C" {
 
@@ -654,6 +540,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   hipSetDevice(c->device);
   sync_ctx(c);          // (a null handle is the NULL stream: tsdf_adopt_null_stream)
   if (c->copy_stream) hipStreamSynchronize(c->copy_stream);   // an asynchronous upload may still be writing a frame slot
+  tsdf_comm_destroy(c);
   release_view(c); release_bricks(c);
   release_volume(c);
   for (auto& sl : c->slots) { hipFree(sl.dqs); hipFree(sl.depth); hipFree(sl.color); hipFree(sl.ranges); if (sl.ready) hipEventDestroy(sl.ready); if (sl.released) hipEventDestroy(sl.released); }

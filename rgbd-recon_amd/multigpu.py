@@ -111,8 +111,13 @@ class SlabDriver:
     LAG = 2            # frames between a hit count and its use as the gather size: its pinned copy has long arrived, the host never waits
 
     def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense", preprocess=False,
-                 exchange_when_alone=False, stream=None, min_capacity=4096, compositor="shared"):
+                 exchange_when_alone=False, stream=None, min_capacity=4096, compositor="shared", native=False):
+        """native: the two exchanges run inside the library (tsdf_halo_exchange / tsdf_composite_gather / tsdf_composite_finish, comm.cpp: RCCL
+        called from C++ on the context's stream) and this class only issues the frame's calls -- what a C++ host does; torch.distributed is
+        then used once, to carry the communicator's 128-byte id from rank 0 to the others.  Compact composite only."""
         assert halo in ("exchange", "recompute") and composite in ("dense", "compact") and compositor in ("shared", "dedicated")
+        self.native = bool(native)
+        assert not self.native or composite == "compact", "the native exchange gathers hit records (compact composite)"
         assert compositor == "shared" or world >= 2, "a dedicated compositor needs at least one worker rank"
         self.dedicated = compositor == "dedicated"
         self.is_worker = not (self.dedicated and rank == 0)          # owns a slab: marks bricks, integrates, marches, exports
@@ -128,10 +133,20 @@ class SlabDriver:
             assert self.stream.cuda_stream != 0, "the NULL stream cannot be handed to tsdf_set_stream"
             backend.set_stream(self.stream.cuda_stream)
         self.frame_no = 0
+        self.caps = {}                        # frame -> capacity it was gathered with, until its counts have been looked at
         self.last = None                      # (frame number, gathered capacity) of the latest compact frame, until finish() has checked it
         self.regathers = 0                    # frames whose first gather was too small (finish() repaired them)
         self.min_capacity = int(min_capacity)
-        if self.exchanging:
+        self.overflowed_frames = 0            # frames that were composited from truncated record lists and were no longer the latest when finish() ran
+        if self.exchanging and self.native:
+            ids = [backend.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0, group=group)
+            with self._on_stream():
+                backend.comm_init(ids[0], rank, world, dedicated_compositor=self.dedicated)
+                backend.comm_set_min_capacity(self.min_capacity)
+            self.stage_cpu = False
+        elif self.exchanging:
             npx = view[0] * view[1]
             self.npx = npx
             with self._on_stream():
@@ -201,6 +216,9 @@ class SlabDriver:
         if f < self.LAG:
             return self.npx                                # no history yet: a slab cannot hit more rays than there are pixels
         m = int(self._counts_of(f - self.LAG)[:, 1].max())
+        if m > self.caps.get(f - self.LAG, self.npx):      # that frame hit more rays than were gathered (finish() repairs the LATEST frame only)
+            self.overflowed_frames += 1
+        self.caps.pop(f - self.LAG, None)
         cap = max(self.min_capacity, ((m * 3) // 2 + 1024 + 1023) // 1024 * 1024)
         return min(cap, self.npx)
 
@@ -244,6 +262,14 @@ class SlabDriver:
         if not self.exchanging:
             b.drawF(mv, proj)
             return
+        if self.native:
+            if self.halo == "exchange":
+                b.halo_exchange()
+            if self.is_worker:
+                b.draw(mv, proj)
+            b.composite_gather()
+            self.last = True
+            return
         if self.halo == "exchange":
             self.exchange_halo()
         if self.is_worker:
@@ -259,18 +285,27 @@ class SlabDriver:
         f = self.frame_no
         cap = self._capacity(f)
         self._exchange_hits(cap, record_counts_of=f)
+        self.caps[f] = cap
         self.last = (f, cap)
         self.frame_no = f + 1
 
     def finish(self):
         """Completes the latest frame: call before reading its result (and at the end of a timed region).  A COLLECTIVE when
         the compact gather of that frame turned out too small -- every rank sees the same counts and re-gathers together."""
-        if self.exchanging and self.composite == "compact" and self.last is not None:
+        if self.exchanging and self.native:
+            if self.last is not None:
+                self.last = None
+                with self._on_stream():
+                    self.b.composite_finish()
+                st = self.b.comm_stats()
+                self.regathers, self.overflowed_frames = st["regathers"], st["overflowed_frames"]
+        elif self.exchanging and self.composite == "compact" and self.last is not None:
             f, cap = self.last
             self.last = None
             m = int(self._counts_of(f)[:, 1].max())
             if m > cap:
                 self.regathers += 1
+                self.caps[f] = min(self.npx, m)
                 with self._on_stream():
                     self._exchange_hits(min(self.npx, m))
         if self.stream is not None:

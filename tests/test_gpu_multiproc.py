@@ -146,3 +146,53 @@ def test_slab_exchange_over_rccl_with_one_rank(halo, composite):
     p.join(600)
     assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+# ------------------------------------------------------------------------------------------------ native RCCL exchange (comm.cpp), world of one
+def _native_alone(q, halo, force_regather):
+    import torch                                           # first: librccl of the process is torch's, the library binds to it
+    import rgbd_recon_amd as rr
+    mgpu = import_module("rgbd-recon_amd.multigpu")
+    torch.cuda.set_device(0)
+    same = lambda a, b: bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+    scene = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32)
+    moved = rr.scene.make_scene(n_streams=4, width=160, height=120, lut_res=32, inv_res=32, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2))
+    mv, pr = rr.scene.default_view(*KW["view"])
+    hip = rr.ReconIntegrationHip(scene, slab=mgpu.slab_range(KW["res"][2], 0, 1), recompute_halo=(halo == "recompute"), **KW)
+    drv = mgpu.SlabDriver(hip, 0, 1, "cuda:0", view=KW["view"], halo=halo, composite="compact", exchange_when_alone=True, native=True,
+                          min_capacity=64 if force_regather else 4096)
+    whole = rr.ReconIntegrationHip(scene, **KW)
+    ok = True
+    for k, sc in enumerate((scene, moved, scene, moved, moved)):
+        hip.broadcast_frame(0, sc)                          # the frame arrives on the root: RCCL broadcast (of one) + re-layout on every rank
+        drv.frame(mv, pr)
+        whole.upload_frame(sc)
+        whole.clearOccupiedBricks(); whole.markBricks(); whole.updateOccupiedBricks(); whole.integrate(); whole.drawF(mv, pr)
+        if k >= 3 or not force_regather:
+            drv.finish()
+            (wc, wdd), (sc_, sdd) = whole.framebuffer(), hip.framebuffer()
+            ok &= same(sdd, wdd) and same(sc_, wc) and int((wdd < 1).sum()) > 300
+    st = hip.comm_stats()
+    ok &= (st["regathers"] >= 1) if force_regather else (st["regathers"] == 0 and st["overflowed_frames"] == 0)
+    hip.comm_destroy()
+    hip.close()
+    q.put(bool(ok))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("halo,force_regather", [("exchange", False), ("recompute", False), ("recompute", True)])
+def test_native_rccl_exchange_with_one_rank(halo, force_regather):
+    """tsdf_comm_init / tsdf_broadcast_frame / tsdf_halo_exchange / tsdf_composite_gather / tsdf_composite_finish: RCCL called from inside the
+    library on the context's stream (what a C++ host drives), a world of one rank on the one GPU: the frames equal an unpartitioned
+    context's bit for bit, no host synchronisation inside the frame loop; with 64 records per gather the first gathers are too small
+    and tsdf_composite_finish repairs the latest one (the earlier truncated frames are counted)."""
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_alone, args=(q, halo, force_regather))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) is True

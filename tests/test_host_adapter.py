@@ -78,3 +78,19 @@ def test_harness_runs_a_frame_on_the_gpu():
     p = subprocess.run([build_harness()], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert "of 4096 voxels at sdist 0.02" in p.stdout
+
+
+def test_multi_gpu_host_example_compiles_and_links_against_the_library():
+    """host/multi_gpu_example.cpp -- the C++ loop a host adds to drive N GPUs through the native RCCL entry points --
+    compiles as C++11 and every tsdf_* symbol it calls resolves against librgbd_recon_hip.so."""
+    src = os.path.join(HOST, "multi_gpu_example.cpp")
+    obj = os.path.join(HOST, "multi_gpu_example.o")
+    p = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-c", src, "-o", obj], capture_output=True, text=True)
+    assert p.returncode == 0 and not p.stderr.strip(), p.stderr[-3000:]
+    und = subprocess.run(["nm", "-u", obj], capture_output=True, text=True).stdout
+    need = sorted(set(l.split()[-1] for l in und.splitlines() if " tsdf_" in l))
+    os.remove(obj)
+    assert "tsdf_comm_init" in need and "tsdf_composite_gather" in need and "tsdf_broadcast_frame" in need
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "rgbd-recon_amd", "librgbd_recon_hip.so"))
+    assert all(hasattr(lib, n) for n in need), [n for n in need if not hasattr(lib, n)]

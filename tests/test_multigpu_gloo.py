@@ -251,6 +251,7 @@ def test_capacity_rule():
     class D(mgpu.SlabDriver):
         def __init__(self, counts, npx, min_capacity):
             self.npx, self.min_capacity, self._c = npx, min_capacity, counts
+            self.caps, self.overflowed_frames = {}, 0
 
         def _counts_of(self, f):
             return torch.tensor(self._c[f], dtype=torch.int32)
@@ -260,6 +261,11 @@ def test_capacity_rule():
     assert d._capacity(2) == 15360                                            # 1.5 * 9000 + 1024 = 14524 -> the next multiple of 1024
     assert d._capacity(3) == 4096                                             # nothing hit two frames ago: the floor
     assert d._capacity(7) == 921600                                           # capped at one record per pixel
+    assert d.overflowed_frames == 0
+    # a frame that hit more rays than were gathered for it, and was no longer the latest when finish() ran, is counted
+    d.caps[5] = 4096                                                          # frame 5 was gathered with 4096 records; rank 0 hit 900000 rays
+    d._capacity(7)
+    assert d.overflowed_frames == 1
 
 
 # ------------------------------------------------------------------------------------------------ dedicated compositor rank

@@ -7,8 +7,8 @@ T=$(mktemp -d)
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-vectorize -fno-slp-vectorize -Wno-unused-result -Wno-unused-value $EXTRA"
 mkdir -p ../../build_variants
 for f in $(ls *.hip | sed 's/\.hip$//'); do /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -c $f.hip -o $T/$f.o & done
-for f in abi file_io calib_inverter; do /opt/rocm/bin/hipcc $FLAGS -c $f.cpp -o $T/$f.o & done
+for f in abi comm file_io calib_inverter; do /opt/rocm/bin/hipcc $FLAGS -c $f.cpp -o $T/$f.o & done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build_variants/lib_$NAME.so $T/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build_variants/lib_$NAME.so $T/*.o -ldl
 rm -rf $T
 echo built build_variants/lib_$NAME.so
