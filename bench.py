@@ -148,6 +148,12 @@ def main():
                     help="N > 1: 'dedicated' = rank 0 only receives, composites and fills holes and the volume is split over ranks 1..N-1 "
                          "(the gathering rank's image-space tail is longer than a slab's share of the volume work, so an even split makes "
                          "rank 0 every frame's critical path); 'shared' = N slabs, rank 0 composites as well.  auto = dedicated")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
+                    help="N > 1: the collectives through torch.distributed (RCCL), or from inside the library (tsdf_halo_exchange / tsdf_composite_gather / "
+                         "tsdf_broadcast_frame: RCCL called from C++ on the context's stream, what a C++ host drives; compact composite only)")
+    ap.add_argument("--frames", default="broadcast", choices=["broadcast", "resident"],
+                    help="N > 1: every new frame arrives on rank 0 and is broadcast to the slab ranks inside the step (default: the frame reaches ONE process "
+                         "in the reference, NetKinectArray.cpp:482-529), or both bench frames lie in every rank's HBM")
     ap.add_argument("--partition", default="even", choices=["even", "balanced"],
                     help="N > 1: slabs of equal thickness, or boundaries by the occupied bricks per tile layer of the bench frames (measured no better: "
                          "a slab's march cost follows its position along the view, not its bricks -- DESIGN.md section 6)")
@@ -195,6 +201,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if "RR_BENCH_DEVICE" not in os.environ and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) visible: one rank per GPU (RCCL refuses two ranks on one device)")
+    if "RR_BENCH_DEVICE" not in os.environ and local >= torch.cuda.device_count():
+        raise SystemExit(f"LOCAL_RANK {local} has no device (visible: {torch.cuda.device_count()})")
     # rehearsal hooks for a box with ONE GPU (never set by the driver): all ranks on device RR_BENCH_DEVICE, gloo instead of RCCL
     backend = os.environ.get("RR_BENCH_BACKEND", "nccl")
     if "RR_BENCH_DEVICE" in os.environ:
@@ -275,7 +285,8 @@ def main():
     if args.preprocess:
         hip.upload_raw_frame(scene)
     drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite,
-                        preprocess=args.preprocess, exchange_when_alone=alone, stream=stream, compositor="dedicated" if dedicated else "shared")
+                        preprocess=args.preprocess, exchange_when_alone=alone, stream=stream, compositor="dedicated" if dedicated else "shared",
+                        native=slabs_mode and args.exchange == "native")
     mv, pr = rr.scene.default_view(*VIEW)
     nsc = len(scenes)
     # the frames as they arrive, resident in HBM before anything is timed: every step re-lays one of them out (tsdf_upload_frame_dev) --
@@ -288,7 +299,13 @@ def main():
             raw.append((ts, tuple(t.data_ptr() for t in ts)))
         torch.cuda.synchronize()
 
+    bcast = slabs_mode and repack and args.frames == "broadcast"
+
     def step(d, i):
+        if bcast and d is drv:                             # the frame arrived on rank 0: broadcast, re-layout on the slab ranks, then the frame
+            d.broadcast_frame(0, raw[i % nsc][0] if rank == 0 else None)
+            d.frame(mv, pr)
+            return
         if repack:
             d.frame(mv, pr, new_frame=raw[i % nsc][1])
             return
@@ -531,7 +548,9 @@ def main():
                    "storage": ("sparse pool: %d of %d tiles in use" % hip.sparse_pool_stats()) if args.sparse_pool else "dense",
                    "parallelism": ((f"single GPU holding slab {alone_slab} of the volume, " if alone_slab else "single GPU, ") + "slab exchange over RCCL with one rank (rehearsal)" if alone else "single GPU") if world == 1 else
                                   (f"ONE volume in {world - 1} Z-slab(s) on ranks 1..{world - 1} + rank 0 as dedicated compositor (receive, composite, hole filling)" if dedicated else
-                                   f"ONE volume in {world} Z-slabs") + f" (strong scaling; slab boundaries {partition_note}; this rank's voxel planes {list(slab)}), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame"},
+                                   f"ONE volume in {world} Z-slabs") + f" (strong scaling; slab boundaries {partition_note}; this rank's voxel planes {list(slab)}), halo {args.halo}, RCCL {args.composite} hit gather to rank 0, no host sync per frame; "
+                                  + ("collectives called from inside the library (comm.cpp)" if args.exchange == "native" else "collectives through torch.distributed")
+                                  + ("; every new frame is broadcast from rank 0 inside the step" if bcast else "; both frames resident on every rank")},
         "stage_overlap": bool(overlap),
         "serial": serial,
         "static": static,

@@ -530,8 +530,11 @@ class ReconIntegrationHip:
 
     def comm_destroy(self): self._ck(self._L.tsdf_comm_destroy(self._c))
 
-    def broadcast_frame(self, root, scene=None):
-        """scene: on the root the frame as it arrived (host arrays), elsewhere None"""
+    def broadcast_frame(self, root, scene=None, dev_ptrs=None):
+        """on the root the frame as it arrived -- scene: host arrays, or dev_ptrs: (depth, quality, silhouette, colour) device pointers --, elsewhere nothing"""
+        if dev_ptrs is not None:
+            self._ck(self._L.tsdf_broadcast_frame(self._c, int(root), *[C.c_void_p(int(p)) for p in dev_ptrs]))
+            return
         if scene is None:
             self._ck(self._L.tsdf_broadcast_frame(self._c, int(root), None, None, None, None))
             return

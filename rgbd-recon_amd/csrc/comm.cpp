@@ -197,8 +197,8 @@ int32_t tsdf_comm_stats(tsdf_ctx* c, uint32_t* regathers, uint32_t* overflowed_f
   return TSDF_OK;
 }
 
-// SURVEY.md section 8e "Per-frame images are replicated: uploaded to every rank, or ncclBroadcast from the receiving rank".  Root passes the frame
-// as host pointers (as tsdf_upload_frame) -- or NULL for all four when it has put it into the staging area itself --, the others NULL.
+// SURVEY.md section 8e "Per-frame images are replicated: uploaded to every rank, or ncclBroadcast from the receiving rank".  The root passes the
+// frame's four arrays (host or device memory), the others NULL.
 int32_t tsdf_broadcast_frame(tsdf_ctx* c, uint32_t root, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour) {
   NEED_COMM(c);
   tsdf_ctx::Comm& M = c->comm;
@@ -209,12 +209,13 @@ int32_t tsdf_broadcast_frame(tsdf_ctx* c, uint32_t root, const float* depth_rg, 
   const size_t bytes = np * 16 + ((nc * 3 + 15) & ~(size_t)15);         // [depth_rg 8 B][quality 4 B][silhouette 4 B] per pixel, then RGB8
   if (!M.d_frame_stage) { HIP_TRY(c, hipMalloc((void**)&M.d_frame_stage, bytes)); M.frame_stage_bytes = bytes; }
   uint8_t* st = (uint8_t*)M.d_frame_stage;
-  if ((int)root == M.rank && depth_rg) {
-    if (!quality || !silhouette || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "the root passes all four arrays (or none: already staged)");
-    HIP_TRY(c, hipMemcpyAsync(st, depth_rg, np * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(st + np * 8, quality, np * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(st + np * 12, silhouette, np * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(st + np * 16, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
+  if ((int)root == M.rank) {
+    if (!depth_rg || !quality || !silhouette || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "the root passes all four arrays");
+    // (hipMemcpyDefault: the root's arrays may lie in host memory -- pinned, for a copy that really is asynchronous -- or in device memory)
+    HIP_TRY(c, hipMemcpyAsync(st, depth_rg, np * 8, hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(st + np * 8, quality, np * 4, hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(st + np * 12, silhouette, np * 4, hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(st + np * 16, colour, nc * 3, hipMemcpyDefault, c->stream));
   }
   if (M.world > 1) NCCL_TRY(c, rccl()->Broadcast(st, st, bytes, ncclUint8, (int)root, (ncclComm_t)M.comm, c->stream));
   if (!is_worker(c)) return TSDF_OK;                                    // a compositor without a slab reads no frame

@@ -240,6 +240,36 @@ class SlabDriver:
             b.composite_hits_dev(self.hitparts.data_ptr(), self.world, self.hitparts.stride(0) * 4)
             b.fillColors()
 
+    # ------------------------------------------------------------------ frame distribution ("ncclBroadcast from the receiving rank")
+    def broadcast_frame(self, root, tensors=None):
+        """The frame arrived on `root` (there: its four arrays as device tensors -- depth RG32F, quality, silhouette, colour RGB8 --, elsewhere
+        None): every rank gets a copy and the ranks that own a slab re-lay it out.  native: tsdf_broadcast_frame (RCCL called from C++);
+        else ONE torch.distributed broadcast of the packed arrays, then tsdf_upload_frame_dev."""
+        with self._on_stream():
+            if self.native:
+                self.b.broadcast_frame(root, dev_ptrs=[t.data_ptr() for t in tensors] if self.rank == root else None)
+                return
+            n, (h, w, ch, cw) = self.b.n, self.b._dims
+            npx, ncp = n * h * w, n * ch * cw
+            offs = (0, npx * 8, npx * 12, npx * 16)
+            if getattr(self, "frame_stage", None) is None:
+                self.frame_stage = torch.empty(npx * 16 + ((ncp * 3 + 15) // 16) * 16, dtype=torch.uint8, device=self.dev)
+            st = self.frame_stage
+            if self.rank == root:
+                for off, t in zip(offs, tensors):
+                    b = t.contiguous().view(torch.uint8).reshape(-1)
+                    st[off:off + b.numel()].copy_(b)
+            if self.world > 1:
+                if self.stage_cpu:
+                    t = st.cpu()
+                    dist.broadcast(t, src=root, group=self.group)
+                    st.copy_(t)
+                else:
+                    dist.broadcast(st, src=root, group=self.group)
+            if self.is_worker:
+                p = st.data_ptr()
+                self.b.upload_frame_dev(p + offs[0], p + offs[1], p + offs[2], p + offs[3])
+
     # ------------------------------------------------------------------ per frame
     def frame(self, mv, proj, new_frame=None):
         """new_frame: device pointers (depth_rg, quality, silhouette, colour) of a frame that has just arrived in device memory -- the
