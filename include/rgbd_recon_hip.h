@@ -325,8 +325,9 @@ int32_t tsdf_composite_gather(tsdf_ctx* ctx);
 int32_t tsdf_composite_finish(tsdf_ctx* ctx, uint32_t* regathered);
 /* gathers that tsdf_composite_finish had to repeat / frames that were composited from truncated record lists (0 in a healthy run) */
 int32_t tsdf_comm_stats(tsdf_ctx* ctx, uint32_t* regathers, uint32_t* overflowed_frames);
-/* smallest number of hit records gathered per rank and frame (default 4096) */
-int32_t tsdf_comm_set_min_capacity(tsdf_ctx* ctx, uint32_t records);
+/* bounds of the per-frame gather size guess: at least min_records (default 4096), at most max_records (0: one per view pixel).  The frame
+ * never depends on the guess (tsdf_composite_finish repairs a gather that was too small). */
+int32_t tsdf_comm_set_capacity_limits(tsdf_ctx* ctx, uint32_t min_records, uint32_t max_records);
 
 /* A whole-volume context marches in two passes: rays still running after `samples` samples are finished and shaded by a
  * wave-per-ray pass (0 switches the second pass off; the default is 24, or RR_MARCH_CAP).  A tuning knob: results do not depend on the

@@ -550,7 +550,7 @@ class ReconIntegrationHip:
         self._ck(self._L.tsdf_composite_finish(self._c, C.byref(r)))
         return bool(r.value)
 
-    def comm_set_min_capacity(self, records): self._ck(self._L.tsdf_comm_set_min_capacity(self._c, int(records)))
+    def comm_set_capacity_limits(self, min_records, max_records=0): self._ck(self._L.tsdf_comm_set_capacity_limits(self._c, int(min_records), int(max_records)))
 
     def comm_stats(self):
         a, b = C.c_uint32(), C.c_uint32()

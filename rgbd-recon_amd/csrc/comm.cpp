@@ -78,7 +78,7 @@ void release_comm_buffers(tsdf_ctx* c) {
   for (int k = 0; k < kRing; ++k) { if (M.h_counts[k]) hipHostFree(M.h_counts[k]); if (M.counts_evt[k]) hipEventDestroy(M.counts_evt[k]); }
   tsdf_ctx::Comm fresh;                                                 // the communicator, the roles and the statistics stay
   fresh.comm = M.comm; fresh.rank = M.rank; fresh.world = M.world; fresh.dedicated = M.dedicated;
-  fresh.regathers = M.regathers; fresh.overflowed_frames = M.overflowed_frames; fresh.min_capacity = M.min_capacity;
+  fresh.regathers = M.regathers; fresh.overflowed_frames = M.overflowed_frames; fresh.min_capacity = M.min_capacity; fresh.max_capacity = M.max_capacity;
   M = fresh;
 }
 
@@ -100,7 +100,7 @@ uint32_t max_hits(tsdf_ctx* c, uint64_t f) {
 // tsdf_composite_finish ran, it was composited from truncated lists -- counted, so that a caller can tell.
 uint32_t capacity_for(tsdf_ctx* c, uint64_t f) {
   tsdf_ctx::Comm& M = c->comm;
-  const uint32_t npx = (uint32_t)(c->vw * c->vh);
+  const uint32_t npx = M.max_capacity ? std::min(M.max_capacity, (uint32_t)(c->vw * c->vh)) : (uint32_t)(c->vw * c->vh);
   if (f < (uint64_t)kLag) return npx;                                   // no history yet: a slab cannot hit more rays than there are pixels
   const uint32_t m = max_hits(c, f - kLag);
   if (m > M.caps[(f - kLag) % kRing]) ++M.overflowed_frames;
@@ -108,12 +108,19 @@ uint32_t capacity_for(tsdf_ctx* c, uint64_t f) {
   return std::min(cap, npx);
 }
 
-int32_t exchange_hits(tsdf_ctx* c, uint32_t cap, bool record_counts, uint64_t f) {
+// Rank 0's own records never travel: it exports them -- ALL of them, whatever the capacity of the gather -- straight into its row of the
+// gather buffer, once per frame.  (They must not be exported again for a repeated gather: the first composite has overwritten the march
+// target they are read from.)
+int32_t exchange_hits(tsdf_ctx* c, uint32_t cap, bool first, uint64_t f) {
   tsdf_ctx::Comm& M = c->comm;
   Rccl* R = rccl();
-  if (is_worker(c)) { if (int32_t rc = tsdf_export_hits_dev(c, M.d_hitbuf, cap)) return rc; }   // (a compositor's header stays {0 records, 0 hits})
+  float* const own = M.rank == 0 ? M.d_hitparts : M.d_hitbuf;
+  if (is_worker(c) && (first || M.rank != 0)) {                         // (a compositor's header stays {0 records, 0 hits})
+    if (int32_t rc = tsdf_export_hits_dev(c, own, M.rank == 0 ? (uint32_t)(c->vw * c->vh) : cap)) return rc;
+  }
+  const bool record_counts = first;
   if (record_counts) {
-    NCCL_TRY(c, R->AllGather(M.d_hitbuf, M.d_counts, 2, ncclInt32, (ncclComm_t)M.comm, c->stream));
+    NCCL_TRY(c, R->AllGather(own, M.d_counts, 2, ncclInt32, (ncclComm_t)M.comm, c->stream));
     const int slot = (int)(f % kRing);
     HIP_TRY(c, hipMemcpyAsync(M.h_counts[slot], M.d_counts, (size_t)M.world * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(M.counts_evt[slot], c->stream));
@@ -131,7 +138,6 @@ int32_t exchange_hits(tsdf_ctx* c, uint32_t cap, bool record_counts, uint64_t f)
     NCCL_TRY(c, R->GroupEnd());
   }
   if (M.rank == 0) {
-    HIP_TRY(c, hipMemcpyAsync(M.d_hitparts, M.d_hitbuf, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));   // rank 0's own records
     if (int32_t rc = tsdf_composite_hits_dev(c, M.d_hitparts, (uint32_t)M.world, (uint64_t)M.hit_floats * sizeof(float))) return rc;
     if (c->fill_holes) { if (int32_t rc = tsdf_fill_colors(c)) return rc; }
   }
@@ -183,11 +189,12 @@ int32_t tsdf_comm_destroy(tsdf_ctx* c) {
   return TSDF_OK;
 }
 
-// smallest number of hit records gathered per rank (default 4096; tests force the repair path with a small one)
-int32_t tsdf_comm_set_min_capacity(tsdf_ctx* c, uint32_t records) {
+// bounds of the lagged guess of a frame's gather size: at least min_records (default 4096), at most max_records (0 = one per view pixel).  The
+// result never depends on the guess -- tsdf_composite_finish repairs a gather that was too small --; tests force that path with a small maximum.
+int32_t tsdf_comm_set_capacity_limits(tsdf_ctx* c, uint32_t min_records, uint32_t max_records) {
   NEED_COMM(c);
-  if (records < 1) return TSDF_ERR_INVALID_ARGUMENT;
-  c->comm.min_capacity = records;
+  if (min_records < 1 || (max_records && max_records < min_records)) return TSDF_ERR_INVALID_ARGUMENT;
+  c->comm.min_capacity = min_records; c->comm.max_capacity = max_records;
   return TSDF_OK;
 }
 int32_t tsdf_comm_stats(tsdf_ctx* c, uint32_t* regathers, uint32_t* overflowed_frames) {
@@ -250,11 +257,13 @@ int32_t tsdf_composite_gather(tsdf_ctx* c) {
   tsdf_ctx::Comm& M = c->comm;
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t npx = (size_t)c->vw * c->vh, hf = 8 + npx * 8;
-  if (!M.d_hitbuf || M.hit_floats != hf) {
+  if (!(M.d_hitbuf || M.d_hitparts) || M.hit_floats != hf) {
     HIP_TRY(c, sync_ctx(c));
     release_comm_buffers(c);
-    HIP_TRY(c, hipMalloc((void**)&M.d_hitbuf, hf * sizeof(float)));
-    HIP_TRY(c, hipMemsetAsync(M.d_hitbuf, 0, hf * sizeof(float), c->stream));
+    if (M.rank != 0) {
+      HIP_TRY(c, hipMalloc((void**)&M.d_hitbuf, hf * sizeof(float)));
+      HIP_TRY(c, hipMemsetAsync(M.d_hitbuf, 0, hf * sizeof(float), c->stream));
+    }
     if (M.rank == 0) { HIP_TRY(c, hipMalloc((void**)&M.d_hitparts, (size_t)M.world * hf * sizeof(float))); HIP_TRY(c, hipMemsetAsync(M.d_hitparts, 0, (size_t)M.world * hf * sizeof(float), c->stream)); }
     HIP_TRY(c, hipMalloc((void**)&M.d_counts, (size_t)M.world * 2 * sizeof(int32_t)));
     for (int k = 0; k < kRing; ++k) {

@@ -128,7 +128,7 @@ struct tsdf_ctx {
     int32_t* h_counts[3] = {nullptr, nullptr, nullptr}; hipEvent_t counts_evt[3] = {nullptr, nullptr, nullptr}; bool counts_rec[3] = {false, false, false};
     uint32_t caps[3] = {0, 0, 0};             // capacity each of the ring's frames was gathered with
     uint64_t frame_no = 0; bool have_last = false; uint64_t last_frame = 0; uint32_t last_cap = 0;
-    uint32_t regathers = 0, overflowed_frames = 0, min_capacity = 4096;
+    uint32_t regathers = 0, overflowed_frames = 0, min_capacity = 4096, max_capacity = 0;   // max_capacity: 0 = one record per pixel
     float* d_frame_stage = nullptr; size_t frame_stage_bytes = 0;                          // tsdf_broadcast_frame: the four arrays as delivered
   } comm;
   bool timers_on = false;

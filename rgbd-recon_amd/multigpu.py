@@ -111,7 +111,7 @@ class SlabDriver:
     LAG = 2            # frames between a hit count and its use as the gather size: its pinned copy has long arrived, the host never waits
 
     def __init__(self, backend, rank, world, buf_device, group=None, view=(1280, 720), halo="exchange", composite="dense", preprocess=False,
-                 exchange_when_alone=False, stream=None, min_capacity=4096, compositor="shared", native=False):
+                 exchange_when_alone=False, stream=None, min_capacity=4096, compositor="shared", native=False, max_capacity=0):
         """native: the two exchanges run inside the library (tsdf_halo_exchange / tsdf_composite_gather / tsdf_composite_finish, comm.cpp: RCCL
         called from C++ on the context's stream) and this class only issues the frame's calls -- what a C++ host does; torch.distributed is
         then used once, to carry the communicator's 128-byte id from rank 0 to the others.  Compact composite only."""
@@ -126,7 +126,7 @@ class SlabDriver:
         self.view, self.halo, self.composite = view, halo, composite
         self.preprocess = preprocess          # frames start from the raw sensor images: processTextures() instead of markBricks()
         self.exchanging = world > 1 or exchange_when_alone
-        self.stage_cpu = self.exchanging and dist.get_backend(group) == "gloo" and self.dev.type == "cuda"
+        self.stage_cpu = self.exchanging and not self.native and dist.get_backend(group) == "gloo" and self.dev.type == "cuda"
         self.stream = None
         if self.dev.type == "cuda":
             self.stream = stream if stream is not None else torch.cuda.Stream(self.dev)
@@ -144,7 +144,7 @@ class SlabDriver:
                 dist.broadcast_object_list(ids, src=0, group=group)
             with self._on_stream():
                 backend.comm_init(ids[0], rank, world, dedicated_compositor=self.dedicated)
-                backend.comm_set_min_capacity(self.min_capacity)
+                backend.comm_set_capacity_limits(self.min_capacity, max_capacity)
             self.stage_cpu = False
         elif self.exchanging:
             npx = view[0] * view[1]
@@ -223,11 +223,16 @@ class SlabDriver:
         return min(cap, self.npx)
 
     def _exchange_hits(self, cap, record_counts_of=None):
+        """record_counts_of: the frame number on the frame's first exchange, None on a repeated one (finish()).  Rank 0's own records never
+        travel: it exports them -- ALL of them, whatever the capacity of the gather -- straight into its row of the gather buffer, once
+        per frame (a repeated gather must not export them again: the first composite has overwritten the march target they are read from)."""
         b = self.b
-        if self.is_worker:
-            b.export_hits_dev(self.hitbuf.data_ptr(), cap)          # (a compositor's header stays {0 records, 0 hits})
+        first = record_counts_of is not None
+        own = self.hitparts[0] if self.rank == 0 else self.hitbuf
+        if self.is_worker and (first or self.rank != 0):
+            b.export_hits_dev(own.data_ptr(), self.npx if self.rank == 0 else cap)     # (a compositor's header stays {0 records, 0 hits})
         if record_counts_of is not None:
-            self._all_gather(self.counts, self.hitbuf[:2].view(torch.int32))
+            self._all_gather(self.counts, own[:2].view(torch.int32))
             slot = record_counts_of % (self.LAG + 1)
             self.counts_host[slot].copy_(self.counts, non_blocking=True)
             if self.stream is not None:
@@ -235,7 +240,10 @@ class SlabDriver:
                 ev.record(self.stream)
                 self.counts_evt[slot] = ev
         n = 8 + cap * 8
-        self._gather0([self.hitparts[r, :n] for r in range(self.world)] if self.rank == 0 else None, self.hitbuf[:n])
+        if self.world > 1:      # (rank 0's contribution to the collective is a header-sized dummy: its row is in place already)
+            if self.rank == 0 and getattr(self, "selfrow", None) is None:
+                self.selfrow = torch.zeros_like(self.hitbuf)
+            self._gather0([self.selfrow[:n]] + [self.hitparts[r, :n] for r in range(1, self.world)] if self.rank == 0 else None, self.hitbuf[:n])
         if self.rank == 0:
             b.composite_hits_dev(self.hitparts.data_ptr(), self.world, self.hitparts.stride(0) * 4)
             b.fillColors()

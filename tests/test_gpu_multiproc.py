@@ -160,7 +160,7 @@ def _native_alone(q, halo, force_regather):
     mv, pr = rr.scene.default_view(*KW["view"])
     hip = rr.ReconIntegrationHip(scene, slab=mgpu.slab_range(KW["res"][2], 0, 1), recompute_halo=(halo == "recompute"), **KW)
     drv = mgpu.SlabDriver(hip, 0, 1, "cuda:0", view=KW["view"], halo=halo, composite="compact", exchange_when_alone=True, native=True,
-                          min_capacity=64 if force_regather else 4096)
+                          min_capacity=64 if force_regather else 4096, max_capacity=64 if force_regather else 0)
     whole = rr.ReconIntegrationHip(scene, **KW)
     ok = True
     for k, sc in enumerate((scene, moved, scene, moved, moved)):
