@@ -68,10 +68,13 @@ bool mat_inv_d(const double* m, double* o) {
 Mat4 to_mat4(const double* d) { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (float)d[i]; return r; }
 
 void release_view(tsdf_ctx* c) {
-  hipFree(c->atlas.color); hipFree(c->atlas.depth); hipFree(c->d_peels); hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
+  for (int k = 0; k < 2; ++k) { hipFree(c->atlas_color[k]); hipFree(c->atlas_depth[k]); c->atlas_color[k] = nullptr; c->atlas_depth[k] = nullptr; }
+  c->atlas_parity = 0;
+  hipFree(c->d_peels); hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
   hipFree(c->d_long); c->d_long = nullptr;
   hipFree(c->d_tri_z); hipFree(c->d_tri_acc); c->d_tri_z = nullptr; c->d_tri_acc = nullptr;
-  hipFree(c->d_touched[0]); hipFree(c->d_touched[1]); c->d_touched[0] = c->d_touched[1] = nullptr; c->tile_history = false;
+  for (int k = 0; k < 3; ++k) { hipFree(c->d_touched[k]); c->d_touched[k] = nullptr; }
+  c->tile_history = false; c->touched_idx = 0;
   hipFree(c->d_hits); hipFree(c->d_hit_counters); hipFree(c->d_comp_key); c->d_hits = nullptr; c->d_hit_counters = nullptr; c->d_comp_key = nullptr;
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
@@ -107,6 +110,7 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   const size_t na = (size_t)A.aw * A.h, nv = (size_t)w * h;
   HIP_TRY(c, hipMalloc(&A.color, na * sizeof(float4)));
   HIP_TRY(c, hipMalloc(&A.depth, na * sizeof(float)));
+  c->atlas_color[0] = A.color; c->atlas_depth[0] = A.depth; c->atlas_parity = 0;    // (the second pyramid: on the first overlapped draw)
   HIP_TRY(c, hipMalloc(&c->d_peels, nv * sizeof(float4)));
   HIP_TRY(c, hipMalloc(&c->d_nsamples, nv * sizeof(float)));
   HIP_TRY(c, hipMalloc(&c->d_fb_c, nv * sizeof(float4)));
@@ -114,8 +118,8 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   HIP_TRY(c, hipMalloc(&c->d_hits, nv * 16));
   HIP_TRY(c, hipMalloc(&c->d_long, nv * sizeof(LongRay)));
   const size_t n_img_tiles = (size_t)((c->vw + 7) / 8) * ((c->vh + 7) / 8);
-  for (int k = 0; k < 2; ++k) { HIP_TRY(c, hipMalloc(&c->d_touched[k], n_img_tiles)); HIP_TRY(c, hipMemsetAsync(c->d_touched[k], 0, n_img_tiles, c->stream)); }
-  c->tile_history = false;
+  for (int k = 0; k < 3; ++k) { HIP_TRY(c, hipMalloc(&c->d_touched[k], n_img_tiles)); HIP_TRY(c, hipMemsetAsync(c->d_touched[k], 0, n_img_tiles, c->stream)); }
+  c->tile_history = false; c->touched_idx = 0;
   HIP_TRY(c, hipMalloc(&c->d_hit_counters, 4 * sizeof(uint32_t)));
   HIP_TRY(c, hipMemsetAsync(c->d_hit_counters, 0, 4 * sizeof(uint32_t), c->stream));
   if (const char* e = getenv("RR_MARCH_CAP")) c->march_cap = (uint32_t)atoi(e);
@@ -264,15 +268,19 @@ void timer_begin_on(tsdf_ctx* c, const char* name, hipStream_t st) { hipStream_t
 void timer_end_on(tsdf_ctx* c, const char* name, hipStream_t st) { hipStream_t keep = c->stream; c->stream = st; timer_end(c, name); c->stream = keep; }
 
 // stage overlap: GPU-side join (the context's stream waits for the hole filling that is still in flight) and host-side sync of both streams
+hipError_t join_fill_of(tsdf_ctx* c, int pyramid) {
+  if (!c->fill_pending[pyramid]) return hipSuccess;
+  c->fill_pending[pyramid] = false;
+  return hipStreamWaitEvent(c->stream, c->fill_done[pyramid], 0);
+}
 hipError_t join_fill(tsdf_ctx* c) {
-  if (!c->fill_pending) return hipSuccess;
-  c->fill_pending = false;
-  return hipStreamWaitEvent(c->stream, c->fill_done, 0);
+  const hipError_t a = join_fill_of(c, 0), b = join_fill_of(c, 1);
+  return a != hipSuccess ? a : b;
 }
 hipError_t sync_ctx(tsdf_ctx* c) {
   hipError_t e = hipStreamSynchronize(c->stream);
   if (c->fill_stream) { const hipError_t f = hipStreamSynchronize(c->fill_stream); if (e == hipSuccess) e = f; }
-  c->fill_pending = false;
+  c->fill_pending[0] = c->fill_pending[1] = false;
   return e;
 }
 
@@ -557,7 +565,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   for (auto& kv : c->timers) for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (c->fill_stream) hipStreamDestroy(c->fill_stream);
   if (c->march_done) hipEventDestroy(c->march_done);
-  if (c->fill_done) hipEventDestroy(c->fill_done);
+  for (hipEvent_t e : c->fill_done) if (e) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
   return TSDF_OK;
@@ -1027,7 +1035,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   {
     const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
     if (c->use_bricks && !c->full_classify && c->skip_space && whole && c->use_tile_history && c->tile_history && c->d_peels) {
-      pc.peels = (uint4*)c->d_peels; pc.touched_prev = c->d_touched[c->touched_parity ^ 1];
+      pc.peels = (uint4*)c->d_peels; pc.touched_prev = c->d_touched[(c->touched_idx + 2) % 3];     // the previous draw's tiles
       pc.w = c->vw; pc.h = c->vh; pc.ntx = (c->vw + 7) / 8; pc.n_tiles = pc.ntx * ((c->vh + 7) / 8);
       c->peels_cleared = true;
     }
@@ -1113,22 +1121,42 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
     timer_begin(c, "brickdraw");
     if (use_tiles && !c->tile_history) {
       const size_t n_img_tiles = (size_t)((c->vw + 7) / 8) * ((c->vh + 7) / 8);
-      HIP_TRY(c, hipMemsetAsync(c->d_touched[0], 0, n_img_tiles, c->stream));
-      HIP_TRY(c, hipMemsetAsync(c->d_touched[1], 0, n_img_tiles, c->stream));
+      for (int k = 0; k < 3; ++k) HIP_TRY(c, hipMemsetAsync(c->d_touched[k], 0, n_img_tiles, c->stream));
     }
-    launch_depth_limits(c->stream, P, c->br, c->d_peels, use_tiles ? c->d_touched[c->touched_parity] : nullptr,
-                        use_tiles && c->tile_history ? c->d_touched[c->touched_parity ^ 1] : nullptr, use_tiles && c->tile_history && c->peels_cleared ? 1 : 0);
+    launch_depth_limits(c->stream, P, c->br, c->d_peels, use_tiles ? c->d_touched[c->touched_idx] : nullptr,
+                        use_tiles && c->tile_history ? c->d_touched[(c->touched_idx + 2) % 3] : nullptr, use_tiles && c->tile_history && c->peels_cleared ? 1 : 0);
     timer_end(c, "brickdraw");
   }
   c->peels_cleared = false;                                              // consumed (or void: this draw did its own reset)
+  // two pyramids alternate while the hole filling runs beside the next frame (stage overlap): this draw takes the other one and only has
+  // to wait for the hole filling of the draw BEFORE the previous one -- long finished -- instead of the previous draw's
+  const bool two_pyramids = c->fill_holes && c->overlap_fill && !masked_direct(c);
+  if (two_pyramids) {
+    const int p = c->atlas_parity ^ 1;
+    if (!c->atlas_color[p]) {
+      const size_t na = (size_t)c->atlas.aw * c->atlas.h;
+      HIP_TRY(c, hipMalloc(&c->atlas_color[p], na * sizeof(float4)));
+      HIP_TRY(c, hipMalloc(&c->atlas_depth[p], na * sizeof(float)));
+      launch_clear_image(c->stream, c->atlas_color[p], c->atlas_depth[p], na, make_float4(0.0f, 1.0f, 0.0f, 0.0f), 1.0f);   // ViewLod::enable's clear
+      c->tile_history = false;
+    }
+    c->atlas_parity = p;
+    c->atlas.color = c->atlas_color[p]; c->atlas.depth = c->atlas_depth[p];
+    HIP_TRY(c, join_fill_of(c, p));
+  } else HIP_TRY(c, join_fill(c));                                       // the previous draw's hole filling still reads level 0 / writes the framebuffer
+  if (!c->tile_history) c->tiled_draws = 0;
   RayTarget RT = ray_target(c);
   if (use_tiles) {
-    RT.touched_cur = c->d_touched[c->touched_parity]; RT.touched_prev = c->d_touched[c->touched_parity ^ 1];
-    RT.rewrite_all = c->tile_history ? 0 : 1;
-    c->touched_parity ^= 1;
+    const int cur = c->touched_idx, prev = (cur + 2) % 3, oldest = (cur + 1) % 3;
+    RT.touched_cur = c->d_touched[cur]; RT.touched_prev = c->d_touched[prev];
+    RT.touched_prev_target = c->d_touched[two_pyramids ? oldest : prev];
+    RT.touched_recycle = c->d_touched[oldest];
+    RT.rewrite_all = c->tiled_draws >= 1 ? 0 : 1;
+    RT.rewrite_target = c->tiled_draws >= (two_pyramids ? 2 : 1) ? 0 : 1;
+    c->touched_idx = (cur + 1) % 3;
     c->tile_history = true;
+    c->tiled_draws = std::min(2, c->tiled_draws + 1);
   } else c->tile_history = false;
-  HIP_TRY(c, join_fill(c));                                              // the previous draw's hole filling still reads level 0 / writes the framebuffer
   timer_begin(c, "draw");
   timer_begin(c, "k_march");
   launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
@@ -1228,7 +1256,7 @@ static int32_t fill_colors_impl(tsdf_ctx* c, hipStream_t* used) {
     if (!c->fill_stream) {
       HIP_TRY(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking));
       HIP_TRY(c, hipEventCreateWithFlags(&c->march_done, hipEventDisableTiming));
-      HIP_TRY(c, hipEventCreateWithFlags(&c->fill_done, hipEventDisableTiming));
+      for (hipEvent_t& e : c->fill_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     HIP_TRY(c, hipEventRecord(c->march_done, c->stream));                 // everything the caller queued so far: the march / composite into level 0
     HIP_TRY(c, hipStreamWaitEvent(c->fill_stream, c->march_done, 0));
@@ -1238,7 +1266,7 @@ static int32_t fill_colors_impl(tsdf_ctx* c, hipStream_t* used) {
   launch_inpaint_pyramid(fs, c->atlas);
   launch_colorfill(fs, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
   timer_end_on(c, "holefill", fs);
-  if (c->overlap_fill) { HIP_TRY(c, hipEventRecord(c->fill_done, fs)); c->fill_pending = true; }
+  if (c->overlap_fill) { HIP_TRY(c, hipEventRecord(c->fill_done[c->atlas_parity], fs)); c->fill_pending[c->atlas_parity] = true; }
   HIP_TRY(c, hipGetLastError());
   if (used) *used = fs;
   return TSDF_OK;
@@ -1263,6 +1291,7 @@ int32_t tsdf_set_stage_overlap(tsdf_ctx* c, int32_t on) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, sync_ctx(c));
   c->overlap_fill = on != 0;
+  c->tile_history = false;                                               // one pyramid or two alternating: what the march targets hold changes
   return TSDF_OK;
 }
 
@@ -1584,7 +1613,7 @@ int32_t tsdf_timer_end(tsdf_ctx* c, const char* name) { CHECK_CTX(c); if (!name)
 int32_t tsdf_timer_end_after_fill(tsdf_ctx* c, const char* name) {
   CHECK_CTX(c);
   if (!name) return TSDF_ERR_INVALID_ARGUMENT;
-  timer_end_on(c, name, c->fill_pending ? c->fill_stream : c->stream);
+  timer_end_on(c, name, (c->fill_pending[0] || c->fill_pending[1]) ? c->fill_stream : c->stream);
   return TSDF_OK;
 }
 // the individual samples recorded since the last tsdf_timer_stats / tsdf_timer_samples of this timer (and resets it)

@@ -89,8 +89,14 @@ struct tsdf_ctx {
   Atlas atlas{};
   float4* d_peels = nullptr; float* d_nsamples = nullptr;
   void* d_hits = nullptr; uint32_t* d_hit_counters = nullptr; int hit_parity = 0;
-  uint8_t* d_touched[2]{}; int touched_parity = 0; bool tile_history = false;   // image-space dirty tiles (k_raymarch.hip); history is dropped
-                                                                                // whenever something else writes the march target
+  // image-space dirty tiles (k_raymarch.hip): three masks in rotation -- d_touched[touched_idx] is the coming draw's, (idx + 2) % 3 the
+  // previous draw's (peels, sample counts), (idx + 1) % 3 the one before (the other pyramid when two alternate; recycled by the march).
+  // The history is dropped whenever something else writes the march target; tiled_draws = consecutive draws since then (saturates at 2).
+  uint8_t* d_touched[3]{}; int touched_idx = 0; bool tile_history = false; int tiled_draws = 0;
+  // two pyramids, alternating per draw while stage overlap is on (round 3): the march of frame f + 1 writes level 0 of the OTHER one while
+  // the hole filling of frame f still reads this one (the reference's m_view_inpaint / m_view_inpaint2, for another reason: it swaps them
+  // between its transfer passes, recon_integration.cpp:279-338).  c->atlas points at the one the latest draw used.
+  float4* atlas_color[2]{}; float* atlas_depth[2]{}; int atlas_parity = 0;
   uint32_t* d_tri_z = nullptr; float4* d_tri_acc = nullptr; float min_length = 0.0125f;   // triangle-grid back-end; KinectCalibrationFile.cpp:96 default
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
   bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)
@@ -115,7 +121,7 @@ struct tsdf_ctx {
   // Stage overlap (round 3): the hole filling of draw f runs on a stream of its own beside whatever the caller queues next -- the brick
   // passes and the integrate of frame f + 1 do not touch the pyramid or the framebuffer --, tied to the context's stream by two events:
   // march_done (the fill waits for the march) and fill_done (the next writer / reader of the pyramid or the framebuffer waits for it).
-  hipStream_t fill_stream = nullptr; hipEvent_t march_done = nullptr, fill_done = nullptr; bool fill_pending = false;
+  hipStream_t fill_stream = nullptr; hipEvent_t march_done = nullptr, fill_done[2] = {nullptr, nullptr}; bool fill_pending[2] = {false, false};   // (per pyramid)
   bool overlap_fill = true;      // RR_OVERLAP_FILL=0 / tsdf_set_stage_overlap(ctx, 0): everything on the one stream, as in rounds 1 and 2
   // native multi-GPU exchange (comm.cpp): one RCCL communicator per context, every collective on the context's stream
   struct Comm {

@@ -263,14 +263,16 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
     const int ntx = (P.w + 7) >> 3, tx = blockIdx.x * 2 + (wv & 1), ty = blockIdx.y * 2 + (wv >> 1);
     if (tx >= ntx || ty * 8 >= P.h) return;
     const int t = ty * ntx + tx;
-    const uint8_t cur = R.touched_cur[t], before = R.touched_prev[t];
-    if (ln == 0) R.touched_prev[t] = 0;                                  // becomes the next frame's (empty) current mask
+    const uint8_t cur = R.touched_cur[t], before = R.touched_prev[t], before_target = R.touched_prev_target[t];
+    if (ln == 0) R.touched_recycle[t] = 0;                               // the oldest mask becomes the next draw's (empty) current one
     if (!cur) {
-      if ((before || R.rewrite_all) && inside) {
-        const size_t oi = (size_t)py * R.stride + px;
-        R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
-        R.depth[oi] = 1.0f;
-        R.nsamples[(size_t)py * P.w + px] = 0.0f;
+      if (inside) {
+        if (before_target || R.rewrite_target) {                         // what the draw that last wrote THIS target left here
+          const size_t oi = (size_t)py * R.stride + px;
+          R.color[oi] = make_float4(R.clear[0], R.clear[1], R.clear[2], R.clear[3]);
+          R.depth[oi] = 1.0f;
+        }
+        if (before || R.rewrite_all) R.nsamples[(size_t)py * P.w + px] = 0.0f;   // (one sample-count image: the previous draw's)
       }
       return;
     }

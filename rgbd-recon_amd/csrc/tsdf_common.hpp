@@ -238,7 +238,10 @@ void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, f
 struct LongRay { uint32_t pix, n, max_n; float prev; float x, y, z, pad; };   // state of a ray handed to k_march_long
 struct RayTarget {
   float4* color; float* depth; int stride; float* nsamples; const float4* peels; float clear[4];
-  const uint8_t* touched_cur; uint8_t* touched_prev; int rewrite_all;   // 8x8-pixel tile history (k_raymarch.hip); null = none
+  // 8x8-pixel tile history (k_raymarch.hip); null = none.  touched_prev: the previous draw's tiles (its sample counts), touched_prev_target:
+  // the tiles of the draw that last wrote THIS target (the previous one, or the one before when two pyramids alternate), touched_recycle:
+  // the oldest mask, zeroed for the next draw; rewrite_target / rewrite_all: no valid history for the target / for the sample counts
+  const uint8_t* touched_cur; const uint8_t* touched_prev; const uint8_t* touched_prev_target; uint8_t* touched_recycle; int rewrite_all, rewrite_target;
 };
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
                      void* hit_list, uint32_t* hit_counters, int parity, int phase = 0, void* long_list = nullptr, uint32_t cap = 0xffffffffu,
