@@ -108,11 +108,16 @@ int32_t tsdf_set_calibration(tsdf_ctx* ctx, uint32_t stream,
 int32_t tsdf_upload_frame(tsdf_ctx* ctx, const float* depth_rg, const float* quality,
                           const float* silhouette, const uint8_t* colour_rgb);
 
-/* The same frame from DEVICE memory (arrays produced on the GPU, or staged there by the caller): no copy, one re-layout launch on the
- * context's stream into the current frame slot -- what a new frame costs the path itself; integrate() is handed a new frame every
- * time in the reference (kinect_client.cpp:586-599, NetKinectArray.cpp:225-236).  Pointers aligned to their element size. */
+/* The same frame from DEVICE memory (arrays produced on the GPU, or staged there by the caller): no copy, one re-layout launch into a
+ * frame slot -- what a new frame costs the path itself; integrate() is handed a new frame every time in the reference
+ * (kinect_client.cpp:586-599, NetKinectArray.cpp:225-236).  Pointers aligned to their element size; colour may be NULL.
+ *   flags 0                      the arrays are written by work queued on the context's stream: the re-layout is ordered behind it
+ *   TSDF_FRAME_ARRAYS_COMPLETE   the arrays are complete when the call is made: the re-layout starts at once, on the context's lane
+ *                                ahead (see tsdf_set_stage_overlap), beside the previous frame's kernels
+ * The arrays must stay untouched until work queued on the context's stream after the next tsdf_integrate() / draw call runs. */
+#define TSDF_FRAME_ARRAYS_COMPLETE 1u
 int32_t tsdf_upload_frame_dev(tsdf_ctx* ctx, const float* depth_rg_dev, const float* quality_dev,
-                              const float* silhouette_dev, const uint8_t* colour_rgb_dev);
+                              const float* silhouette_dev, const uint8_t* colour_rgb_dev, uint32_t flags);
 
 /* Asynchronous upload: NetKinectArray keeps the incoming frame in a double-buffered, mapped PBO (framework/double_pixel_buffer.cpp:18-81:
  * the reader thread memcpy's into the back buffer, NetKinectArray.cpp:516-520; update() swaps and starts the PBO -> texture
@@ -346,10 +351,16 @@ int32_t tsdf_set_timer_filter(tsdf_ctx* ctx, const char* names);
 int32_t tsdf_timer_reserve(tsdf_ctx* ctx, const char* name, uint32_t n);   /* create n event pairs now instead of on first use */
 int32_t tsdf_timer_begin(tsdf_ctx* ctx, const char* name);
 int32_t tsdf_timer_end(tsdf_ctx* ctx, const char* name);
-/* Stage overlap (default on; RR_OVERLAP_FILL=0 in the environment turns it off at creation): fillColors() of a draw runs on a second
- * HIP stream of the context, beside whatever is queued next on the context's stream (the brick passes and integrate() of the next
- * frame touch neither the pyramid nor the framebuffer); the next draw, every download and tsdf_sync() wait for it.  Results are
- * identical either way.  tsdf_set_stage_overlap(ctx, 0) puts everything back on the one stream (synchronises first);
+/* Stage overlap (default on; RR_OVERLAP_FILL=0 in the environment turns it off at creation).  A frame's kernels form three chains that
+ * touch disjoint state, and the context runs them on three HIP streams of its own, tied by events:
+ *   the lane ahead      what a NEW frame needs before integrate(): its re-layout (tsdf_upload_frame / _dev) and the brick passes
+ *                       (clear / mark / update) run while the context's stream still works on the previous frame; the frame slots and the
+ *                       brick state exist twice and alternate
+ *   the context's stream  integrate(), depth limits, march, shading (and every collective / export)
+ *   the fill lane       fillColors() of a draw runs beside the next frame's integrate(); two pyramids alternate per draw
+ * integrate() / draws wait (on the GPU) for the lane ahead, every download and tsdf_sync() for all three.  Results are identical either
+ * way.  The lane ahead is not used after an explicit frame-slot call (tsdf_select_frame_slot, tsdf_frame_staging, tsdf_upload_frame_async)
+ * or with the pre-processing path.  tsdf_set_stage_overlap(ctx, 0) puts everything back on the one stream (synchronises first);
  * tsdf_timer_end_after_fill records a caller timer's end behind the hole filling in flight (a frame's latency). */
 int32_t tsdf_set_stage_overlap(tsdf_ctx* ctx, int32_t on);
 int32_t tsdf_timer_end_after_fill(tsdf_ctx* ctx, const char* name);

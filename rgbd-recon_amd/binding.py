@@ -260,10 +260,11 @@ class ReconIntegrationHip:
         self._ck(self._L.tsdf_upload_frame(self._c, _fp(_f32(scene["depth"])), _fp(_f32(scene["quality"])),
                                            _fp(_f32(scene["silhouette"])), col.ctypes.data_as(C.POINTER(C.c_uint8))))
 
-    def upload_frame_dev(self, depth_ptr, quality_ptr, silhouette_ptr, colour_ptr=0):
-        """the frame's arrays are in device memory already (raw device pointers, e.g. torch tensors' data_ptr()): one re-layout launch"""
+    def upload_frame_dev(self, depth_ptr, quality_ptr, silhouette_ptr, colour_ptr=0, complete=False):
+        """the frame's arrays are in device memory already (raw device pointers, e.g. torch tensors' data_ptr()): one re-layout launch.
+        complete: the arrays are finished when the call is made (TSDF_FRAME_ARRAYS_COMPLETE: the launch need not wait for the context's stream)"""
         self._ck(self._L.tsdf_upload_frame_dev(self._c, C.c_void_p(int(depth_ptr)), C.c_void_p(int(quality_ptr)), C.c_void_p(int(silhouette_ptr)),
-                                               C.c_void_p(int(colour_ptr)) if colour_ptr else None))
+                                               C.c_void_p(int(colour_ptr)) if colour_ptr else None, C.c_uint32(1 if complete else 0)))
 
     # asynchronous upload into the frame slot that is not current (double PBO analog) + slot switch
     def frame_staging(self):

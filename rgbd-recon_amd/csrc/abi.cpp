@@ -79,7 +79,8 @@ void release_view(tsdf_ctx* c) {
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
 void release_bricks(tsdf_ctx* c) {
-  hipFree(c->d_counters[0]); hipFree(c->d_counters[1]); hipFree(c->br.flags); hipFree(c->br.occupied);
+  hipFree(c->d_counters[0]); hipFree(c->d_counters[1]);
+  for (int k = 0; k < 2; ++k) { hipFree(c->d_flags[k]); hipFree(c->d_occupied[k]); c->d_flags[k] = nullptr; c->d_occupied[k] = nullptr; }
   c->d_counters[0] = c->d_counters[1] = nullptr;
   c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr;
   for (int a = 0; a < 3; ++a) {
@@ -234,12 +235,15 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
   }
   c->counters_cur = 0; c->spare_clean = true;
   B.counters = c->d_counters[0];
-  if (!c->d_occ_counts) HIP_TRY(c, hipMalloc(&c->d_occ_counts, 2 * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemset(c->d_occ_counts, 0, 2 * sizeof(uint32_t)));      // a new grid: no occupied list yet
+  if (!c->d_occ_counts) HIP_TRY(c, hipMalloc(&c->d_occ_counts, 3 * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemset(c->d_occ_counts, 0, 3 * sizeof(uint32_t)));      // a new grid: no occupied list yet
   B.num_occupied = c->d_occ_counts + c->occ_parity;
-  HIP_TRY(c, hipMalloc(&B.flags, (size_t)B.n));
-  HIP_TRY(c, hipMalloc(&B.occupied, (size_t)B.n * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemset(B.flags, 0, (size_t)B.n));
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(c, hipMalloc(&c->d_flags[k], (size_t)B.n));
+    HIP_TRY(c, hipMalloc(&c->d_occupied[k], (size_t)B.n * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemset(c->d_flags[k], 0, (size_t)B.n));
+  }
+  B.flags = c->d_flags[c->occ_parity]; B.occupied = c->d_occupied[c->occ_parity];
   return TSDF_OK;
 }
 
@@ -277,8 +281,45 @@ hipError_t join_fill(tsdf_ctx* c) {
   const hipError_t a = join_fill_of(c, 0), b = join_fill_of(c, 1);
   return a != hipSuccess ? a : b;
 }
+// ---- the lane ahead (see tsdf_ctx::pre_stream)
+bool pipelined(const tsdf_ctx* c) { return c->overlap_fill && !c->pipeline_blocked; }
+hipStream_t pre_enter(tsdf_ctx* c) {
+  if (!pipelined(c)) return c->stream;
+  if (!c->pre_stream) {
+    if (hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess) { c->pipeline_blocked = true; return c->stream; }
+  }
+  if (c->main_since_gate) {                                               // the lane's first call of a new frame
+    if (c->pre_gate_recorded) hipStreamWaitEvent(c->pre_stream, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
+    hipEventRecord(c->pre_gate, c->stream);
+    c->pre_gate_recorded = true; c->main_since_gate = false;
+    c->slot_flipped = c->counters_flipped = c->occ_flipped = false;
+  }
+  return c->pre_stream;
+}
+hipError_t pre_leave(tsdf_ctx* c, hipStream_t lane) {
+  if (lane == c->stream) return hipSuccess;
+  c->pre_pending = true;
+  return hipEventRecord(c->pre_done, lane);
+}
+hipError_t join_pre(tsdf_ctx* c) {
+  c->main_since_gate = true;
+  if (!c->pre_pending) return hipSuccess;
+  c->pre_pending = false;
+  return hipStreamWaitEvent(c->stream, c->pre_done, 0);
+}
+// leave the pipelined mode for good (explicit frame-slot calls, the pre-processing path): drain the lanes, everything on the context's stream from now on
+hipError_t block_pipeline(tsdf_ctx* c) {
+  if (c->pipeline_blocked) return hipSuccess;
+  c->pipeline_blocked = true;
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (c->pre_stream) { const hipError_t f = hipStreamSynchronize(c->pre_stream); if (e == hipSuccess) e = f; }
+  c->pre_pending = false;
+  return e;
+}
 hipError_t sync_ctx(tsdf_ctx* c) {
   hipError_t e = hipStreamSynchronize(c->stream);
+  if (c->pre_stream) { const hipError_t f = hipStreamSynchronize(c->pre_stream); if (e == hipSuccess) e = f; c->pre_pending = false; }
   if (c->fill_stream) { const hipError_t f = hipStreamSynchronize(c->fill_stream); if (e == hipSuccess) e = f; }
   c->fill_pending[0] = c->fill_pending[1] = false;
   return e;
@@ -345,7 +386,7 @@ int32_t alloc_frame_slot(tsdf_ctx* c, int k) {
   HIP_TRY(c, hipMalloc((void**)&S.depth, np * sizeof(float)));
   HIP_TRY(c, hipMalloc((void**)&S.color, nc * sizeof(uchar4)));
   HIP_TRY(c, hipMalloc((void**)&S.ranges, (size_t)c->cfg.num_streams * ((c->cfg.depth_w + 7) / 8) * ((c->cfg.depth_h + 7) / 8) * sizeof(float4)));
-  HIP_TRY(c, hipMemsetAsync(S.color, 0, nc * sizeof(uchar4), c->stream));
+  HIP_TRY(c, hipMemset(S.color, 0, nc * sizeof(uchar4)));                // (synchronous: the slot may be written on another lane right away)
   HIP_TRY(c, hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&S.released, hipEventDisableTiming));
   return TSDF_OK;
@@ -563,6 +604,10 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   for (int k = 0; k < 2; ++k) { if (c->h_wire[k]) hipHostFree(c->h_wire[k]); if (c->wire_done[k]) hipEventDestroy(c->wire_done[k]); }
   hipFree(c->d_wire);
   for (auto& kv : c->timers) for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  if (c->pre_stream) hipStreamDestroy(c->pre_stream);
+  if (c->pre_done) hipEventDestroy(c->pre_done);
+  if (c->pre_gate) hipEventDestroy(c->pre_gate);
+  if (c->src_ready) hipEventDestroy(c->src_ready);
   if (c->fill_stream) hipStreamDestroy(c->fill_stream);
   if (c->march_done) hipEventDestroy(c->march_done);
   for (hipEvent_t e : c->fill_done) if (e) hipEventDestroy(e);
@@ -680,39 +725,67 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
   return TSDF_OK;
 }
 
+// The frame slot a new frame is written to.  On the lane ahead: the OTHER slot (the context's stream may still read the current one for
+// the previous frame), once per frame of the lane; c->frame then points at it, so everything queued from now on reads the new frame.
+static int32_t begin_slot_write(tsdf_ctx* c, hipStream_t lane, bool keep_colour) {
+  if (lane == c->stream || c->slot_flipped) return TSDF_OK;
+  const int old = c->cur_slot, t = old ^ 1;
+  if (int32_t rc = alloc_frame_slot(c, t)) return rc;
+  if (keep_colour) {                                                     // "colour may be NULL (keeps the previous one)": the previous one lives in the other slot
+    const size_t nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
+    HIP_TRY(c, hipMemcpyAsync(c->slots[t].color, c->slots[old].color, nc * sizeof(uchar4), hipMemcpyDeviceToDevice, lane));
+  }
+  use_frame_slot(c, t);
+  c->slot_flipped = true;
+  return TSDF_OK;
+}
 int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour) {
   CHECK_CTX(c);
   if (!depth_rg || !quality || !silhouette) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "depth, quality and silhouette are required");
   HIP_TRY(c, hipSetDevice(c->device));
+  const hipStream_t lane = pre_enter(c);
+  if (int32_t rc = begin_slot_write(c, lane, colour == nullptr)) return rc;
   const FrameImages& F = c->frame;
   const size_t np = (size_t)c->cfg.num_streams * F.w * F.h, nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
-  HIP_TRY(c, hipMemcpyAsync(c->d_stage_depth, depth_rg, np * 8, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_stage_q, quality, np * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_stage_s, silhouette, np * 4, hipMemcpyHostToDevice, c->stream));
-  if (colour) HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
-  launch_pack_frame_fused(c->stream, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, (float*)c->frame.depth, c->slots[c->cur_slot].ranges,
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_depth, depth_rg, np * 8, hipMemcpyHostToDevice, lane));
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_q, quality, np * 4, hipMemcpyHostToDevice, lane));
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_s, silhouette, np * 4, hipMemcpyHostToDevice, lane));
+  if (colour) HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, lane));
+  launch_pack_frame_fused(lane, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, (float*)c->frame.depth, c->slots[c->cur_slot].ranges,
                           (int)c->cfg.num_streams, F.w, F.h, colour ? c->d_stage_col : nullptr, (uchar4*)F.color, nc);
   HIP_TRY(c, hipGetLastError());
   c->slots[c->cur_slot].have = true;
+  HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
 // The same with the four arrays already in device memory (a producer on the GPU: the pre-processing of another library, a decoder, a
-// staging buffer the caller DMA'd himself): no copy, one re-layout launch on the context's stream into the current frame slot.  This is
-// what a NEW frame costs the path itself (NetKinectArray hands integrate() a new frame every time, kinect_client.cpp:586-599).
-int32_t tsdf_upload_frame_dev(tsdf_ctx* c, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour) {
+// staging buffer the caller DMA'd himself): no copy, one re-layout launch into a frame slot.  This is what a NEW frame costs the path
+// itself (NetKinectArray hands integrate() a new frame every time, kinect_client.cpp:586-599).
+//   flags 0                      the arrays were (or are being) written by work queued on the context's stream: the re-layout is ordered behind it
+//   TSDF_FRAME_ARRAYS_COMPLETE   the arrays are complete now: the re-layout starts at once on the lane ahead, beside the previous frame's kernels
+// Either way the arrays must stay untouched until work queued on the context's stream AFTER the next tsdf_integrate() / draw call runs.
+int32_t tsdf_upload_frame_dev(tsdf_ctx* c, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour, uint32_t flags) {
   CHECK_CTX(c);
   if (!depth_rg || !quality || !silhouette) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "depth, quality and silhouette are required");
   if (((uintptr_t)depth_rg & 7u) || ((uintptr_t)quality & 3u) || ((uintptr_t)silhouette & 3u) || ((uintptr_t)colour & 3u))
     FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "device arrays must be aligned to their element size (depth 8 bytes, the others 4)");
   HIP_TRY(c, hipSetDevice(c->device));
+  const hipStream_t lane = pre_enter(c);
+  if (lane != c->stream && !(flags & TSDF_FRAME_ARRAYS_COMPLETE)) {      // the producer may be work on the context's stream: behind all of it
+    if (!c->src_ready) HIP_TRY(c, hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->src_ready, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(lane, c->src_ready, 0));
+  }
+  if (int32_t rc = begin_slot_write(c, lane, colour == nullptr)) return rc;
   const FrameImages& F = c->frame;
   const size_t nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
-  timer_begin(c, "0repack");
-  launch_pack_frame_fused(c->stream, depth_rg, quality, silhouette, (float4*)F.dqs, (float*)c->frame.depth, c->slots[c->cur_slot].ranges,
+  timer_begin_on(c, "0repack", lane);
+  launch_pack_frame_fused(lane, depth_rg, quality, silhouette, (float4*)F.dqs, (float*)c->frame.depth, c->slots[c->cur_slot].ranges,
                           (int)c->cfg.num_streams, F.w, F.h, colour, (uchar4*)F.color, nc);
-  timer_end(c, "0repack");
+  timer_end_on(c, "0repack", lane);
   HIP_TRY(c, hipGetLastError());
   c->slots[c->cur_slot].have = true;
+  HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
 
@@ -737,6 +810,7 @@ static int32_t ensure_async_upload(tsdf_ctx* c) {
 int32_t tsdf_frame_staging(tsdf_ctx* c, float** depth_rg, float** quality, float** silhouette, uint8_t** colour) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, block_pipeline(c));                                          // the caller manages the two frame slots himself from here on
   if (int32_t rc = ensure_async_upload(c)) return rc;
   const int k = c->stage_k;
   if (c->stage_busy[k]) { HIP_TRY(c, hipEventSynchronize(c->stage_done[k])); c->stage_busy[k] = false; }   // its last upload has left the buffer
@@ -777,6 +851,7 @@ int32_t tsdf_select_frame_slot(tsdf_ctx* c, uint32_t slot) {
   CHECK_CTX(c);
   if (slot > 1) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "frame slot must be 0 or 1");
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, block_pipeline(c));                                          // the caller manages the two frame slots himself from here on
   if (int32_t rc = alloc_frame_slot(c, (int)slot)) return rc;
   tsdf_ctx::FrameSlot& N = c->slots[slot];
   if ((int)slot != c->cur_slot) {
@@ -808,6 +883,7 @@ int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t
   CHECK_CTX(c);
   if (!depth_raw || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "raw depth and colour are required");
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, block_pipeline(c));                                          // the pre-processing passes write the images AND mark the bricks: one stream
   const FrameImages& F = c->frame;
   const size_t np = (size_t)c->cfg.num_streams * F.w * F.h, nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
   if (int32_t rc = ensure_pre_buffers(c)) return rc;
@@ -872,6 +948,7 @@ int32_t tsdf_upload_wire_frame(tsdf_ctx* c, const void* message, uint64_t bytes,
   const uint64_t want = (cs + ds) * c->cfg.num_streams;
   if (!message || bytes != want) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "wire message must be %llu bytes (%u x (colour %llu + depth %llu)), got %llu", (unsigned long long)want, c->cfg.num_streams, (unsigned long long)cs, (unsigned long long)ds, (unsigned long long)bytes);
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, block_pipeline(c));
   if (int32_t rc = ensure_pre_buffers(c)) return rc;
   if (c->wire_capacity < want) {
     HIP_TRY(c, sync_ctx(c));
@@ -927,6 +1004,7 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
     if (!c->have_limits[i] || !c->have_cam[i]) FAIL(c, TSDF_ERR_STATE, "stream %u needs tsdf_set_depth_limits and tsdf_set_camera_position", i);
   }
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, block_pipeline(c));
   PreParams& P = c->pre;
   P.W = c->frame.w; P.H = c->frame.h; P.N = (int)c->cfg.num_streams;
   for (int a = 0; a < 3; ++a) { P.bbox_min[a] = c->cfg.bbox_min[a]; P.bbox_max[a] = c->cfg.bbox_max[a]; }
@@ -973,12 +1051,18 @@ static int32_t require_inputs(tsdf_ctx* c, bool need_xyz, bool need_uv) {
 int32_t tsdf_clear_bricks(tsdf_ctx* c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  timer_begin(c, "bricks");
-  if (c->spare_clean) {                                                  // the other buffer was zeroed by the last integrate(): swap
+  const hipStream_t lane = pre_enter(c);
+  timer_begin_on(c, "bricks", lane);
+  if (lane != c->stream) {                                               // the lane ahead: the other counter buffer (the previous frame's draw may still read this one)
+    if (!c->counters_flipped) { c->counters_cur ^= 1; c->br.counters = c->d_counters[c->counters_cur]; c->counters_flipped = true; }
+    c->spare_clean = false;
+    HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), lane));
+  } else if (c->spare_clean) {                                           // the other buffer was zeroed by the last integrate(): swap
     c->counters_cur ^= 1;
     c->br.counters = c->d_counters[c->counters_cur];
     c->spare_clean = false;
   } else HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
 int32_t tsdf_mark_bricks(tsdf_ctx* c) {
@@ -986,18 +1070,32 @@ int32_t tsdf_mark_bricks(tsdf_ctx* c) {
   int32_t rc = require_inputs(c, true, false);
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
-  launch_mark_bricks(c->stream, c->luts, c->frame, c->br);
+  const hipStream_t lane = pre_enter(c);
+  launch_mark_bricks(lane, c->luts, c->frame, c->br);
   HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
 int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->device));
-  c->occ_parity ^= 1;
-  c->br.num_occupied = c->d_occ_counts + c->occ_parity;              // zero since the previous update (or creation) re-armed it
-  launch_update_occupied(c->stream, c->br, c->min_voxels, c->d_occ_counts + (c->occ_parity ^ 1));
+  const hipStream_t lane = pre_enter(c);
+  if (lane != c->stream) {
+    // the lane ahead: the other occupancy set (flags, list, count) -- the previous frame's integrate / draw may still read this one --, its
+    // count zeroed here instead of by the previous update (which would zero the word the context's stream is reading)
+    if (!c->occ_flipped) { c->occ_parity ^= 1; c->occ_flipped = true; }
+    c->br.num_occupied = c->d_occ_counts + c->occ_parity; c->br.flags = c->d_flags[c->occ_parity]; c->br.occupied = c->d_occupied[c->occ_parity];
+    HIP_TRY(c, hipMemsetAsync(c->br.num_occupied, 0, sizeof(uint32_t), lane));
+    launch_update_occupied(lane, c->br, c->min_voxels, c->d_occ_counts + 2);          // (a third word takes the kernel's re-arming store)
+  } else {
+    c->occ_parity ^= 1;
+    c->br.num_occupied = c->d_occ_counts + c->occ_parity;            // zero since the previous update (or creation) re-armed it
+    c->br.flags = c->d_flags[c->occ_parity]; c->br.occupied = c->d_occupied[c->occ_parity];
+    launch_update_occupied(c->stream, c->br, c->min_voxels, c->d_occ_counts + (c->occ_parity ^ 1));
+  }
   HIP_TRY(c, hipGetLastError());
-  timer_end(c, "bricks");
+  timer_end_on(c, "bricks", lane);
+  HIP_TRY(c, pre_leave(c, lane));
   if (ratio) return tsdf_occupied_ratio(c, ratio);                     // the reference reads the count back every frame (:432-440); here only on request
   return TSDF_OK;
 }
@@ -1005,6 +1103,7 @@ int32_t tsdf_occupied_ratio(tsdf_ctx* c, float* ratio) {
   CHECK_CTX(c);
   if (!ratio) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, join_pre(c));
   HIP_TRY(c, hipMemcpyAsync(c->h_num_occupied, c->br.num_occupied, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, sync_ctx(c));
   *ratio = (float)*c->h_num_occupied / (float)c->br.n;                 // :440
@@ -1017,6 +1116,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   if (rc) return rc;
   if (c->vol.slot && !c->use_bricks) FAIL(c, TSDF_ERR_STATE, "a sparse tile pool needs brick culling (setUseBricks(true)): without it every tile is active");
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, join_pre(c));
   timer_begin(c, "2integrate");
   int lds = 2;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = std::min(lds, c->lds_ok[i]);
@@ -1040,7 +1140,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
       c->peels_cleared = true;
     }
   }
-  if (c->use_bricks && !c->full_classify && !c->spare_clean) {          // ... and zero the spare counter buffer for the next clearOccupiedBricks()
+  if (c->use_bricks && !c->full_classify && !c->spare_clean && !pipelined(c)) {   // ... and zero the spare counter buffer for the next clearOccupiedBricks() (the lane ahead clears its own)
     pc.zero = c->d_counters[c->counters_cur ^ 1]; pc.zero_words = (uint32_t)c->counter_words;
     c->spare_clean = true;
   }
@@ -1109,6 +1209,7 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   HIP_TRY(c, hipSetDevice(c->device));
   ViewParams P;
   if (!make_view_params(c, mv, pr, &P)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "singular modelview / projection matrix");
+  HIP_TRY(c, join_pre(c));
   if (outer_timer) timer_begin(c, "3recon");
   const bool partial = !(c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
   const bool shifted = P.vp_org[0] != 0 || P.vp_org[1] != 0 || P.vp_off[0] != 0.0f || P.vp_off[1] != 0.0f;
@@ -1211,6 +1312,7 @@ int32_t tsdf_draw_points(tsdf_ctx* c, const float* mv, const float* pr) {
   if (!c->d_comp_key) HIP_TRY(c, hipMalloc(&c->d_comp_key, (size_t)c->vw * c->vh * sizeof(unsigned long long)));
   FrameImages F = c->frame;
   F.depth = (float*)c->frame.depth;
+  HIP_TRY(c, join_pre(c));
   timer_begin(c, "points");
   HIP_TRY(c, join_fill(c));
   launch_draw_points(c->stream, P, Q, c->luts, F, c->d_comp_key, c->d_fb_c, c->d_fb_d);
@@ -1236,6 +1338,7 @@ int32_t tsdf_draw_trigrid(tsdf_ctx* c, const float* mv, const float* pr) {
   for (int a = 0; a < 3; ++a) { Q.bbox_min[a] = c->cfg.bbox_min[a]; Q.bbox_max[a] = c->cfg.bbox_max[a]; }
   const size_t nv = (size_t)c->vw * c->vh;
   if (!c->d_tri_z) { HIP_TRY(c, hipMalloc(&c->d_tri_z, nv * sizeof(uint32_t))); HIP_TRY(c, hipMalloc(&c->d_tri_acc, nv * sizeof(float4))); }
+  HIP_TRY(c, join_pre(c));
   timer_begin(c, "trigrid");
   HIP_TRY(c, join_fill(c));
   launch_draw_trigrid(c->stream, P, Q, c->luts, c->frame, c->min_length, c->d_tri_z, c->d_tri_acc, c->d_fb_c, c->d_fb_d);

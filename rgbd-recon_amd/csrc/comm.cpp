@@ -226,7 +226,7 @@ int32_t tsdf_broadcast_frame(tsdf_ctx* c, uint32_t root, const float* depth_rg, 
   }
   if (M.world > 1) NCCL_TRY(c, rccl()->Broadcast(st, st, bytes, ncclUint8, (int)root, (ncclComm_t)M.comm, c->stream));
   if (!is_worker(c)) return TSDF_OK;                                    // a compositor without a slab reads no frame
-  return tsdf_upload_frame_dev(c, (const float*)st, (const float*)(st + np * 8), (const float*)(st + np * 12), st + np * 16);
+  return tsdf_upload_frame_dev(c, (const float*)st, (const float*)(st + np * 8), (const float*)(st + np * 12), st + np * 16, 0);   // (behind the broadcast on the context's stream)
 }
 
 int32_t tsdf_halo_exchange(tsdf_ctx* c) {

@@ -123,6 +123,18 @@ struct tsdf_ctx {
   // march_done (the fill waits for the march) and fill_done (the next writer / reader of the pyramid or the framebuffer waits for it).
   hipStream_t fill_stream = nullptr; hipEvent_t march_done = nullptr, fill_done[2] = {nullptr, nullptr}; bool fill_pending[2] = {false, false};   // (per pyramid)
   bool overlap_fill = true;      // RR_OVERLAP_FILL=0 / tsdf_set_stage_overlap(ctx, 0): everything on the one stream, as in rounds 1 and 2
+  // ... and a third lane AHEAD of the context's stream (round 3): what a new frame needs before integrate() can run -- its re-layout and the
+  // brick passes (clear / mark / update) -- reads only the new frame and writes state nobody else writes, so it runs on `pre_stream` while
+  // the context's stream still works on the previous frame.  Everything the lane writes exists twice and alternates: the frame slots (flip at
+  // the first upload of a frame), the brick counters (flip at clearOccupiedBricks), flags + occupied list + count (flip at
+  // updateOccupiedBricks).  Two events tie the lanes: pre_done (integrate / draw wait for the lane) and pre_gate (recorded on the context's
+  // stream at the lane's first call of a frame, waited for at its first call of the NEXT frame: what the lane overwrites then was last read
+  // two frames ago).  Off with stage overlap off, after an explicit frame-slot call (tsdf_select_frame_slot, tsdf_upload_frame_async) and for
+  // the pre-processing path.
+  hipStream_t pre_stream = nullptr; hipEvent_t pre_done = nullptr, pre_gate = nullptr, src_ready = nullptr;
+  bool pre_pending = false, pre_gate_recorded = false, main_since_gate = true, pipeline_blocked = false;
+  bool slot_flipped = false, counters_flipped = false, occ_flipped = false;     // once per frame of the lane
+  uint8_t* d_flags[2]{}; uint32_t* d_occupied[2]{};                             // the two occupancy sets (Bricks::flags / occupied point at the latest update's)
   // native multi-GPU exchange (comm.cpp): one RCCL communicator per context, every collective on the context's stream
   struct Comm {
     void* comm = nullptr;                     // ncclComm_t
@@ -148,6 +160,9 @@ struct tsdf_ctx {
 
 // helpers defined in abi.cpp
 namespace rrhost {
+hipStream_t pre_enter(tsdf_ctx* c);     // the lane a frame-preparing call queues its work on (the context's stream when the lane is off); opens the lane's frame
+hipError_t pre_leave(tsdf_ctx* c, hipStream_t lane);   // ... and after queuing it
+hipError_t join_pre(tsdf_ctx* c);       // GPU side: the context's stream waits for the lane; called by every consumer of a frame's images / brick state
 void timer_begin(tsdf_ctx* c, const char* name);
 void timer_end(tsdf_ctx* c, const char* name);
 hipError_t join_fill(tsdf_ctx* c);      // GPU side: the context's stream waits for the hole filling in flight on the second stream

@@ -288,7 +288,7 @@ class SlabDriver:
     def _frame(self, mv, proj, new_frame=None):
         b = self.b
         if self.is_worker and new_frame is not None:
-            b.upload_frame_dev(*new_frame)
+            b.upload_frame_dev(*new_frame, complete=True)
         if self.is_worker:
             b.clearOccupiedBricks()
             if self.preprocess:

@@ -32,7 +32,7 @@ def test_device_resident_frame_upload_equals_host_upload(rr, w, h, cw, ch, n):
         for k, sc in enumerate((b, a, b)):
             t = [torch.from_numpy(np.ascontiguousarray(sc[key])).cuda() for key in ("depth", "quality", "silhouette", "color")]
             torch.cuda.synchronize()
-            dev.upload_frame_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr() if k != 1 else 0)   # colour is optional
+            dev.upload_frame_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr() if k != 1 else 0, complete=(k == 2))   # colour is optional
             if k == 1:
                 dev.sync(); dev.upload_frame(sc)                       # (frame 1: colour through the host path, same result)
             host.upload_frame(sc); orc.upload_frame(sc)
@@ -66,7 +66,7 @@ def test_stage_overlap_of_hole_filling_changes_nothing(rr):
     for rounds in range(2):
         for n, k in enumerate(order):                     # eight frames queued without a single host read
             for o in (over, plain):
-                o.upload_frame_dev(*[t.data_ptr() for t in raw[k]])
+                o.upload_frame_dev(*[t.data_ptr() for t in raw[k]], complete=True)
                 frame_nosync(o, mvs[n % 3], pr)
         if rounds == 0:
             over.set_stage_overlap(False); over.set_stage_overlap(True)       # (synchronises, drops and re-arms the second stream's state)

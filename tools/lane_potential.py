@@ -16,7 +16,7 @@ mv, pr = rr.scene.default_view(*bench.VIEW)
 raw = [torch.from_numpy(np.ascontiguousarray(a[k])).cuda() for k in ("depth", "quality", "silhouette", "color")]
 ptr = [t.data_ptr() for t in raw]
 def full():
-    hip.upload_frame_dev(*ptr); hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv, pr)
+    hip.upload_frame_dev(*ptr, complete=True); hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv, pr)
 def main_only():
     hip.integrate(); hip.drawF(mv, pr)
 for name, fn in (("full step", full), ("integrate + drawF only", main_only), ("full step", full)):
