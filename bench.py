@@ -79,7 +79,7 @@ def culled_integrate_bytes(np, hip, scenes, res, n_streams):
     averaged over the frames of the timed region.  (the dense formula only applies with use_bricks off.)"""
     tot, tiles_n = 0.0, []
     for k, sc in enumerate(scenes):
-        hip.select_frame_slot(k); hip.upload_frame(sc)       # (the timed loop re-lays new frames out into the current slot: put the scene back)
+        hip.upload_frame(sc)
         hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate()
         tiles, _ = hip.active_tiles()
         touched = np.zeros((LUT, LUT, LUT), bool)
@@ -269,13 +269,18 @@ def main():
         k_, n_ = int(parts[0]), int(parts[1])
         slab = balanced_ranges(n_)[k_] if len(parts) > 2 else mg.slab_range(cfg["res"][2], k_, n_)
 
+    # the frames as they arrive lie in HBM before anything is timed and every step re-lays one of them out (tsdf_upload_frame_dev) --
+    # except in the pre-processing / ingest modes (they produce the images themselves) and the frames-in-flight throughput mode
+    repack = not (args.preprocess or args.frames_in_flight > 1)
+
     def make_ctx(slab=(0, 0), recompute=False, sparse=0):
         h = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=VIEW, device=local, slab=slab,
                                    recompute_halo=recompute, sparse_pool_tiles=sparse)
         h.setUseBricks(cfg["use_bricks"]); h.setSpaceSkip(cfg["skip_space"]); h.setColorFilling(cfg["fill_holes"])
-        for k, sc in enumerate(scenes[1:], 1):            # the second resident frame
-            h.select_frame_slot(k); h.upload_frame(sc)
-        h.select_frame_slot(0)
+        if not repack:                                    # the second resident frame (modes without a per-frame re-layout alternate the two frame slots;
+            for k, sc in enumerate(scenes[1:], 1):        #  an explicit frame-slot call switches the context's lane ahead off for good)
+                h.select_frame_slot(k); h.upload_frame(sc)
+            h.select_frame_slot(0)
         return h
 
     hip = make_ctx(slab, args.halo == "recompute" and slabs_mode, args.sparse_pool)
@@ -289,9 +294,6 @@ def main():
                         native=slabs_mode and args.exchange == "native")
     mv, pr = rr.scene.default_view(*VIEW)
     nsc = len(scenes)
-    # the frames as they arrive, resident in HBM before anything is timed: every step re-lays one of them out (tsdf_upload_frame_dev) --
-    # except in the pre-processing / ingest modes (they produce the images themselves) and the frames-in-flight throughput mode
-    repack = not (args.preprocess or args.frames_in_flight > 1)
     raw = []
     if repack:
         for sc in scenes:
@@ -347,7 +349,10 @@ def main():
         if rank == 0:
             whole = make_ctx()
             for k in range(nsc):
-                whole.select_frame_slot(k)
+                if repack:
+                    whole.upload_frame(scenes[k])
+                else:
+                    whole.select_frame_slot(k)
                 whole.clearOccupiedBricks(); whole.markBricks(); whole.updateOccupiedBricks(False); whole.integrate(); whole.drawF(mv, pr)
                 (wa, wd, wn, _), (wc, wdd) = whole.view_images(), whole.framebuffer()
                 (sa, sd, sn), (sc, sdd) = got[k]
@@ -370,7 +375,8 @@ def main():
 
     # host -> device frame upload, outside the timed region (value = HBM-resident rate); reported for the PCIe-inclusive figure
     hip.sync()
-    hip.select_frame_slot(0)        # scene A's slot (the slab check above leaves the LAST slot current: uploading A there would overwrite frame B)
+    if not repack:
+        hip.select_frame_slot(0)    # scene A's slot (the slab check above leaves the LAST slot current: uploading A there would overwrite frame B)
     tu0 = time.perf_counter()
     for _ in range(5):
         hip.upload_frame(scene)
@@ -438,21 +444,27 @@ def main():
             d.b.set_stage_overlap(overlap)
         for i in range(20):                               # back into the overlapped steady state
             step(drv, i)
-        # ... and the timed region records the same two events per frame in situ
-        if dom:
-            hip.enable_timers(True)
     barrier()
-    # at most ~200 event pairs in flight: many hundreds of un-synchronised events slow the launch path down (600 steps with an
-    # event pair each ran 12 % slower than 200), so long runs time the dominant kernel on every stride-th frame
-    stride = max(1, args.steps // 200)
-    timing = bool(dom)
+    # ---- the timed region: exactly --steps frames as shipped (stage overlap on), no event recorded inside (an event pair per frame on the
+    # context's stream costs the frame 4-8 us: the kernel timers run in the serial pass above and in the overlapped pass below)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if timing and stride > 1:
-            hip.enable_timers(i % stride == 0)
         step(slots[i % len(slots)], i // len(slots) if len(slots) > 1 else i)
     barrier()
     dt = time.perf_counter() - t0
+    dom_ms_insitu = None
+    if not args.no_timers:                                # the dominant kernel in situ (beside the other lanes' kernels), a pass of its own
+        if dom:                                           # (every rank runs the loop -- its steps hold collectives --, whether it times a kernel or not)
+            hip.timer_stats(dom)                          # (drops the serial pass's samples)
+        stride = max(1, args.steps // 200)
+        for i in range(args.steps):
+            hip.enable_timers(bool(dom) and i % stride == 0)
+            step(drv, i)
+        barrier()
+        hip.enable_timers(False)
+        if dom:
+            n, ms = hip.timer_stats(dom)
+            dom_ms_insitu = ms / n if n else None
     hip.enable_timers(False)
     hip.set_timer_filter(None)
 
@@ -464,12 +476,7 @@ def main():
         return x
 
     dt = max_over_ranks(dt)
-    dom_ms = None
-    dom_ms_insitu = None
-    if dom:
-        n, ms = hip.timer_stats(dom)
-        dom_ms_insitu = ms / n if n else None
-        dom_ms = dom_ms_serial if dom_ms_serial else dom_ms_insitu
+    dom_ms = dom_ms_serial if dom_ms_serial else dom_ms_insitu
 
     def timed(n_steps, sel):
         barrier()
@@ -485,24 +492,35 @@ def main():
     if nsc > 1:
         def st(i):
             drv.frame(mv, pr, new_frame=raw[0][1] if repack else None)
-        hip.select_frame_slot(0)
+        if not repack:
+            hip.select_frame_slot(0)
         timed(20, st)
         ds = timed(args.steps, st)
         static = {"value": args.steps / ds, "ms_per_step": ds / args.steps * 1e3,
                   "note": "frame A arrives every step (re-laid out every time): no tile goes stale, the dirty-tile history is a no-op"}
-    if nsc > 1 and repack:
+    if nsc > 1 and repack and not slabs_mode:
         # rounds 1 / 2 defined `value` without the per-frame re-layout: two already re-laid-out frames in the two frame slots alternate
+        # (a context of its own: explicit frame-slot calls switch a context's lane ahead off)
+        rh = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=VIEW, device=local, sparse_pool_tiles=args.sparse_pool)
+        rh.setUseBricks(cfg["use_bricks"]); rh.setSpaceSkip(cfg["skip_space"]); rh.setColorFilling(cfg["fill_holes"])
         for k, sc in enumerate(scenes):
-            hip.select_frame_slot(k); hip.upload_frame(sc)
+            rh.select_frame_slot(k); rh.upload_frame(sc)
 
         def rs(i):
-            hip.select_frame_slot(i % nsc)
-            drv.frame(mv, pr)
-        timed(20, rs)
-        dr = timed(args.steps, rs)
-        hip.select_frame_slot(0)
+            rh.select_frame_slot(i % nsc)
+            rh.clearOccupiedBricks(); rh.markBricks(); rh.updateOccupiedBricks(False); rh.integrate(); rh.drawF(mv, pr)
+        with torch.cuda.stream(stream):
+            for i in range(300):
+                rs(i)
+            rh.sync()
+            tr0 = time.perf_counter()
+            for i in range(args.steps):
+                rs(i)
+            rh.sync()
+            dr = time.perf_counter() - tr0
+        rh.close()
         resident = {"value": args.steps / dr, "ms_per_step": dr / args.steps * 1e3,
-                    "note": "two frames already in the kernels' layout alternate (tsdf_select_frame_slot): the definition of `value` in rounds 1 and 2"}
+                    "note": "two frames already in the kernels' layout alternate (tsdf_select_frame_slot; brick passes on the context's stream): the definition of `value` in rounds 1 and 2"}
     long_run = None
     if args.long_steps and args.frames_in_flight == 1:
         dl = timed(args.long_steps, lambda i: step(drv, i))
@@ -600,7 +618,8 @@ def main():
                 # share of the SIMDs' vector issue capacity: a SIMD-32 issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md,
                 # "Wave scheduling"), 1024 SIMDs at 2.4 GHz
                 "valu_issue_frac": (valu * 2.0 / (1024 * 2.4e9 * ms * 1e-3)) if valu else None,
-                "timing": "HIP events around this kernel alone, recorded on the launch stream, over --steps frames with stage overlap off", "note": note}
+                "timing": "HIP events around this kernel alone, recorded on the launch stream, over a pass of --steps frames with stage overlap off (the timed region "
+                          "itself records no event: a pair per frame costs it 4-8 us)", "note": note}
 
     db = dense_bytes(cfg["res"], n_streams)
     if dom_ms and world == 1 and not alone:
@@ -613,7 +632,7 @@ def main():
         else:
             alg, note = db["march"], "dense march: 4V + 24R (BASELINE.md section 3); with depth limits the rays sample only inside occupied bricks, so this is an upper figure"
         out["roofline"] = roofline(dom, alg, dom_ms, args.config, note)
-        out["roofline"]["avg_launch_ms_in_timed_region"] = dom_ms_insitu      # in situ: beside the previous frame's hole filling when stage overlap is on
+        out["roofline"]["avg_launch_ms_overlapped"] = dom_ms_insitu           # in situ: beside the other lanes' kernels (stage overlap on), a pass of its own after the timed region
         if dom == "k_integrate_tiles" and "k_pair_masks" in stages:
             # the launch reads its (tile, stream) pair classes from the pair-mask pass that runs right before it: kernel + helper together
             both = dom_ms + stages["k_pair_masks"]
@@ -660,7 +679,6 @@ def main():
         ext1 = sc1["bbox_max"] - sc1["bbox_min"]
         h1 = rr.ReconIntegrationHip(sc1, res=c1["res"], brick_size=[float(ext1[a]) / c1["res"][a] * 8 for a in range(3)], limit=LIMIT, view=VIEW, device=local)
         h1.setUseBricks(False); h1.setSpaceSkip(False); h1.setColorFilling(False)
-        h1.set_stream(stream.cuda_stream)
 
         def f1():
             h1.clearOccupiedBricks(); h1.markBricks(); h1.updateOccupiedBricks(False); h1.integrate(); h1.drawF(mv, pr)

@@ -285,7 +285,7 @@ hipError_t join_fill(tsdf_ctx* c) {
 bool pipelined(const tsdf_ctx* c) { return c->overlap_fill && !c->pipeline_blocked; }
 hipStream_t pre_enter(tsdf_ctx* c) {
   if (!pipelined(c)) return c->stream;
-  if (!c->pre_stream) {
+  if (!c->pre_stream) {                                                   // (a context created with RR_OVERLAP_FILL=0 and switched on later)
     if (hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess) { c->pipeline_blocked = true; return c->stream; }
   }
@@ -304,6 +304,7 @@ hipError_t pre_leave(tsdf_ctx* c, hipStream_t lane) {
 }
 hipError_t join_pre(tsdf_ctx* c) {
   c->main_since_gate = true;
+  c->slot_in_use = c->counters_in_use = c->occ_in_use = true;
   if (!c->pre_pending) return hipSuccess;
   c->pre_pending = false;
   return hipStreamWaitEvent(c->stream, c->pre_done, 0);
@@ -535,6 +536,14 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(TSDF_ERR_HIP); }
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   c->stream = c->own_stream;
+  // The three lanes of a context (stage overlap) are created together: the HIP runtime deals its hardware queues (4 by default,
+  // GPU_MAX_HW_QUEUES) to streams in creation order, and two lanes that share a queue do not overlap at all
+  if (getenv("RR_OVERLAP_FILL") == nullptr || atoi(getenv("RR_OVERLAP_FILL")) != 0) {
+    if (hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->march_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->fill_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fill_done[1], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
+  }
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
   if (const char* e = getenv("RR_OVERLAP_FILL")) c->overlap_fill = atoi(e) != 0;
   {
@@ -729,6 +738,9 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
 // the previous frame), once per frame of the lane; c->frame then points at it, so everything queued from now on reads the new frame.
 static int32_t begin_slot_write(tsdf_ctx* c, hipStream_t lane, bool keep_colour) {
   if (lane == c->stream || c->slot_flipped) return TSDF_OK;
+  c->slot_flipped = true;
+  if (!c->slot_in_use) return TSDF_OK;                                   // nothing queued reads the current slot (the first frame): in place
+  c->slot_in_use = false;
   const int old = c->cur_slot, t = old ^ 1;
   if (int32_t rc = alloc_frame_slot(c, t)) return rc;
   if (keep_colour) {                                                     // "colour may be NULL (keeps the previous one)": the previous one lives in the other slot
@@ -736,7 +748,6 @@ static int32_t begin_slot_write(tsdf_ctx* c, hipStream_t lane, bool keep_colour)
     HIP_TRY(c, hipMemcpyAsync(c->slots[t].color, c->slots[old].color, nc * sizeof(uchar4), hipMemcpyDeviceToDevice, lane));
   }
   use_frame_slot(c, t);
-  c->slot_flipped = true;
   return TSDF_OK;
 }
 int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour) {
@@ -1054,7 +1065,8 @@ int32_t tsdf_clear_bricks(tsdf_ctx* c) {
   const hipStream_t lane = pre_enter(c);
   timer_begin_on(c, "bricks", lane);
   if (lane != c->stream) {                                               // the lane ahead: the other counter buffer (the previous frame's draw may still read this one)
-    if (!c->counters_flipped) { c->counters_cur ^= 1; c->br.counters = c->d_counters[c->counters_cur]; c->counters_flipped = true; }
+    if (!c->counters_flipped && c->counters_in_use) { c->counters_cur ^= 1; c->br.counters = c->d_counters[c->counters_cur]; }
+    c->counters_flipped = true; c->counters_in_use = false;
     c->spare_clean = false;
     HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), lane));
   } else if (c->spare_clean) {                                           // the other buffer was zeroed by the last integrate(): swap
@@ -1083,7 +1095,8 @@ int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
   if (lane != c->stream) {
     // the lane ahead: the other occupancy set (flags, list, count) -- the previous frame's integrate / draw may still read this one --, its
     // count zeroed here instead of by the previous update (which would zero the word the context's stream is reading)
-    if (!c->occ_flipped) { c->occ_parity ^= 1; c->occ_flipped = true; }
+    if (!c->occ_flipped && c->occ_in_use) c->occ_parity ^= 1;
+    c->occ_flipped = true; c->occ_in_use = false;
     c->br.num_occupied = c->d_occ_counts + c->occ_parity; c->br.flags = c->d_flags[c->occ_parity]; c->br.occupied = c->d_occupied[c->occ_parity];
     HIP_TRY(c, hipMemsetAsync(c->br.num_occupied, 0, sizeof(uint32_t), lane));
     launch_update_occupied(lane, c->br, c->min_voxels, c->d_occ_counts + 2);          // (a third word takes the kernel's re-arming store)
@@ -1356,7 +1369,7 @@ int32_t tsdf_raymarch(tsdf_ctx* c, const float* mv, const float* pr) {
 static int32_t fill_colors_impl(tsdf_ctx* c, hipStream_t* used) {
   hipStream_t fs = c->stream;
   if (c->overlap_fill) {
-    if (!c->fill_stream) {
+    if (!c->fill_stream) {                                                // (a context created with RR_OVERLAP_FILL=0 and switched on later)
       HIP_TRY(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking));
       HIP_TRY(c, hipEventCreateWithFlags(&c->march_done, hipEventDisableTiming));
       for (hipEvent_t& e : c->fill_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));

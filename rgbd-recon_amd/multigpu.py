@@ -127,8 +127,10 @@ class SlabDriver:
         self.preprocess = preprocess          # frames start from the raw sensor images: processTextures() instead of markBricks()
         self.exchanging = world > 1 or exchange_when_alone
         self.stage_cpu = self.exchanging and not self.native and dist.get_backend(group) == "gloo" and self.dev.type == "cuda"
+        # the collectives are torch's, so the context's kernels go to a torch stream -- but only when there IS an exchange: a context that
+        # keeps its own stream has its three lanes (stage overlap) on consecutively created streams, i.e. on different hardware queues
         self.stream = None
-        if self.dev.type == "cuda":
+        if self.dev.type == "cuda" and self.exchanging and not self.native:
             self.stream = stream if stream is not None else torch.cuda.Stream(self.dev)
             assert self.stream.cuda_stream != 0, "the NULL stream cannot be handed to tsdf_set_stream"
             backend.set_stream(self.stream.cuda_stream)

@@ -19,7 +19,10 @@ def full():
     hip.upload_frame_dev(*ptr, complete=True); hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv, pr)
 def main_only():
     hip.integrate(); hip.drawF(mv, pr)
-for name, fn in (("full step", full), ("integrate + drawF only", main_only), ("full step", full)):
+def block():
+    hip.select_frame_slot(hip.current_frame_slot())          # an explicit frame-slot call: the lane ahead is switched off for good
+    full()
+for name, fn in (("full step", full), ("integrate + drawF only", main_only), ("full step", full), ("full step, lane ahead off", block), ("full step, lane ahead off", full)):
     for _ in range(300): fn()
     hip.sync(); t = time.perf_counter()
     for _ in range(1000): fn()
