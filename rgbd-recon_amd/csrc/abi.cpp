@@ -244,6 +244,9 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
     HIP_TRY(c, hipMemset(c->d_flags[k], 0, (size_t)B.n));
   }
   B.flags = c->d_flags[c->occ_parity]; B.occupied = c->d_occupied[c->occ_parity];
+  // the fills above run on the NULL stream, asynchronously with respect to the host, and the context's streams are non-blocking: finished
+  // before any of them touches the new tables
+  HIP_TRY(c, hipDeviceSynchronize());
   return TSDF_OK;
 }
 
@@ -387,7 +390,10 @@ int32_t alloc_frame_slot(tsdf_ctx* c, int k) {
   HIP_TRY(c, hipMalloc((void**)&S.depth, np * sizeof(float)));
   HIP_TRY(c, hipMalloc((void**)&S.color, nc * sizeof(uchar4)));
   HIP_TRY(c, hipMalloc((void**)&S.ranges, (size_t)c->cfg.num_streams * ((c->cfg.depth_w + 7) / 8) * ((c->cfg.depth_h + 7) / 8) * sizeof(float4)));
-  HIP_TRY(c, hipMemset(S.color, 0, nc * sizeof(uchar4)));                // (synchronous: the slot may be written on another lane right away)
+  // (finished before anything else touches the slot: it may be written on another lane right away, and hipMemset itself is asynchronous
+  // with respect to the host and not ordered against non-blocking streams)
+  HIP_TRY(c, hipMemsetAsync(S.color, 0, nc * sizeof(uchar4), c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&S.released, hipEventDisableTiming));
   return TSDF_OK;

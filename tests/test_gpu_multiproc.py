@@ -163,6 +163,7 @@ def _native_alone(q, halo, force_regather):
                           min_capacity=64 if force_regather else 4096, max_capacity=64 if force_regather else 0)
     whole = rr.ReconIntegrationHip(scene, **KW)
     ok = True
+    why = []
     for k, sc in enumerate((scene, moved, scene, moved, moved)):
         hip.broadcast_frame(0, sc)                          # the frame arrives on the root: RCCL broadcast (of one) + re-layout on every rank
         drv.frame(mv, pr)
@@ -171,12 +172,18 @@ def _native_alone(q, halo, force_regather):
         if k >= 3 or not force_regather:
             drv.finish()
             (wc, wdd), (sc_, sdd) = whole.framebuffer(), hip.framebuffer()
-            ok &= same(sdd, wdd) and same(sc_, wc) and int((wdd < 1).sum()) > 300
+            good = same(sdd, wdd) and same(sc_, wc) and int((wdd < 1).sum()) > 300
+            if not good:
+                why.append(f"frame {k}: depth differs at {int((sdd != wdd).sum())} pixels, colour at {int((sc_ != wc).sum())} values")
+            ok &= good
     st = hip.comm_stats()
-    ok &= (st["regathers"] >= 1) if force_regather else (st["regathers"] == 0 and st["overflowed_frames"] == 0)
+    good = (st["regathers"] >= 1) if force_regather else (st["regathers"] == 0 and st["overflowed_frames"] == 0)
+    if not good:
+        why.append(f"stats {st}")
+    ok &= good
     hip.comm_destroy()
     hip.close()
-    q.put(bool(ok))
+    q.put("ok" if ok else "; ".join(why))
 
 
 @pytest.mark.timeout(900)
@@ -195,4 +202,4 @@ def test_native_rccl_exchange_with_one_rank(halo, force_regather):
     p.start()
     p.join(600)
     assert p.exitcode == 0
-    assert q.get(timeout=5) is True
+    assert q.get(timeout=5) == "ok"
