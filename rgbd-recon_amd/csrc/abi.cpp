@@ -293,24 +293,26 @@ hipStream_t pre_enter(tsdf_ctx* c) {
         hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess) { c->pipeline_blocked = true; return c->stream; }
   }
   if (c->main_since_gate) {                                               // the lane's first call of a new frame
-    if (c->pre_gate_recorded) hipStreamWaitEvent(c->pre_stream, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
+    static const bool no_gate = getenv("RR_NO_GATE") != nullptr;         // (timing experiment only: unsafe)
+    if (c->pre_gate_recorded && !no_gate) hipStreamWaitEvent(c->pre_stream, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
     hipEventRecord(c->pre_gate, c->stream);
     c->pre_gate_recorded = true; c->main_since_gate = false;
     c->slot_flipped = c->counters_flipped = c->occ_flipped = false;
+    c->counters_zeroed = c->occ_count_zeroed = false;
   }
   return c->pre_stream;
 }
 hipError_t pre_leave(tsdf_ctx* c, hipStream_t lane) {
-  if (lane == c->stream) return hipSuccess;
-  c->pre_pending = true;
-  return hipEventRecord(c->pre_done, lane);
+  if (lane != c->stream) c->pre_pending = true;                          // (the event is recorded once, when a consumer asks: every record costs the lane ~4 us)
+  return hipSuccess;
 }
 hipError_t join_pre(tsdf_ctx* c) {
   c->main_since_gate = true;
   c->slot_in_use = c->counters_in_use = c->occ_in_use = true;
   if (!c->pre_pending) return hipSuccess;
   c->pre_pending = false;
-  return hipStreamWaitEvent(c->stream, c->pre_done, 0);
+  const hipError_t e = hipEventRecord(c->pre_done, c->pre_stream);
+  return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->pre_done, 0);
 }
 // leave the pipelined mode for good (explicit frame-slot calls, the pre-processing path): drain the lanes, everything on the context's stream from now on
 hipError_t block_pipeline(tsdf_ctx* c) {
@@ -545,7 +547,14 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   // The three lanes of a context (stage overlap) are created together: the HIP runtime deals its hardware queues (4 by default,
   // GPU_MAX_HW_QUEUES) to streams in creation order, and two lanes that share a queue do not overlap at all
   if (getenv("RR_OVERLAP_FILL") == nullptr || atoi(getenv("RR_OVERLAP_FILL")) != 0) {
-    if (hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking) != hipSuccess ||
+    // RR_LANE_PRIORITY (A/B hook): "pre,fill" stream priorities relative to the context's stream: -1 = higher, 0 = equal, 1 = lower
+    int lo = 0, hi = 0, ppre = 0, pfill = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);                           // (least, greatest): numerically greatest <= least
+    if (const char* e = getenv("RR_LANE_PRIORITY")) sscanf(e, "%d,%d", &ppre, &pfill);
+    auto prio = [&](int rel) { return rel < 0 ? hi : (rel > 0 ? lo : (lo + hi) / 2); };
+    const bool two_lanes = getenv("RR_LANES") && atoi(getenv("RR_LANES")) == 2;   // (A/B hook) the lane ahead and the fill lane share one stream
+    if (hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, prio(ppre)) != hipSuccess ||
+        (two_lanes ? (c->fill_stream = c->pre_stream, hipSuccess) : hipStreamCreateWithPriority(&c->fill_stream, hipStreamNonBlocking, prio(pfill))) != hipSuccess ||
         hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->march_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->fill_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->fill_done[1], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
@@ -619,7 +628,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   for (int k = 0; k < 2; ++k) { if (c->h_wire[k]) hipHostFree(c->h_wire[k]); if (c->wire_done[k]) hipEventDestroy(c->wire_done[k]); }
   hipFree(c->d_wire);
   for (auto& kv : c->timers) for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-  if (c->pre_stream) hipStreamDestroy(c->pre_stream);
+  if (c->pre_stream && c->pre_stream != c->fill_stream) hipStreamDestroy(c->pre_stream);
   if (c->pre_done) hipEventDestroy(c->pre_done);
   if (c->pre_gate) hipEventDestroy(c->pre_gate);
   if (c->src_ready) hipEventDestroy(c->src_ready);
@@ -740,6 +749,14 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
   return TSDF_OK;
 }
 
+// On the lane ahead the re-layout launch of a new frame also clears the brick counters the frame's clearOccupiedBricks() is going to use
+// (it flips to them here instead): one launch and one dependent step less on the lane.
+static uint32_t* counters_for_upload(tsdf_ctx* c, hipStream_t lane) {
+  if (lane == c->stream || c->counters_zeroed || !c->d_counters[0]) return nullptr;
+  if (!c->counters_flipped && c->counters_in_use) { c->counters_cur ^= 1; c->br.counters = c->d_counters[c->counters_cur]; }
+  c->counters_flipped = true; c->counters_in_use = false; c->counters_zeroed = true; c->spare_clean = false;
+  return c->br.counters;
+}
 // The frame slot a new frame is written to.  On the lane ahead: the OTHER slot (the context's stream may still read the current one for
 // the previous frame), once per frame of the lane; c->frame then points at it, so everything queued from now on reads the new frame.
 static int32_t begin_slot_write(tsdf_ctx* c, hipStream_t lane, bool keep_colour) {
@@ -769,7 +786,7 @@ int32_t tsdf_upload_frame(tsdf_ctx* c, const float* depth_rg, const float* quali
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_s, silhouette, np * 4, hipMemcpyHostToDevice, lane));
   if (colour) HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, lane));
   launch_pack_frame_fused(lane, c->d_stage_depth, c->d_stage_q, c->d_stage_s, (float4*)F.dqs, (float*)c->frame.depth, c->slots[c->cur_slot].ranges,
-                          (int)c->cfg.num_streams, F.w, F.h, colour ? c->d_stage_col : nullptr, (uchar4*)F.color, nc);
+                          (int)c->cfg.num_streams, F.w, F.h, colour ? c->d_stage_col : nullptr, (uchar4*)F.color, nc, counters_for_upload(c, lane), (uint32_t)c->counter_words);
   HIP_TRY(c, hipGetLastError());
   c->slots[c->cur_slot].have = true;
   HIP_TRY(c, pre_leave(c, lane));
@@ -798,7 +815,7 @@ int32_t tsdf_upload_frame_dev(tsdf_ctx* c, const float* depth_rg, const float* q
   const size_t nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
   timer_begin_on(c, "0repack", lane);
   launch_pack_frame_fused(lane, depth_rg, quality, silhouette, (float4*)F.dqs, (float*)c->frame.depth, c->slots[c->cur_slot].ranges,
-                          (int)c->cfg.num_streams, F.w, F.h, colour, (uchar4*)F.color, nc);
+                          (int)c->cfg.num_streams, F.w, F.h, colour, (uchar4*)F.color, nc, counters_for_upload(c, lane), (uint32_t)c->counter_words);
   timer_end_on(c, "0repack", lane);
   HIP_TRY(c, hipGetLastError());
   c->slots[c->cur_slot].have = true;
@@ -1074,7 +1091,8 @@ int32_t tsdf_clear_bricks(tsdf_ctx* c) {
     if (!c->counters_flipped && c->counters_in_use) { c->counters_cur ^= 1; c->br.counters = c->d_counters[c->counters_cur]; }
     c->counters_flipped = true; c->counters_in_use = false;
     c->spare_clean = false;
-    HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), lane));
+    if (c->counters_zeroed) c->counters_zeroed = false;                  // the frame's re-layout launch cleared them (a second clear of the frame fills again)
+    else HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), lane));
   } else if (c->spare_clean) {                                           // the other buffer was zeroed by the last integrate(): swap
     c->counters_cur ^= 1;
     c->br.counters = c->d_counters[c->counters_cur];
@@ -1089,7 +1107,12 @@ int32_t tsdf_mark_bricks(tsdf_ctx* c) {
   if (rc) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
   const hipStream_t lane = pre_enter(c);
-  launch_mark_bricks(lane, c->luts, c->frame, c->br);
+  uint32_t* zero_word = nullptr;
+  if (lane != c->stream) {                                               // the count of the occupancy set the coming update flips to (or stays on)
+    zero_word = c->d_occ_counts + ((!c->occ_flipped && c->occ_in_use) ? (c->occ_parity ^ 1) : c->occ_parity);
+    c->occ_count_zeroed = true;
+  }
+  launch_mark_bricks(lane, c->luts, c->frame, c->br, zero_word);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
@@ -1104,7 +1127,8 @@ int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
     if (!c->occ_flipped && c->occ_in_use) c->occ_parity ^= 1;
     c->occ_flipped = true; c->occ_in_use = false;
     c->br.num_occupied = c->d_occ_counts + c->occ_parity; c->br.flags = c->d_flags[c->occ_parity]; c->br.occupied = c->d_occupied[c->occ_parity];
-    HIP_TRY(c, hipMemsetAsync(c->br.num_occupied, 0, sizeof(uint32_t), lane));
+    if (c->occ_count_zeroed) c->occ_count_zeroed = false;                // the frame's marking launch cleared the count (a second update of the frame fills again)
+    else HIP_TRY(c, hipMemsetAsync(c->br.num_occupied, 0, sizeof(uint32_t), lane));
     launch_update_occupied(lane, c->br, c->min_voxels, c->d_occ_counts + 2);          // (a third word takes the kernel's re-arming store)
   } else {
     c->occ_parity ^= 1;

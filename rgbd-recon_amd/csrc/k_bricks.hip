@@ -43,9 +43,15 @@ __global__ __launch_bounds__(256) void k_pack_color(const uint8_t* __restrict__ 
 // 4 x 640 x 480) it cost an eighth of the frame.  Blocks [0, cell_blocks): one wave per 8x8-pixel cell reads its 64 pixels of the three
 // source arrays, writes the packed texel and the depth plane and reduces the cell's range (DPP); the remaining blocks turn RGB8 into RGBA8,
 // four pixels per thread (12 bytes in, 16 out).  HBM bound: 23.4 MB in, 29.8 MB out at c2.
+constexpr uint32_t kPackZeroBlocks = 64;
 __global__ __launch_bounds__(256) void k_pack_frame_fused(const float2* __restrict__ depth_rg, const float* __restrict__ quality, const float* __restrict__ silhouette,
                                                           float4* __restrict__ dqs, float* __restrict__ depth, float4* __restrict__ ranges, int n_streams, int w, int h,
-                                                          int rcw, int rch, int cell_blocks, const uint8_t* __restrict__ rgb, uchar4* __restrict__ rgba, uint32_t n_quads, uint32_t n_px) {
+                                                          int rcw, int rch, int cell_blocks, const uint8_t* __restrict__ rgb, uchar4* __restrict__ rgba, uint32_t n_quads, uint32_t n_px,
+                                                          int colour_blocks, uint4* __restrict__ zero, uint32_t zero_quads) {
+  if ((int)blockIdx.x >= cell_blocks + colour_blocks) {                  // ---- (optional) the brick counters of the frame this one starts: clearOccupiedBricks()'s fill rides along
+    for (uint32_t i = (blockIdx.x - (uint32_t)(cell_blocks + colour_blocks)) * blockDim.x + threadIdx.x; i < zero_quads; i += kPackZeroBlocks * blockDim.x) zero[i] = make_uint4(0, 0, 0, 0);
+    return;
+  }
   if ((int)blockIdx.x >= cell_blocks) {                                  // ---- colour (rgb == nullptr: the grid has no such blocks)
     const uint32_t q = (blockIdx.x - (uint32_t)cell_blocks) * blockDim.x + threadIdx.x;   // pixels 4q .. 4q + 3
     if (q >= n_quads) return;
@@ -83,11 +89,12 @@ __global__ __launch_bounds__(256) void k_pack_frame_fused(const float2* __restri
   if (ln == 0) ranges[cell] = make_float4(d0, d1, s0, s1);
 }
 void launch_pack_frame_fused(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, float4* ranges,
-                             int n_streams, int w, int h, const uint8_t* rgb, uchar4* rgba, size_t n_color_px) {
+                             int n_streams, int w, int h, const uint8_t* rgb, uchar4* rgba, size_t n_color_px, uint32_t* zero, uint32_t zero_words) {
   const int rcw = (w + 7) / 8, rch = (h + 7) / 8, cells = n_streams * rcw * rch, cell_blocks = (cells + 3) / 4;
   const uint32_t n_quads = rgb ? (uint32_t)((n_color_px + 3) / 4) : 0u;
-  hipLaunchKernelGGL(k_pack_frame_fused, dim3((unsigned)cell_blocks + (n_quads + 255) / 256), dim3(256), 0, st, (const float2*)depth_rg, quality, silhouette, dqs, depth, ranges,
-                     n_streams, w, h, rcw, rch, cell_blocks, rgb, rgba, n_quads, (uint32_t)n_color_px);
+  const int colour_blocks = (int)((n_quads + 255) / 256);
+  hipLaunchKernelGGL(k_pack_frame_fused, dim3((unsigned)(cell_blocks + colour_blocks) + (zero ? kPackZeroBlocks : 0u)), dim3(256), 0, st, (const float2*)depth_rg, quality, silhouette,
+                     dqs, depth, ranges, n_streams, w, h, rcw, rch, cell_blocks, rgb, rgba, n_quads, (uint32_t)n_color_px, colour_blocks, (uint4*)zero, zero_words >> 2);
 }
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* __restrict__ p, uint32_t v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
@@ -105,7 +112,8 @@ void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n) {
 }
 
 // One thread per depth pixel and stream (pre_normal.fs:22-33 runs per fragment of every layer).
-__global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages F, Bricks B) {
+__global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages F, Bricks B, uint32_t* __restrict__ zero_word) {
+  if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *zero_word = 0u;   // the count the coming updateOccupiedBricks() adds to
   const int px = blockIdx.x * 64 + (threadIdx.x & 63);
   const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int layer = blockIdx.z;
@@ -124,9 +132,9 @@ __global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages 
   wave_count(B.counters, id_nbr, nbr);
   wave_count(B.counters, id_own, own);
 }
-void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B) {
+void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B, uint32_t* zero_word) {
   dim3 grid((F.w + 63) / 64, (F.h + 3) / 4, T.n);
-  hipLaunchKernelGGL(k_mark_bricks, grid, dim3(256), 0, st, T, F, B);
+  hipLaunchKernelGGL(k_mark_bricks, grid, dim3(256), 0, st, T, F, B, zero_word);
 }
 
 // flags[b] = counter[b] >= min_voxels, the compacted occupied list and its length (one atomic per wave)

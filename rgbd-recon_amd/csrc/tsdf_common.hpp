@@ -211,9 +211,10 @@ void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t 
 void launch_frame_ranges(hipStream_t st, const float4* dqs, int n_streams, int w, int h, float4* ranges);
 // pack_frame + frame_ranges (+ pack_color when rgb != nullptr) as one launch; rgb / rgba must be readable / writable up to a multiple of 4 pixels
 void launch_pack_frame_fused(hipStream_t st, const float* depth_rg, const float* quality, const float* silhouette, float4* dqs, float* depth, float4* ranges,
-                             int n_streams, int w, int h, const uint8_t* rgb, uchar4* rgba, size_t n_color_px);
+                             int n_streams, int w, int h, const uint8_t* rgb, uchar4* rgba, size_t n_color_px,
+                             uint32_t* zero = nullptr, uint32_t zero_words = 0);   // zero: a word buffer (multiple of 4 words) the launch clears as well (the coming frame's brick counters)
 void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
-void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B);
+void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B, uint32_t* zero_word = nullptr);   // zero_word: a device word the launch clears as well
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, uint32_t* next_count);
 // full_classify: 1 = walk every tile (first frame, after anything that may have left non-clear data outside the previous active
 // list); 0 = scatter from the occupied bricks + check the previous list only (work follows the scene, not the volume)

@@ -22,7 +22,16 @@ ext = scene["bbox_max"] - scene["bbox_min"]
 hip = rr.ReconIntegrationHip(scene, res=(res,) * 3, brick_size=[float(ext[a]) / res * 8 for a in range(3)], limit=0.01, view=VIEW)
 dense = CFG != "c2"
 hip.setUseBricks(not dense); hip.setSpaceSkip(not dense); hip.setColorFilling(not dense)
-hip.select_frame_slot(1); hip.upload_frame(scene_b); hip.select_frame_slot(0)
+# round 3: every frame ARRIVES (device arrays -> tsdf_upload_frame_dev), so the three lanes of the context -- the lane ahead (re-layout +
+# brick passes of frame f + 1), the context's stream (integrate / march / shade of frame f) and the fill lane (hole filling of frame f - 1) --
+# run against each other for the whole soak; SOAK_SLOTS=1 selects round 2's flow (two resident frames, explicit frame slots: no lane ahead)
+SLOTS = os.environ.get("SOAK_SLOTS") == "1"
+if SLOTS:
+    hip.select_frame_slot(1); hip.upload_frame(scene_b); hip.select_frame_slot(0)
+else:
+    raw = [[torch.from_numpy(np.ascontiguousarray(sc[k])).cuda() for k in ("depth", "quality", "silhouette", "color")] for sc in (scene_b, scene)]
+    ptr = [[t.data_ptr() for t in r] for r in raw]
+    torch.cuda.synchronize()
 mv, pr = rr.scene.default_view(*VIEW)
 mv_b = rr.scene.gl_flat(rr.scene.look_at((1.6, 1.4, 2.4), (0.0, 1.1, 0.0)))
 
@@ -36,7 +45,10 @@ ref = {}
 t0 = time.perf_counter()
 for f in range(1, N + 1):
     which = f & 1
-    hip.select_frame_slot(0 if which else 1)
+    if SLOTS:
+        hip.select_frame_slot(0 if which else 1)
+    else:
+        hip.upload_frame_dev(*ptr[which], complete=True)
     hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv if which else mv_b, pr)
     if f <= 2 or f % CHECK in (0, 1):
         h = digest()
