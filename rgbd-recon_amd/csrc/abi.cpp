@@ -293,8 +293,7 @@ hipStream_t pre_enter(tsdf_ctx* c) {
         hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess) { c->pipeline_blocked = true; return c->stream; }
   }
   if (c->main_since_gate) {                                               // the lane's first call of a new frame
-    static const bool no_gate = getenv("RR_NO_GATE") != nullptr;         // (timing experiment only: unsafe)
-    if (c->pre_gate_recorded && !no_gate) hipStreamWaitEvent(c->pre_stream, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
+    if (c->pre_gate_recorded) hipStreamWaitEvent(c->pre_stream, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
     hipEventRecord(c->pre_gate, c->stream);
     c->pre_gate_recorded = true; c->main_since_gate = false;
     c->slot_flipped = c->counters_flipped = c->occ_flipped = false;
