@@ -4,10 +4,16 @@ set -e
 TAG=$1; NAME=$2
 R=$(cd "$(dirname "$0")/.." && pwd)
 G=$R/gpurun_out/$TAG
+find_stats() { find $G/$1 -name '*kernel_stats.csv' | head -n 1; }
+# the kernel stats the roofline figures agree with: one stream (RR_OVERLAP_FILL=0); the three-lane run's stats beside them
+cp $(find_stats c2_serial) $R/profiles/${NAME}_c2_kernel_stats.csv
+cp $(find_stats c2_lanes) $R/profiles/${NAME}_c2_three_lanes_kernel_stats.csv
+cp $(find_stats c1_serial) $R/profiles/${NAME}_c1_kernel_stats.csv
+cp $G/bench_stats_c2_serial.json $R/profiles/${NAME}_bench_c2_under_rocprof.json
+cp $G/bench_stats_c2_lanes.json $R/profiles/${NAME}_bench_c2_three_lanes_under_rocprof.json
+cp $G/bench_stats_c1_serial.json $R/profiles/${NAME}_bench_c1_under_rocprof.json
 for c in c2 c1; do
-  cp $G/$c/stats_kernel_stats.csv $R/profiles/${NAME}_${c}_kernel_stats.csv
-  cp $G/bench_stats_$c.json $R/profiles/${NAME}_bench_${c}_under_rocprof.json
   for p in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do cp $G/pmc_${p}_$c.csv $R/profiles/${NAME}_pmc_${p}_$c.csv; done
   python3 $R/profiles/summarize_pmc.py $c $R/profiles/${NAME}_pmc_FETCH_SIZE_$c.csv $R/profiles/${NAME}_pmc_WRITE_SIZE_$c.csv $R/profiles/${NAME}_pmc_SQ_INSTS_VALU_$c.csv
 done
-for c in c1 c2 c3 c4 c2_exchange_alone c2_3_frames_in_flight; do cp $G/bench_$c.json $R/profiles/${NAME}_bench_$c.json; done
+for c in c1 c2 c3 c4 c2_exchange_alone c2_exchange_alone_native c2_one_stream c2_3_frames_in_flight; do cp $G/bench_$c.json $R/profiles/${NAME}_bench_$c.json; done
