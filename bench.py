@@ -277,6 +277,8 @@ def main():
         h = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=VIEW, device=local, slab=slab,
                                    recompute_halo=recompute, sparse_pool_tiles=sparse)
         h.setUseBricks(cfg["use_bricks"]); h.setSpaceSkip(cfg["skip_space"]); h.setColorFilling(cfg["fill_holes"])
+        if args.frames_in_flight > 1:
+            h.set_stage_overlap(False)                    # several contexts already overlap whole frames: one stream each (three lanes each would fight over the hardware queues)
         if not repack:                                    # the second resident frame (modes without a per-frame re-layout alternate the two frame slots;
             for k, sc in enumerate(scenes[1:], 1):        #  an explicit frame-slot call switches the context's lane ahead off for good)
                 h.select_frame_slot(k); h.upload_frame(sc)
