@@ -444,7 +444,7 @@ def main():
                   "note": "stage overlap off (tsdf_set_stage_overlap(0)): every kernel of the frame on one stream, as in rounds 1 and 2; the roofline's kernel time comes from this pass"}
         for d in every:
             d.b.set_stage_overlap(overlap)
-        for i in range(20):                               # back into the overlapped steady state
+        for i in range(60):                               # back into the overlapped steady state (the switch drops the image-space tile history)
             step(drv, i)
     barrier()
     # ---- the timed region: exactly --steps frames as shipped (stage overlap on), no event recorded inside (an event pair per frame on the
