@@ -86,6 +86,10 @@ int32_t tsdf_sparse_pool_stats(tsdf_ctx* ctx, uint32_t* tiles_needed, uint32_t* 
  * coordinates read each), out[3] tiles taken by the LUT kernel, out[4] cache slots in use, out[5] cache capacity in slots.
  * All zero when the context does not use the cache. */
 int32_t tsdf_integrate_stats(tsdf_ctx* ctx, uint32_t out[6]);
+/* hole filling (fillColors): out[0] passes so far, out[1] of them restricted to the screen tiles the last three draws touched (the
+ * default whenever three culled draws in a row left nothing else in the pyramid and the framebuffer; RR_FILL_TILES=0 in the
+ * environment at tsdf_create switches it off).  Host counters, no synchronisation. */
+int32_t tsdf_fill_stats(tsdf_ctx* ctx, uint64_t out[2]);
 int32_t tsdf_set_stream(tsdf_ctx* ctx, void* hip_stream);   /* adopt a caller-owned hipStream_t (NULL: back to own) */
 /* adopt the process's NULL ("legacy default") stream, whose handle is 0 and therefore cannot be passed to tsdf_set_stream:
  * torch.cuda.default_stream().cuda_stream is 0, so this is how a context is ordered with work issued on torch's default

@@ -497,6 +497,12 @@ class ReconIntegrationHip:
         self._ck(self._L.tsdf_integrate_stats(self._c, out))
         return dict(zip(("items", "cached", "full_pairs", "lut_items", "slots_used", "slots"), [int(v) for v in out]))
 
+    def fill_stats(self):
+        """(hole-filling passes so far, of them restricted to the dirty screen tiles)"""
+        out = (C.c_uint64 * 2)()
+        self._ck(self._L.tsdf_fill_stats(self._c, out))
+        return int(out[0]), int(out[1])
+
     def timer_reserve(self, name, n): self._ck(self._L.tsdf_timer_reserve(self._c, name.encode(), int(n)))
 
     def timer_begin(self, name): self._ck(self._L.tsdf_timer_begin(self._c, name.encode()))

@@ -74,6 +74,8 @@ void release_view(tsdf_ctx* c) {
   hipFree(c->d_long); c->d_long = nullptr;
   hipFree(c->d_tri_z); hipFree(c->d_tri_acc); c->d_tri_z = nullptr; c->d_tri_acc = nullptr;
   for (int k = 0; k < 3; ++k) { hipFree(c->d_touched[k]); c->d_touched[k] = nullptr; }
+  for (int k = 0; k < 2; ++k) { hipFree(c->d_fill_mask[k]); hipFree(c->d_lvl_mask[k]); c->d_fill_mask[k] = nullptr; c->d_lvl_mask[k] = nullptr; }
+  c->draw_masks_valid = false; c->fb_consistent = false;
   c->tile_history = false; c->touched_idx = 0;
   hipFree(c->d_hits); hipFree(c->d_hit_counters); hipFree(c->d_comp_key); c->d_hits = nullptr; c->d_hit_counters = nullptr; c->d_comp_key = nullptr;
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
@@ -120,6 +122,9 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   HIP_TRY(c, hipMalloc(&c->d_long, nv * sizeof(LongRay)));
   const size_t n_img_tiles = (size_t)((c->vw + 7) / 8) * ((c->vh + 7) / 8);
   for (int k = 0; k < 3; ++k) { HIP_TRY(c, hipMalloc(&c->d_touched[k], n_img_tiles)); HIP_TRY(c, hipMemsetAsync(c->d_touched[k], 0, n_img_tiles, c->stream)); }
+  for (int k = 0; k < 2; ++k) { HIP_TRY(c, hipMalloc(&c->d_fill_mask[k], n_img_tiles)); HIP_TRY(c, hipMalloc(&c->d_lvl_mask[k], n_img_tiles)); }
+  c->draw_masks_valid = false; c->fb_consistent = false;
+  if (const char* e = getenv("RR_FILL_TILES")) c->fill_tiles = atoi(e) != 0;          // A/B and test hook
   c->tile_history = false; c->touched_idx = 0;
   HIP_TRY(c, hipMalloc(&c->d_hit_counters, 4 * sizeof(uint32_t)));
   HIP_TRY(c, hipMemsetAsync(c->d_hit_counters, 0, 4 * sizeof(uint32_t), c->stream));
@@ -648,6 +653,12 @@ int32_t tsdf_sparse_pool_stats(tsdf_ctx* c, uint32_t* need, uint32_t* cap) {
   HIP_TRY(c, sync_ctx(c));
   if (need) *need = n;
   if (cap) *cap = c->vol.pool_tiles;
+  return TSDF_OK;
+}
+int32_t tsdf_fill_stats(tsdf_ctx* c, uint64_t out[2]) {
+  CHECK_CTX(c);
+  if (!out) return TSDF_ERR_INVALID_ARGUMENT;
+  out[0] = c->n_fills; out[1] = c->n_fills_by_tiles;
   return TSDF_OK;
 }
 int32_t tsdf_integrate_stats(tsdf_ctx* c, uint32_t out[6]) {
@@ -1296,10 +1307,15 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
     RT.touched_recycle = c->d_touched[oldest];
     RT.rewrite_all = c->tiled_draws >= 1 ? 0 : 1;
     RT.rewrite_target = c->tiled_draws >= (two_pyramids ? 2 : 1) ? 0 : 1;
+    // the hole filling of this draw may keep to the tiles of this draw and the two before, once three tiled draws in a row have left
+    // nothing else in the pyramid it fills and in the framebuffer
+    RT.fill_mask = c->fill_holes ? c->d_fill_mask[c->atlas_parity] : nullptr;
+    c->draw_masks_valid = c->fill_holes && c->tiled_draws >= 2 && !partial;
     c->touched_idx = (cur + 1) % 3;
     c->tile_history = true;
     c->tiled_draws = std::min(2, c->tiled_draws + 1);
-  } else c->tile_history = false;
+  } else { c->tile_history = false; c->draw_masks_valid = false; }
+  if (!c->fill_holes) c->fb_consistent = false;                          // the march (or the masked merge below) writes the framebuffer itself
   timer_begin(c, "draw");
   timer_begin(c, "k_march");
   launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
@@ -1357,6 +1373,7 @@ int32_t tsdf_draw_points(tsdf_ctx* c, const float* mv, const float* pr) {
   HIP_TRY(c, join_pre(c));
   timer_begin(c, "points");
   HIP_TRY(c, join_fill(c));
+  c->fb_consistent = false;
   launch_draw_points(c->stream, P, Q, c->luts, F, c->d_comp_key, c->d_fb_c, c->d_fb_d);
   timer_end(c, "points");
   HIP_TRY(c, hipGetLastError());
@@ -1383,6 +1400,7 @@ int32_t tsdf_draw_trigrid(tsdf_ctx* c, const float* mv, const float* pr) {
   HIP_TRY(c, join_pre(c));
   timer_begin(c, "trigrid");
   HIP_TRY(c, join_fill(c));
+  c->fb_consistent = false;
   launch_draw_trigrid(c->stream, P, Q, c->luts, c->frame, c->min_length, c->d_tri_z, c->d_tri_acc, c->d_fb_c, c->d_fb_d);
   timer_end(c, "trigrid");
   HIP_TRY(c, hipGetLastError());
@@ -1408,8 +1426,13 @@ static int32_t fill_colors_impl(tsdf_ctx* c, hipStream_t* used) {
     fs = c->fill_stream;
   }
   timer_begin_on(c, "holefill", fs);
-  launch_inpaint_pyramid(fs, c->atlas);
-  launch_colorfill(fs, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
+  const bool by_tiles = c->fill_tiles && c->draw_masks_valid && c->fb_consistent && c->color_mask_mode == 0 && !c->keep_color;
+  const uint8_t* tile_mask = by_tiles ? c->d_fill_mask[c->atlas_parity] : nullptr;
+  ++c->n_fills; c->n_fills_by_tiles += by_tiles ? 1 : 0;
+  launch_inpaint_pyramid(fs, c->atlas, tile_mask, c->d_lvl_mask);
+  launch_colorfill(fs, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0, tile_mask);
+  c->fb_consistent = c->color_mask_mode == 0 && !c->keep_color;         // the framebuffer is this pass's now: background wherever no tile was dirty
+  c->draw_masks_valid = false;                                           // (consumed: a second fillColors() of the same draw, e.g. after a composite, goes through every tile)
   timer_end_on(c, "holefill", fs);
   if (c->overlap_fill) { HIP_TRY(c, hipEventRecord(c->fill_done[c->atlas_parity], fs)); c->fill_pending[c->atlas_parity] = true; }
   HIP_TRY(c, hipGetLastError());
@@ -1621,7 +1644,7 @@ int32_t tsdf_upload_image(tsdf_ctx* c, const float* rgba, const float* depth) {
   const size_t w = (size_t)c->vw, h = (size_t)c->vh;
   HIP_TRY(c, hipMemcpy2D(R.color, (size_t)R.stride * 16, rgba, w * 16, w * 16, h, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy2D(R.depth, (size_t)R.stride * 4, depth, w * 4, w * 4, h, hipMemcpyHostToDevice));
-  c->tile_history = false;                                               // the march target no longer holds what the last march left
+  c->tile_history = false; c->draw_masks_valid = false;                  // the march target no longer holds what the last march left
   return TSDF_OK;
 }
 int32_t tsdf_download_framebuffer(tsdf_ctx* c, float* rgba, float* depth) {
@@ -1690,6 +1713,7 @@ int32_t tsdf_composite_dev(tsdf_ctx* c, const void* gathered, uint32_t n) {
   if (!gathered || n < 1) return TSDF_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, join_fill(c));
+  c->draw_masks_valid = false;                                           // the composite writes every pixel of the march target
   launch_composite(c->stream, gathered, (int)n, ray_target(c), c->vw, c->vh);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
@@ -1713,6 +1737,7 @@ int32_t tsdf_composite_hits_dev(tsdf_ctx* c, const void* gathered, uint32_t n, u
   if (!c->d_comp_key) HIP_TRY(c, hipMalloc(&c->d_comp_key, (size_t)c->vw * c->vh * sizeof(unsigned long long)));
   // a compositing context that did not march this frame (dedicated compositor, multigpu.py) has no miss counts of its own: 0 then
   HIP_TRY(c, join_fill(c));
+  c->draw_masks_valid = false;                                           // the composite writes every pixel of the march target
   launch_composite_hits(c->stream, gathered, (size_t)stride_bytes, (int)n, ray_target(c), c->vw, c->vh, c->d_comp_key, c->own_miss_counts ? 1 : 0);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;

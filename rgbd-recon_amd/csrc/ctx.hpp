@@ -97,6 +97,9 @@ struct tsdf_ctx {
   // the hole filling of frame f still reads this one (the reference's m_view_inpaint / m_view_inpaint2, for another reason: it swaps them
   // between its transfer passes, recon_integration.cpp:279-338).  c->atlas points at the one the latest draw used.
   float4* atlas_color[2]{}; float* atlas_depth[2]{}; int atlas_parity = 0;
+  // hole filling by dirty tiles (k_inpaint.hip): per pyramid the tile byte mask the march leaves, scratch masks of levels 1 / 2, and
+  // whether the masks of the latest draw may be trusted / the framebuffer holds the background outside them
+  uint8_t* d_fill_mask[2]{}; uint8_t* d_lvl_mask[2]{}; bool draw_masks_valid = false, fb_consistent = false, fill_tiles = true; uint64_t n_fills = 0, n_fills_by_tiles = 0;
   uint32_t* d_tri_z = nullptr; float4* d_tri_acc = nullptr; float min_length = 0.0125f;   // triangle-grid back-end; KinectCalibrationFile.cpp:96 default
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
   bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)

@@ -106,8 +106,37 @@ __device__ __forceinline__ void inpaint_pixel(const Atlas& A, int w, int lod, in
   A.depth[o] = td / tw;
 }
 
-// one thread per pixel of level lod + 1 (the large levels)
-__global__ __launch_bounds__(256) void k_inpaint_level(Atlas A, int w, int lod) {
+// Dirty tiles (round 3).  92 % of the c2 picture is background: a level-0 tile (8x8 pixels) without a brick under it holds the clear value,
+// and a pixel of level l + 1 whose whole window lies in clear tiles of level l comes out as the clear value again (no valid tap: depth of
+// the centre tap = 1 -> colour (0,1,0,0), tsdf_inpaint.fs:59-68).  The march leaves one byte per level-0 tile -- the union of the tiles
+// the last three draws touched (k_march: whatever THIS pyramid and the framebuffer may still hold from their previous use lies inside it) --
+// and every level derives its own tile mask from its parent's: the window of level-(l + 1) pixel (x, y) is level-l columns 2x-3 .. 2x+6
+// (through the 2/3 squeeze, res[l] = 2 res[l+1] or 2 res[l+1] + 1) and rows 2y-1 .. 2y+3, i.e. tile T reads parent tiles 2T-1 .. 2T+2 on both
+// axes.  One exception: past its last row a level's window runs into the rows of level l - 1 (off[l].y + res[l].y = off[l-1].y), so
+// from level 3 on the last tile row is always computed.  Clean tiles are not touched: they hold the clear value since the last full pass.
+struct LevelMask { const uint8_t* parent; uint8_t* child; int pnx, pny, cnx, cny; int force_last_row; };   // parent == nullptr: every tile
+__global__ __launch_bounds__(256) void k_inpaint_level(Atlas A, int w, int lod, LevelMask M) {
+  if (M.parent) {
+    __shared__ int s_dirty[4];
+    if (threadIdx.x < 4) s_dirty[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {                                              // tile q of the block's 2 x 2, parent k of its 4 x 4
+      const int q = threadIdx.x >> 4, k = threadIdx.x & 15;
+      const int tx = blockIdx.x * 2 + (q & 1), ty = blockIdx.y * 2 + (q >> 1);
+      const int px = 2 * tx - 1 + (k & 3), py = 2 * ty - 1 + (k >> 2);
+      if (tx < M.cnx && ty < M.cny) {
+        if (px >= 0 && py >= 0 && px < M.pnx && py < M.pny && M.parent[py * M.pnx + px]) atomicOr(&s_dirty[q], 1);
+        if (M.force_last_row && ty == M.cny - 1) atomicOr(&s_dirty[q], 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && M.child) {
+      const int tx = blockIdx.x * 2 + (threadIdx.x & 1), ty = blockIdx.y * 2 + (threadIdx.x >> 1);
+      if (tx < M.cnx && ty < M.cny) M.child[ty * M.cnx + tx] = (uint8_t)s_dirty[threadIdx.x];
+    }
+    const int q = ((threadIdx.x >> 4) >> 3) * 2 + ((threadIdx.x & 15) >> 3);
+    if (!s_dirty[q]) return;
+  }
   const int lx0 = blockIdx.x * 16 + (threadIdx.x & 15), ly0 = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (lx0 >= A.res[lod + 1][0] || ly0 >= A.res[lod + 1][1]) return;
   inpaint_pixel(A, w, lod, lx0, ly0);
@@ -124,15 +153,29 @@ __global__ __launch_bounds__(1024) void k_inpaint_tail(Atlas A, int w, int first
   }
 }
 constexpr int kTailPixels = 1024;   // levels with at most this many pixels go to the fused tail (one pass of 1024 threads each)
-void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod) {
+static void launch_inpaint_level_masked(hipStream_t st, const Atlas& A, int lod, const LevelMask& M) {
   const int w = A.res[0][0];
   dim3 grid((A.res[lod + 1][0] + 15) / 16, (A.res[lod + 1][1] + 15) / 16);
-  hipLaunchKernelGGL(k_inpaint_level, grid, dim3(256), 0, st, A, w, lod);
+  hipLaunchKernelGGL(k_inpaint_level, grid, dim3(256), 0, st, A, w, lod, M);
 }
-void launch_inpaint_pyramid(hipStream_t st, const Atlas& A) {
+void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod) { launch_inpaint_level_masked(st, A, lod, LevelMask{}); }
+// tile_mask: one byte per level-0 tile ((w + 7) / 8 per row), or nullptr = every tile; lvl_mask[0 / 1]: scratch for the masks of levels 1 / 2
+// (each at least ((w / 2 + 7) / 8) * ((h / 2 + 7) / 8) bytes)
+void launch_inpaint_pyramid(hipStream_t st, const Atlas& A, const uint8_t* tile_mask, uint8_t* const lvl_mask[2]) {
   const int w = A.res[0][0];
   int lod = 0;
-  for (; lod + 1 < A.num_lods && A.res[lod + 1][0] * A.res[lod + 1][1] > kTailPixels; ++lod) launch_inpaint_level(st, A, lod);
+  const uint8_t* parent = tile_mask;
+  for (; lod + 1 < A.num_lods && A.res[lod + 1][0] * A.res[lod + 1][1] > kTailPixels; ++lod) {
+    LevelMask M{};
+    if (parent && lod < 3) {                                             // levels 1 .. 3 by their tiles; the (small) rest in full
+      M.parent = parent;
+      M.pnx = (A.res[lod][0] + 7) / 8; M.pny = (A.res[lod][1] + 7) / 8; M.cnx = (A.res[lod + 1][0] + 7) / 8; M.cny = (A.res[lod + 1][1] + 7) / 8;
+      M.child = lod < 2 ? lvl_mask[lod] : nullptr;
+      M.force_last_row = lod + 1 >= 3 ? 1 : 0;
+    }
+    launch_inpaint_level_masked(st, A, lod, M);
+    parent = M.child;
+  }
   if (lod + 1 < A.num_lods) hipLaunchKernelGGL(k_inpaint_tail, dim3(1), dim3(1024), 0, st, A, w, lod);
 }
 
@@ -168,9 +211,12 @@ __device__ __forceinline__ float4 masked_write(float4 out, float4 base, int mask
   if (mask == 2) return make_float4(base.x, out.y, out.z, base.w);           // GL_FALSE, GL_TRUE, GL_TRUE, GL_FALSE
   return out;
 }
-__global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4* __restrict__ fb_c, float* __restrict__ fb_d, int mask, int keep) {
+__global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4* __restrict__ fb_c, float* __restrict__ fb_d, int mask, int keep,
+                                                   const uint8_t* __restrict__ tile_mask) {
   const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (px >= w || py >= h) return;
+  // a tile no brick has been under for three draws: the framebuffer holds the background there since the last full pass (dirty tiles, above)
+  if (tile_mask && !tile_mask[(py >> 3) * ((w + 7) >> 3) + (px >> 3)]) return;
   const float tcx = (float)px / (float)A.res[0][0], tcy = (float)py / (float)A.res[0][1];             // :32
   const size_t o = (size_t)py * w + px;
   // depth comes from level 0 alone (:54) and the fragment only lands if it beats the cleared depth (GL_LESS, :313):
@@ -212,9 +258,9 @@ __global__ __launch_bounds__(256) void k_colorfill(Atlas A, int w, int h, float4
   fb_c[o] = masked_write(out, base, mask);
   fb_d[o] = d0;
 }
-void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask, int keep_color) {
+void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask, int keep_color, const uint8_t* tile_mask) {
   dim3 grid((w + 15) / 16, (h + 15) / 16);
-  hipLaunchKernelGGL(k_colorfill, grid, dim3(256), 0, st, A, w, h, fb_color, fb_depth, mask, keep_color);
+  hipLaunchKernelGGL(k_colorfill, grid, dim3(256), 0, st, A, w, h, fb_color, fb_depth, mask, keep_color, tile_mask);
 }
 // draw() without hole filling but with a colour mask / an uncleared colour buffer: fragments (depth < 1 in the march target) write
 // their unmasked channels, everything else keeps the colour buffer; the depth buffer was cleared before the draw

@@ -264,7 +264,12 @@ __global__ __launch_bounds__(256, RR_MARCH_BOUNDS) void k_march(ViewParams P, Vo
     if (tx >= ntx || ty * 8 >= P.h) return;
     const int t = ty * ntx + tx;
     const uint8_t cur = R.touched_cur[t], before = R.touched_prev[t], before_target = R.touched_prev_target[t];
-    if (ln == 0) R.touched_recycle[t] = 0;                               // the oldest mask becomes the next draw's (empty) current one
+    if (ln == 0) {
+      // what the hole filling has to look at: the tiles of this draw and of the two before (the oldest mask is read as touched_prev_target
+      // when two pyramids alternate, else through touched_recycle before it is zeroed)
+      if (R.fill_mask) R.fill_mask[t] = cur | before | before_target | R.touched_recycle[t];
+      R.touched_recycle[t] = 0;                                          // the oldest mask becomes the next draw's (empty) current one
+    }
     if (!cur) {
       if (inside) {
         if (before_target || R.rewrite_target) {                         // what the draw that last wrote THIS target left here

@@ -243,6 +243,7 @@ struct RayTarget {
   // the tiles of the draw that last wrote THIS target (the previous one, or the one before when two pyramids alternate), touched_recycle:
   // the oldest mask, zeroed for the next draw; rewrite_target / rewrite_all: no valid history for the target / for the sample counts
   const uint8_t* touched_cur; const uint8_t* touched_prev; const uint8_t* touched_prev_target; uint8_t* touched_recycle; int rewrite_all, rewrite_target;
+  uint8_t* fill_mask;   // (nullable) per tile: touched by this draw or one of the two before -- what the hole filling of this draw has to look at
 };
 void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, const FrameImages& F, const Volume& V, const RayTarget& R, int partial,
                      void* hit_list, uint32_t* hit_counters, int parity, int phase = 0, void* long_list = nullptr, uint32_t cap = 0xffffffffu,
@@ -250,10 +251,11 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
 // hit_list: 16 B per view pixel; long_list: 32 B per view pixel (rays handed to the wave-per-ray pass after `cap` samples);
 // hit_counters: 4 words [hit, hit', long, long'], the primed ones re-armed for the next frame by k_shade
 void launch_inpaint_level(hipStream_t st, const Atlas& A, int lod);
-void launch_inpaint_pyramid(hipStream_t st, const Atlas& A);
+// tile_mask (nullable): one byte per 8x8-pixel level-0 tile -- only tiles it flags (and what depends on them) are computed; lvl_mask: scratch
+void launch_inpaint_pyramid(hipStream_t st, const Atlas& A, const uint8_t* tile_mask = nullptr, uint8_t* const lvl_mask[2] = nullptr);
 // mask: Reconstruction::m_color_mask_mode (0 all channels, 1 red only, 2 green + blue only: glColorMask, recon_integration.cpp:321-333);
 // keep_color: the colour buffer was NOT cleared before this draw (the anaglyph's second eye, kinect_client.cpp:627)
-void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask = 0, int keep_color = 0);
+void launch_colorfill(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask = 0, int keep_color = 0, const uint8_t* tile_mask = nullptr);
 // fill_holes off with a colour mask / an uncleared colour buffer: the march renders into the atlas' level-0 region and this merges it
 void launch_resolve_masked(hipStream_t st, const Atlas& A, int w, int h, float4* fb_color, float* fb_depth, int mask, int keep_color);
 void launch_clear_image(hipStream_t st, float4* color, float* depth, size_t n, float4 c, float d);

@@ -89,3 +89,133 @@ def test_stage_overlap_of_hole_filling_changes_nothing(rr):
 
 def frame_nosync(o, mv, pr):
     o.clearOccupiedBricks(); o.markBricks(); o.updateOccupiedBricks(False); o.integrate(); o.drawF(mv, pr)
+
+
+def compare_images(hip, orc, what):
+    (hc, hd), (oc, od) = hip.framebuffer(), orc.framebuffer()
+    assert_same(hd, od, f"framebuffer depth, {what}"); assert_same(hc, oc, f"framebuffer colour, {what}")
+    (ha, hdd), (oa, odd) = hip.atlas(), orc.atlas()
+    assert_same(hdd, odd, f"pyramid depth, {what}"); assert_same(ha, oa, f"pyramid colour, {what}")
+    return int((od < 1).sum())
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("view", [(320, 180), (203, 117), (1280, 720)])
+def test_hole_filling_by_dirty_tiles_equals_the_full_pass(rr, overlap, view):
+    """fillColors() keeps to the screen tiles the last three draws touched once three culled draws in a row have left nothing else in
+    the pyramid and the framebuffer (k_inpaint.hip, "dirty tiles").  Every level of the pyramid and the framebuffer must stay the
+    oracle's -- which fills every pixel of every level, every frame -- while the content moves under a moving camera, and through
+    everything that breaks the three-draw history: a draw without hole filling, a point draw, a colour mask, an uncleared colour buffer,
+    a shifted viewport, an uploaded image, dense draws, a resize."""
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    scs = [rr.scene.make_scene(**mk), rr.scene.make_scene(**mk, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2)), rr.scene.make_scene(**mk, sphere_c=(-0.3, 1.3, 0.2))]
+    kw = dict(res=(96, 96, 96), brick_size=[2.0 / 12, 2.2 / 12, 2.0 / 12], limit=0.03, view=view)
+    pr = rr.scene.gl_flat(rr.scene.perspective(50.0, view[0] / view[1], 0.1, 200.0))
+    eyes = [(0.0, 1.1, 3.0), (1.6, 1.4, 2.4), (-2.2, 0.6, 1.2), (0.2, 3.4, 0.4), (0.0, 1.1, 6.5)]
+    mvs = [rr.scene.gl_flat(rr.scene.look_at(e, (0.0, 1.1, 0.0))) for e in eyes]
+    hip, orc = rr.ReconIntegrationHip(scs[0], **kw), OracleRecon(scs[0], **kw)
+    hip.set_stage_overlap(overlap)
+    n = [0]
+
+    def both(fn):
+        for o in (hip, orc):
+            fn(o)
+
+    def run(frames, what, check_every=True):
+        seen = 0
+        for _ in range(frames):
+            k = n[0]; n[0] += 1
+            both(lambda o: (o.upload_frame(scs[k % 3]), frame(o, mvs[(k * 2) % 5], pr)))
+            if check_every or _ == frames - 1:
+                seen = compare_images(hip, orc, f"{what}, frame {k}")
+        return seen
+
+    assert run(6, "steady state") > 50
+    fills, by_tiles = hip.fill_stats()
+    assert fills == 6 and by_tiles == 4, (fills, by_tiles)               # the first two draws of a history fill every tile
+    run(5, "no read between the frames", check_every=False)
+    assert hip.fill_stats() == (11, 9)
+    # a draw without hole filling writes the framebuffer itself
+    both(lambda o: o.setColorFilling(False)); run(2, "filling off"); both(lambda o: o.setColorFilling(True))
+    run(4, "filling on again")
+    # colour masks / an uncleared colour buffer (the anaglyph pair): full passes, and a full pass after them
+    both(lambda o: (o.setColorMaskMode(1), o.setFramebufferClear(False))); run(2, "red mask, colour kept")
+    both(lambda o: o.setColorMaskMode(2)); run(2, "cyan mask")
+    both(lambda o: (o.setColorMaskMode(0), o.setFramebufferClear(True))); run(4, "mask off")
+    # a shifted viewport marches every pixel
+    both(lambda o: o.setViewportOffset(0.37, -0.21)); run(2, "shifted")
+    both(lambda o: o.setViewportOffset(0.0, 0.0)); run(4, "shift off")
+    # an image uploaded over the march target, then filled
+    rgba, depth = orc.view_images()[:2]
+    rng = np.random.default_rng(5)
+    depth = np.where(rng.random(depth.shape) < 0.02, np.float32(0.5), np.float32(1.0)).astype(np.float32)
+    rgba = np.where(depth[..., None] < 1, rng.random(rgba.shape, dtype=np.float32), np.float32([0, 1, 0, 0])).astype(np.float32)
+    both(lambda o: (o.set_view_images(rgba, depth), o.fillColors()))
+    compare_images(hip, orc, "uploaded image")
+    run(4, "after the uploaded image")
+    # dense draws (no brick culling, no tiles), back to culled
+    both(lambda o: o.setUseBricks(False)); run(2, "dense")
+    both(lambda o: o.setUseBricks(True)); run(4, "culled again")
+    both(lambda o: o.setSpaceSkip(False)); run(2, "no space skipping")
+    both(lambda o: o.setSpaceSkip(True)); run(3, "space skipping again")
+    # another picture size
+    small = (view[0] // 2 + 3, view[1] // 2 + 5)
+    hip.resize(*small)
+    orc2 = OracleRecon(scs[0], **dict(kw, view=small))
+    pr2 = rr.scene.gl_flat(rr.scene.perspective(50.0, small[0] / small[1], 0.1, 200.0))
+    for k in range(5):
+        for o in (hip, orc2):
+            o.upload_frame(scs[k % 3]); frame(o, mvs[(k * 2) % 5], pr2)
+        compare_images(hip, orc2, f"resized, frame {k}")
+    fills, by_tiles = hip.fill_stats()
+    assert by_tiles >= 20 and fills - by_tiles >= 20, (fills, by_tiles)
+
+
+def test_hole_filling_by_dirty_tiles_under_a_point_draw(rr, small_scene):
+    kw = dict(res=(64, 64, 64), brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(160, 90))
+    mv, pr = rr.scene.default_view(*kw["view"])
+    hip, orc = rr.ReconIntegrationHip(small_scene, **kw), OracleRecon(small_scene, **kw)
+    for k in range(4):
+        for o in (hip, orc):
+            frame(o, mv, pr)
+    compare_images(hip, orc, "before")
+    assert hip.fill_stats() == (4, 2)
+    for o in (hip, orc):
+        o.upload_normals(small_scene["normals"])
+        o.drawPoints(mv, pr)                                              # writes the framebuffer outside any tile mask
+    (hc, hd), (oc, od) = hip.framebuffer(), orc.framebuffer()
+    assert_same(hd, od, "points depth"); assert_same(hc, oc, "points colour")
+    for k in range(3):
+        for o in (hip, orc):
+            frame(o, mv, pr)
+        compare_images(hip, orc, f"after the point draw, frame {k}")
+    assert hip.fill_stats() == (7, 4)                                     # the first fill after it went through every tile
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_dirty_tile_masks_reach_as_far_as_the_hole_filling_spreads(rr, overlap):
+    """Small objects that move in a large, still picture: the tile masks hug the bricks, while every level of the hole filling spreads
+    the content three more pixels of its parent level (10 x 5 window, tsdf_inpaint.fs) -- into tiles whose own parents are clean --
+    and levels from the third on read past their last row.  A pass that forgot either (checked with such builds: they fail here)
+    keeps what an earlier frame spread there."""
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    scs = [rr.scene.make_scene(**mk), rr.scene.make_scene(**mk, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2)), rr.scene.make_scene(**mk, sphere_c=(-0.3, 1.3, 0.2))]
+    seen = 0
+    for view, eye, target in [((640, 360), (0.0, 1.1, 9.0), (0.0, 1.1, 0.0)), ((640, 360), (2.0, 5.0, 7.0), (1.5, -1.0, 0.0)),
+                              ((491, 277), (-6.0, 1.5, 5.0), (0.4, 2.4, 0.0)), ((640, 360), (0.0, 0.9, 8.0), (0.0, 3.2, 0.0)),
+                              ((333, 555), (5.0, 2.0, 5.0), (0.0, -0.6, 0.0)),
+                              # the objects cut by the first / the last row of the picture, in its left half: what levels >= 3 pick up past their last row
+                              ((640, 360), (3.0, 4.3, 8.0), (3.0, 4.3, 0.0)), ((640, 360), (3.0, -2.1, 8.0), (3.0, -2.1, 0.0)),
+                              ((512, 512), (1.5, 3.2, 5.0), (1.5, 3.2, 0.0)), ((512, 512), (1.5, -1.0, 5.0), (1.5, -1.0, 0.0))]:
+        kw = dict(res=(96, 96, 96), brick_size=[2.0 / 24, 2.2 / 24, 2.0 / 24], limit=0.012, view=view)
+        pr = rr.scene.gl_flat(rr.scene.perspective(50.0, view[0] / view[1], 0.1, 200.0))
+        mv = rr.scene.gl_flat(rr.scene.look_at(eye, target))
+        hip, orc = rr.ReconIntegrationHip(scs[0], **kw), OracleRecon(scs[0], **kw)
+        hip.set_stage_overlap(overlap)
+        order = [0, 1, 1, 0, 0, 2, 1, 1, 2, 0]
+        for k, i in enumerate(order):
+            for o in (hip, orc):
+                o.upload_frame(scs[i]); frame(o, mv, pr)
+            seen += compare_images(hip, orc, f"view {view} from {eye}, frame {k}")
+        assert hip.fill_stats() == (len(order), len(order) - 2)
+    assert seen > 9000
