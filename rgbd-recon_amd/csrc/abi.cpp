@@ -226,7 +226,7 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
     B.brick_t0[a] = c->d_brick_t0[a];
     B.brick_t1[a] = c->d_brick_t1[a];
   }
-  c->full_classify = true;                                               // a new brick grid: walk every tile once
+  c->full_classify = true; c->alt.full = true;                           // a new brick grid: walk every tile once
   // tiles == bricks structurally?  (every voxel in exactly one brick per axis, and a tile never straddles two)
   bool uniform = true;
   for (int a = 0; a < 3 && uniform; ++a)
@@ -324,11 +324,57 @@ hipError_t block_pipeline(tsdf_ctx* c) {
   c->pipeline_blocked = true;
   hipError_t e = hipStreamSynchronize(c->stream);
   if (c->pre_stream) { const hipError_t f = hipStreamSynchronize(c->pre_stream); if (e == hipSuccess) e = f; }
+  if (c->integ_stream) { const hipError_t f = hipStreamSynchronize(c->integ_stream); if (e == hipSuccess) e = f; c->integ_pending = false; }
   c->pre_pending = false;
   return e;
 }
+// ---- the fourth lane (see tsdf_ctx::integ_stream)
+hipError_t join_integ(tsdf_ctx* c) {
+  if (!c->integ_pending) return hipSuccess;
+  c->integ_pending = false;
+  const hipError_t e = hipEventRecord(c->integ_done, c->integ_stream);
+  return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->integ_done, 0);
+}
+bool deep_ok(const tsdf_ctx* c) {
+  const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
+  return c->deep && !c->deep_failed && pipelined(c) && c->integ_stream && whole && !c->vol.slot && c->proj_budget == 0;
+}
+// exchange the set in use with the other one (host pointers only: kernels already queued keep the pointers they were launched with)
+void swap_volume_set(tsdf_ctx* c) {
+  tsdf_ctx::VolSet& a = c->alt;
+  std::swap(c->vol.data, a.data); std::swap(c->d_cls_all, a.cls_all); std::swap(c->tiles.stamp, a.stamp);
+  std::swap(c->d_tile_list[0], a.list[0]); std::swap(c->d_tile_list[1], a.list[1]); std::swap(c->d_tile_counts, a.counts);
+  std::swap(c->tile_parity, a.parity); std::swap(c->full_classify, a.full); std::swap(c->frame_stamp, a.stampno);
+  c->vol.cls = c->d_cls_all;
+  c->tiles.cls = c->d_cls_all + (size_t)(c->vol.int_tz0 - c->vol.tz0) * c->vol.nty * c->vol.ntx;
+  c->tiles.list = c->d_tile_list[0]; c->tiles.count = c->d_tile_counts;
+  c->vol_set ^= 1;
+}
+// the second set, initialised on `lane` like setup_volume initialises the first; false = no memory for it (the context stays on one volume)
+bool ensure_alt_set(tsdf_ctx* c, hipStream_t lane) {
+  tsdf_ctx::VolSet& a = c->alt;
+  if (a.data) return true;
+  const Volume& V = c->vol;
+  const size_t nvox = (size_t)V.n_stored_tiles * TILE_VOX, n = (size_t)c->tiles.n;
+  bool ok = hipMalloc(&a.data, nvox * sizeof(float)) == hipSuccess && hipMalloc(&a.stamp, n * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(&a.cls_all, (size_t)V.n_stored_tiles) == hipSuccess && hipMalloc(&a.list[0], n * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(&a.list[1], n * sizeof(uint32_t)) == hipSuccess && hipMalloc(&a.counts, 2 * sizeof(uint32_t)) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    hipFree(a.data); hipFree(a.stamp); hipFree(a.cls_all); hipFree(a.list[0]); hipFree(a.list[1]); hipFree(a.counts);
+    a = tsdf_ctx::VolSet{}; c->deep_failed = true;
+    return false;
+  }
+  launch_fill_u32(lane, (uint32_t*)a.data, 0u, nvox);
+  hipMemsetAsync(a.cls_all, kTileMixed, (size_t)V.n_stored_tiles, lane);
+  hipMemsetAsync(a.counts, 0, 2 * sizeof(uint32_t), lane);
+  hipMemsetAsync(a.stamp, 0, n * sizeof(uint32_t), lane);
+  a.parity = 0; a.full = true; a.stampno = 0;
+  return true;
+}
 hipError_t sync_ctx(tsdf_ctx* c) {
   hipError_t e = hipStreamSynchronize(c->stream);
+  if (c->integ_stream) { const hipError_t f = hipStreamSynchronize(c->integ_stream); if (e == hipSuccess) e = f; c->integ_pending = false; c->draw_pending[0] = c->draw_pending[1] = false; }
   if (c->pre_stream) { const hipError_t f = hipStreamSynchronize(c->pre_stream); if (e == hipSuccess) e = f; c->pre_pending = false; }
   if (c->fill_stream) { const hipError_t f = hipStreamSynchronize(c->fill_stream); if (e == hipSuccess) e = f; }
   c->fill_pending[0] = c->fill_pending[1] = false;
@@ -434,6 +480,8 @@ void release_volume(tsdf_ctx* c) {
   hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts); hipFree(c->d_linear); hipFree(c->d_tile_bounds); hipFree(c->d_pair_masks); c->d_pair_masks = nullptr;
   hipFree(c->proj.data); hipFree(c->proj.slot); hipFree(c->proj.items); hipFree(c->d_proj_words); hipFree(c->d_item_stats);
   c->proj = ProjCache{}; c->d_proj_words = nullptr; c->d_item_stats = nullptr; c->proj_failed = false; c->last_integrate_cached = false;
+  hipFree(c->alt.data); hipFree(c->alt.cls_all); hipFree(c->alt.stamp); hipFree(c->alt.list[0]); hipFree(c->alt.list[1]); hipFree(c->alt.counts);
+  c->alt = tsdf_ctx::VolSet{}; c->deep_failed = false;
   c->vol.data = nullptr; c->vol.slot = nullptr; c->tiles.stamp = nullptr; c->d_cls_all = nullptr;
   c->d_tile_list[0] = c->d_tile_list[1] = nullptr; c->d_tile_counts = nullptr; c->d_linear = nullptr; c->d_tile_bounds = nullptr;
   c->tile_bounds_valid = false; c->tile_parity = 0; c->full_classify = true; c->frame_stamp = 0;
@@ -560,11 +608,15 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
     if (hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, prio(ppre)) != hipSuccess ||
         (two_lanes ? (c->fill_stream = c->pre_stream, hipSuccess) : hipStreamCreateWithPriority(&c->fill_stream, hipStreamNonBlocking, prio(pfill))) != hipSuccess ||
         hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->march_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->fill_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->integ_stream, hipStreamNonBlocking, prio(0)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->draw_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->draw_done[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->integ_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->integ_gate, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fill_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->fill_done[1], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   }
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
   if (const char* e = getenv("RR_OVERLAP_FILL")) c->overlap_fill = atoi(e) != 0;
+  if (const char* e = getenv("RR_DEEP")) c->deep = atoi(e) != 0;          // A/B and test hook: integrate() on the context's stream, one volume
   {
     uint64_t mib = cfg->proj_cache_mib;                                   // 0: off (the default: measured slower than the LUT kernel)
     if (mib == 0) if (const char* e = getenv("RR_PROJ_CACHE_MB")) mib = (uint64_t)atoll(e);   // A/B and test hook
@@ -637,7 +689,8 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   if (c->pre_gate) hipEventDestroy(c->pre_gate);
   if (c->src_ready) hipEventDestroy(c->src_ready);
   if (c->fill_stream) hipStreamDestroy(c->fill_stream);
-  if (c->march_done) hipEventDestroy(c->march_done);
+  if (c->integ_stream) hipStreamDestroy(c->integ_stream);
+  for (hipEvent_t e : {c->integ_done, c->integ_gate, c->draw_done[0], c->draw_done[1]}) if (e) hipEventDestroy(e);
   for (hipEvent_t e : c->fill_done) if (e) hipEventDestroy(e);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -1169,8 +1222,36 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   if (rc) return rc;
   if (c->vol.slot && !c->use_bricks) FAIL(c, TSDF_ERR_STATE, "a sparse tile pool needs brick culling (setUseBricks(true)): without it every tile is active");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, join_pre(c));
-  timer_begin(c, "2integrate");
+  // the lane: the fourth one and the volume set the previous draw is NOT reading (stage overlap), or the context's stream
+  hipStream_t lane = c->stream;
+  if (deep_ok(c) && ensure_alt_set(c, c->integ_stream)) {
+    lane = c->integ_stream;
+    if (c->draw_unrecorded) {                                            // a draw without hole filling behind it: mark its end now
+      HIP_TRY(c, hipEventRecord(c->draw_done[c->vol_set], c->stream));
+      c->draw_pending[c->vol_set] = true; c->draw_unrecorded = false;
+    }
+    HIP_TRY(c, join_integ(c));                                           // (bookkeeping only: the lane is in order, and a draw has normally consumed it)
+    swap_volume_set(c);
+    if (c->draw_pending[c->vol_set]) { HIP_TRY(c, hipStreamWaitEvent(lane, c->draw_done[c->vol_set], 0)); c->draw_pending[c->vol_set] = false; }   // the draw two frames back read this set
+    // the frame's images and brick state: from the lane ahead (both this lane and the context's stream wait for it), or from work on the context's stream
+    c->main_since_gate = true;
+    c->slot_in_use = c->counters_in_use = c->occ_in_use = true;
+    if (c->pre_pending) {
+      c->pre_pending = false;
+      HIP_TRY(c, hipEventRecord(c->pre_done, c->pre_stream));
+      HIP_TRY(c, hipStreamWaitEvent(lane, c->pre_done, 0));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pre_done, 0));
+    } else {
+      HIP_TRY(c, hipEventRecord(c->integ_gate, c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(lane, c->integ_gate, 0));
+    }
+    c->integ_pending = true;
+  } else {
+    HIP_TRY(c, join_integ(c));
+    HIP_TRY(c, join_pre(c));
+  }
+  const bool deep = lane != c->stream;
+  timer_begin_on(c, "2integrate", lane);
   int lds = 2;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = std::min(lds, c->lds_ok[i]);
   const bool want_cache = lds == 2 && c->k1_form_cap >= 3 && c->proj_budget > 0 && !c->vol.slot && !c->proj_failed;
@@ -1181,13 +1262,13 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     const int p = c->tile_parity;
     S.list = c->d_tile_list[p]; S.count = c->d_tile_counts + p;
     S.prev_list = c->d_tile_list[p ^ 1]; S.prev_count = c->d_tile_counts + (p ^ 1); S.next_count = c->d_tile_counts + (p ^ 1);
-    if (++c->frame_stamp == 0) { c->frame_stamp = 1; c->full_classify = true; HIP_TRY(c, hipMemsetAsync(S.stamp, 0, (size_t)S.n * sizeof(uint32_t), c->stream)); }
+    if (++c->frame_stamp == 0) { c->frame_stamp = 1; c->full_classify = true; HIP_TRY(c, hipMemsetAsync(S.stamp, 0, (size_t)S.n * sizeof(uint32_t), lane)); }
   }
   // the draw that follows would first reset the peel tiles its predecessor touched: let the classify launch do it
   PeelClear pc{};
   {
     const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
-    if (c->use_bricks && !c->full_classify && c->skip_space && whole && c->use_tile_history && c->tile_history && c->d_peels) {
+    if (!deep && c->use_bricks && !c->full_classify && c->skip_space && whole && c->use_tile_history && c->tile_history && c->d_peels) {   // (the fourth lane runs beside the previous draw, which reads the peels)
       pc.peels = (uint4*)c->d_peels; pc.touched_prev = c->d_touched[(c->touched_idx + 2) % 3];     // the previous draw's tiles
       pc.w = c->vw; pc.h = c->vh; pc.ntx = (c->vw + 7) / 8; pc.n_tiles = pc.ntx * ((c->vh + 7) / 8);
       c->peels_cleared = true;
@@ -1197,14 +1278,14 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     pc.zero = c->d_counters[c->counters_cur ^ 1]; pc.zero_words = (uint32_t)c->counter_words;
     c->spare_clean = true;
   }
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
+  launch_integrate(lane, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
   // dense launches: the static half of the uniform-pair shortcut (k_integrate.hip), built once per calibration
   const float4* bounds = nullptr;
   const bool culled_ranges = c->use_bricks && c->culled_ranges && !c->vol.slot && (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 32 <= ((size_t)512 << 20);
   if ((!c->use_bricks || culled_ranges) && lds >= 2 && c->frame.ranges) {
     if (!c->d_tile_bounds) HIP_TRY(c, hipMalloc((void**)&c->d_tile_bounds, (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 2 * sizeof(float4)));
     if (!c->d_pair_masks) HIP_TRY(c, hipMalloc((void**)&c->d_pair_masks, (size_t)c->tiles.n * sizeof(uint32_t)));
-    if (!c->tile_bounds_valid) { launch_tile_bounds(c->stream, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
+    if (!c->tile_bounds_valid) { launch_tile_bounds(lane, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
     bounds = c->d_tile_bounds;
   }
   // projection cache: the pool and its tables, on the first integrate() that can use them.  Capacity = the budget, at most one slot per
@@ -1241,16 +1322,16 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   }
   c->last_integrate_cached = proj != nullptr;
   if (bounds) {                                                        // this frame's (tile, stream) pair classes (+ which work items are cached)
-    timer_begin(c, "k_pair_masks");
-    launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 3, nullptr, bounds, c->d_pair_masks, proj);
-    timer_end(c, "k_pair_masks");
+    timer_begin_on(c, "k_pair_masks", lane);
+    launch_integrate(lane, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 3, nullptr, bounds, c->d_pair_masks, proj);
+    timer_end_on(c, "k_pair_masks", lane);
   }
-  timer_begin(c, "k_integrate_tiles");                                // the kernel(s) alone (bench.py's roofline)
-  launch_integrate(c->stream, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 4, nullptr, bounds, bounds ? c->d_pair_masks : nullptr, proj);
-  timer_end(c, "k_integrate_tiles");
+  timer_begin_on(c, "k_integrate_tiles", lane);                                // the kernel(s) alone (bench.py's roofline)
+  launch_integrate(lane, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 4, nullptr, bounds, bounds ? c->d_pair_masks : nullptr, proj);
+  timer_end_on(c, "k_integrate_tiles", lane);
   if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
   else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them
-  timer_end(c, "2integrate");
+  timer_end_on(c, "2integrate", lane);
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
 }
@@ -1316,6 +1397,7 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
     c->tiled_draws = std::min(2, c->tiled_draws + 1);
   } else { c->tile_history = false; c->draw_masks_valid = false; }
   if (!c->fill_holes) c->fb_consistent = false;                          // the march (or the masked merge below) writes the framebuffer itself
+  HIP_TRY(c, join_integ(c));                                             // the volume: from here on (the depth limits above needed the bricks only)
   timer_begin(c, "draw");
   timer_begin(c, "k_march");
   launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
@@ -1326,6 +1408,7 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   c->own_miss_counts = true;
   if (masked_direct(c)) launch_resolve_masked(c->stream, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0);
   timer_end(c, "draw");
+  c->draw_unrecorded = c->integ_stream != nullptr;                       // (draw_done[set]: recorded by fillColors(), or by the next integrate())
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
 }
@@ -1418,11 +1501,12 @@ static int32_t fill_colors_impl(tsdf_ctx* c, hipStream_t* used) {
   if (c->overlap_fill) {
     if (!c->fill_stream) {                                                // (a context created with RR_OVERLAP_FILL=0 and switched on later)
       HIP_TRY(c, hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking));
-      HIP_TRY(c, hipEventCreateWithFlags(&c->march_done, hipEventDisableTiming));
       for (hipEvent_t& e : c->fill_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    HIP_TRY(c, hipEventRecord(c->march_done, c->stream));                 // everything the caller queued so far: the march / composite into level 0
-    HIP_TRY(c, hipStreamWaitEvent(c->fill_stream, c->march_done, 0));
+    for (hipEvent_t& e : c->draw_done) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->draw_done[c->vol_set], c->stream));      // everything the caller queued so far: the march / composite into level 0
+    c->draw_pending[c->vol_set] = true; c->draw_unrecorded = false;
+    HIP_TRY(c, hipStreamWaitEvent(c->fill_stream, c->draw_done[c->vol_set], 0));
     fs = c->fill_stream;
   }
   timer_begin_on(c, "holefill", fs);
@@ -1469,9 +1553,18 @@ int32_t tsdf_set_tsdf_limit(tsdf_ctx* c, float limit) {
   if (!(limit > 0.0f)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit must be > 0");
   const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
   if (!whole && halo_layers_for(limit, c->res[2]) > c->halo_layers) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "limit needs a wider slab halo than this context allocated");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, sync_ctx(c));
   c->vol.limit = limit;
   launch_mark_all_mixed(c->stream, c->tiles);    // the clear value changed: no tile is known to hold it
   c->full_classify = true;
+  if (c->alt.data) {                                                     // ... in either volume set
+    TileState other = c->tiles;
+    other.cls = c->alt.cls_all + (size_t)(c->vol.int_tz0 - c->vol.tz0) * c->vol.nty * c->vol.ntx;
+    launch_mark_all_mixed(c->stream, other);
+    c->alt.full = true;
+  }
+  HIP_TRY(c, sync_ctx(c));
   return TSDF_OK;
 }
 // setVoxelSize(), recon_integration.cpp:340-353: res = ceil(bbox / size), a new volume, and the brick grid re-snapped to the new
@@ -1570,6 +1663,7 @@ int32_t tsdf_download_volume(tsdf_ctx* c, float* out) {
   HIP_TRY(c, hipSetDevice(c->device));
   int32_t rc = need_linear(c);
   if (rc) return rc;
+  HIP_TRY(c, join_integ(c));
   launch_volume_to_linear(c->stream, c->vol, c->d_linear);
   HIP_TRY(c, hipMemcpyAsync(out, c->d_linear, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, sync_ctx(c));
@@ -1582,6 +1676,7 @@ int32_t tsdf_upload_volume(tsdf_ctx* c, const float* in) {
   HIP_TRY(c, hipSetDevice(c->device));
   int32_t rc = need_linear(c);
   if (rc) return rc;
+  HIP_TRY(c, sync_ctx(c));
   HIP_TRY(c, hipMemcpyAsync(c->d_linear, in, (size_t)c->res[0] * c->res[1] * c->res[2] * sizeof(float), hipMemcpyHostToDevice, c->stream));
   launch_volume_from_linear(c->stream, c->vol, c->d_linear);
   launch_mark_all_mixed(c->stream, c->tiles);

@@ -123,8 +123,21 @@ struct tsdf_ctx {
   uint32_t color_mask_mode = 0; bool keep_color = false;
   // Stage overlap (round 3): the hole filling of draw f runs on a stream of its own beside whatever the caller queues next -- the brick
   // passes and the integrate of frame f + 1 do not touch the pyramid or the framebuffer --, tied to the context's stream by two events:
-  // march_done (the fill waits for the march) and fill_done (the next writer / reader of the pyramid or the framebuffer waits for it).
-  hipStream_t fill_stream = nullptr; hipEvent_t march_done = nullptr, fill_done[2] = {nullptr, nullptr}; bool fill_pending[2] = {false, false};   // (per pyramid)
+  // draw_done (below: the fill waits for the march) and fill_done (the next writer / reader of the pyramid or the framebuffer waits for it).
+  hipStream_t fill_stream = nullptr; hipEvent_t fill_done[2] = {nullptr, nullptr}; bool fill_pending[2] = {false, false};   // (per pyramid)
+  // ... and a fourth lane (round 3): integrate() of frame f + 1 on `integ_stream` beside the draw of frame f on the context's stream.  Everything
+  // integrate() writes and the draw reads -- the volume, its tile classes, the lists / stamps / counts of the incremental classification --
+  // exists twice and alternates per integrate(): `alt` holds the set not in use (allocated on the first such integrate), and each set evolves
+  // exactly like the single volume of rounds 1 / 2, seeing every other frame (the reference rebuilds the TSDF from scratch every frame,
+  // recon_integration.cpp:249-250: no state is carried from frame to frame).  Events: integ_done (the draw waits for its integrate),
+  // draw_done[set] (recorded behind the draw that read the set: the hole filling waits for it, and so does the integrate two frames later
+  // that overwrites the set), integ_gate (work queued on the context's stream that the lane must not overtake).  Whole-volume contexts with
+  // dense storage only; off with stage overlap off, with the projection cache, and with RR_DEEP=0.
+  struct VolSet { float* data = nullptr; uint8_t* cls_all = nullptr; uint32_t* stamp = nullptr; uint32_t* list[2] = {nullptr, nullptr}; uint32_t* counts = nullptr;
+                  int parity = 0; bool full = true; uint32_t stampno = 0; } alt;
+  hipStream_t integ_stream = nullptr; hipEvent_t integ_done = nullptr, integ_gate = nullptr, draw_done[2] = {nullptr, nullptr};
+  bool integ_pending = false, draw_pending[2] = {false, false}, draw_unrecorded = false, deep = true, deep_failed = false;
+  int vol_set = 0;
   bool overlap_fill = true;      // RR_OVERLAP_FILL=0 / tsdf_set_stage_overlap(ctx, 0): everything on the one stream, as in rounds 1 and 2
   // ... and a third lane AHEAD of the context's stream (round 3): what a new frame needs before integrate() can run -- its re-layout and the
   // brick passes (clear / mark / update) -- reads only the new frame and writes state nobody else writes, so it runs on `pre_stream` while
@@ -171,6 +184,7 @@ hipError_t join_pre(tsdf_ctx* c);       // GPU side: the context's stream waits 
 void timer_begin(tsdf_ctx* c, const char* name);
 void timer_end(tsdf_ctx* c, const char* name);
 hipError_t join_fill(tsdf_ctx* c);      // GPU side: the context's stream waits for the hole filling in flight on the second stream
+hipError_t join_integ(tsdf_ctx* c);     // GPU side: the context's stream waits for the integrate in flight on the fourth lane
 hipError_t sync_ctx(tsdf_ctx* c);       // host side: both streams
 RayTarget ray_target(tsdf_ctx* c);
 }  // namespace rrhost

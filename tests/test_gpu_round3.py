@@ -219,3 +219,103 @@ def test_dirty_tile_masks_reach_as_far_as_the_hole_filling_spreads(rr, overlap):
             seen += compare_images(hip, orc, f"view {view} from {eye}, frame {k}")
         assert hip.fill_stats() == (len(order), len(order) - 2)
     assert seen > 9000
+
+
+def make_pair(rr, scene, deep, monkeypatch, **kw):
+    """a context with the fourth lane (integrate() of frame f + 1 beside the draw of frame f, two volume sets) and one without"""
+    monkeypatch.setenv("RR_DEEP", "1" if deep else "0")
+    return rr.ReconIntegrationHip(scene, **kw)
+
+
+def test_two_volume_sets_alternate_without_a_trace(rr, monkeypatch):
+    """integrate() of frame f + 1 runs on a lane of its own beside the draw of frame f, into the volume set the draw is NOT reading;
+    the two sets (volume, tile classes, incremental tile lists) alternate per integrate() and each sees every other frame.  Volume,
+    active tiles, framebuffer and pyramid must be the oracle's after every frame of a moving scene -- whichever set holds it -- and
+    through everything that touches a set from outside: setTsdfLimit, an uploaded volume, dense passes, a new brick grid, min-voxel
+    changes, integrate() twice in a row, a draw without integrate(), the occupied ratio read back between update and integrate."""
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    scs = [rr.scene.make_scene(**mk), rr.scene.make_scene(**mk, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2)), rr.scene.make_scene(**mk, sphere_c=(-0.3, 1.3, 0.2))]
+    kw = dict(res=(96, 96, 96), brick_size=[2.0 / 12, 2.2 / 12, 2.0 / 12], limit=0.03, view=(320, 180))
+    pr = rr.scene.gl_flat(rr.scene.perspective(50.0, 16.0 / 9.0, 0.1, 200.0))
+    mvs = [rr.scene.gl_flat(rr.scene.look_at(e, (0.0, 1.1, 0.0))) for e in [(0.0, 1.1, 3.0), (1.6, 1.4, 2.4), (-2.2, 0.6, 1.2)]]
+    hip, orc = make_pair(rr, scs[0], True, monkeypatch, **kw), OracleRecon(scs[0], **kw)
+    n = [0]
+
+    def both(fn):
+        for o in (hip, orc):
+            fn(o)
+
+    def check(what):
+        assert_same(hip.tsdf(), orc.tsdf(), f"volume, {what}")
+        compare_images(hip, orc, what)
+
+    def run(frames, what, ratio=False):
+        got = []
+        for _ in range(frames):
+            k = n[0]; n[0] += 1
+            for o in (hip, orc):
+                o.upload_frame(scs[[0, 1, 1, 2, 0, 2][k % 6]])
+                o.clearOccupiedBricks(); o.markBricks()
+                r = o.updateOccupiedBricks(ratio) if o is hip else o.updateOccupiedBricks()
+                if ratio:
+                    got.append(r)
+                o.integrate(); o.drawF(mvs[k % 3], pr)
+            if ratio:
+                assert got[-2] == got[-1] and got[-1] > 0
+            check(f"{what}, frame {k}")
+
+    run(7, "moving scene")
+    run(3, "occupied ratio read back", ratio=True)
+    both(lambda o: o.setTsdfLimit(0.045)); run(4, "another limit")
+    both(lambda o: o.setTsdfLimit(0.03)); run(3, "the first limit again")
+    vol = orc.tsdf().copy(); vol[20:40, 30:50, 10:30] = np.float32(0.01)
+    both(lambda o: (o.set_tsdf(vol), o.drawF(mvs[0], pr))); check("an uploaded volume, drawn")
+    run(4, "after the uploaded volume")
+    both(lambda o: o.setUseBricks(False)); run(3, "dense")
+    both(lambda o: o.setUseBricks(True)); run(4, "culled again")
+    both(lambda o: o.setMinVoxelsPerBrick(60)); run(3, "more voxels per brick")
+    both(lambda o: o.setMinVoxelsPerBrick(10)); run(3, "fewer again")
+    both(lambda o: (o.integrate(), o.integrate(), o.drawF(mvs[1], pr))); check("integrate twice, draw")
+    both(lambda o: o.drawF(mvs[2], pr)); check("a draw without integrate")
+    both(lambda o: (o.integrate(), o.drawF(mvs[0], pr), o.drawF(mvs[1], pr))); check("two draws of one volume")
+    run(4, "and on")
+    hip.setBrickSize([2.0 / 8, 2.2 / 8, 2.0 / 8])
+    orc2 = OracleRecon(scs[0], **dict(kw, brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8]))
+    for k in range(5):
+        for o in (hip, orc2):
+            o.upload_frame(scs[k % 3]); frame(o, mvs[k % 3], pr)
+        assert_same(hip.tsdf(), orc2.tsdf(), f"volume, new brick grid, frame {k}")
+        compare_images(hip, orc2, f"new brick grid, frame {k}")
+
+
+@pytest.mark.parametrize("use_bricks", [True, False])
+def test_fourth_lane_back_to_back_frames(rr, monkeypatch, use_bricks):
+    """Frames queued back to back with no host read in between -- integrate(f + 1) really runs beside march / shade(f) -- leave what a
+    context without the lane leaves, every frame's framebuffer included (kept on the device by a copy queued on the context's stream)."""
+    import torch
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    scs = [rr.scene.make_scene(**mk), rr.scene.make_scene(**mk, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2)), rr.scene.make_scene(**mk, sphere_c=(-0.3, 1.3, 0.2))]
+    kw = dict(res=(128, 128, 128), brick_size=[2.0 / 16, 2.2 / 16, 2.0 / 16], limit=0.03, view=(640, 360))
+    pr = rr.scene.gl_flat(rr.scene.perspective(50.0, 16.0 / 9.0, 0.1, 200.0))
+    mvs = [rr.scene.gl_flat(rr.scene.look_at(e, (0.0, 1.1, 0.0))) for e in [(0.0, 1.1, 3.0), (1.6, 1.4, 2.4), (-2.2, 0.6, 1.2)]]
+    deep, flat = make_pair(rr, scs[0], True, monkeypatch, **kw), make_pair(rr, scs[0], False, monkeypatch, **kw)
+    orc = OracleRecon(scs[0], **kw)
+    raw = [[torch.from_numpy(np.ascontiguousarray(sc[k])).cuda() for k in ("depth", "quality", "silhouette", "color")] for sc in scs]
+    torch.cuda.synchronize()
+    order = [0, 1, 1, 2, 0, 2, 1, 0, 0, 2, 1, 2] * 3
+    for o in (deep, flat, orc):
+        o.setUseBricks(use_bricks); o.setSpaceSkip(use_bricks)
+    for rounds in range(2):
+        for n, k in enumerate(order):
+            for o in (deep, flat):
+                o.upload_frame_dev(*[t.data_ptr() for t in raw[k]], complete=True)
+                frame_nosync(o, mvs[n % 3], pr)
+        last = (order[-1], mvs[(len(order) - 1) % 3])
+        (dc, dd), (fc, fd) = deep.framebuffer(), flat.framebuffer()
+        assert_same(dd, fd, f"framebuffer depth, round {rounds}"); assert_same(dc, fc, f"framebuffer colour, round {rounds}")
+        assert_same(deep.tsdf(), flat.tsdf(), f"volume, round {rounds}")
+    orc.upload_frame(scs[last[0]]); frame(orc, last[1], pr)
+    assert_same(deep.tsdf(), orc.tsdf(), "volume vs oracle")
+    (dc, dd), (oc, od) = deep.framebuffer(), orc.framebuffer()
+    assert_same(dd, od, "framebuffer depth vs oracle"); assert_same(dc, oc, "framebuffer colour vs oracle")
+    assert (od < 1).sum() > 500

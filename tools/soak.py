@@ -44,13 +44,13 @@ def digest():
 ref = {}
 t0 = time.perf_counter()
 for f in range(1, N + 1):
-    which = f & 1
+    which = ((f + 1) >> 1) & 1                            # A A B B ...: with two volume sets alternating per integrate() (the fourth lane) each set still sees A, B, A, B
     if SLOTS:
         hip.select_frame_slot(0 if which else 1)
     else:
         hip.upload_frame_dev(*ptr[which], complete=True)
     hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv if which else mv_b, pr)
-    if f <= 2 or f % CHECK in (0, 1):
+    if f <= 4 or f % CHECK in (0, 1, 2, 3):
         h = digest()
         ref.setdefault(which, h)
         print(f"frame {f} ({'A' if which else 'B'}): {h[:16]} {'ok' if h == ref[which] else 'DIFFERENT'}  ({time.perf_counter() - t0:.1f} s)", flush=True)
