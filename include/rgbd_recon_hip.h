@@ -241,6 +241,12 @@ int32_t tsdf_raymarch(tsdf_ctx* ctx, const float modelview[16], const float proj
 int32_t tsdf_fill_colors(tsdf_ctx* ctx);                        /* fillColors(), :279-338 */
 /* drawF(): tsdf_raymarch + (colour filling on ? tsdf_fill_colors : nothing), :151-174 */
 int32_t tsdf_draw_f(tsdf_ctx* ctx, const float modelview[16], const float projection[16]);
+/* One frame of the client's loop in one call (source/kinect_client.cpp:586-599 update + :616-669 draw): [tsdf_upload_frame_dev when depth_rg
+ * is not NULL,] clearOccupiedBricks, markBricks (tsdf_upload_frame's brick marking), updateOccupiedBricks (no read-back), integrate, drawF.
+ * Exactly the calls above in that order -- same results, same lanes --, for callers whose per-call overhead (an FFI, an interpreter)
+ * is of the order of the frame itself.  Stops at the first failing step and returns its code. */
+int32_t tsdf_frame_dev(tsdf_ctx* ctx, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour_rgb, uint32_t flags,
+                       const float modelview[16], const float projection[16]);
 
 /* ---- setters mirroring recon_integration.hpp:43-49,57 and reconstruction.hpp:20-23 --------------- */
 int32_t tsdf_set_tsdf_limit(tsdf_ctx* ctx, float limit);
@@ -355,20 +361,28 @@ int32_t tsdf_set_timer_filter(tsdf_ctx* ctx, const char* names);
 int32_t tsdf_timer_reserve(tsdf_ctx* ctx, const char* name, uint32_t n);   /* create n event pairs now instead of on first use */
 int32_t tsdf_timer_begin(tsdf_ctx* ctx, const char* name);
 int32_t tsdf_timer_end(tsdf_ctx* ctx, const char* name);
-/* Stage overlap (default on; RR_OVERLAP_FILL=0 in the environment turns it off at creation).  A frame's kernels form three chains that
- * touch disjoint state, and the context runs them on three HIP streams of its own, tied by events:
+/* Stage overlap (default on; RR_OVERLAP_FILL=0 in the environment turns it off at creation).  A frame's kernels form four chains that
+ * touch disjoint state, and the context runs them on four HIP streams of its own, tied by events:
  *   the lane ahead      what a NEW frame needs before integrate(): its re-layout (tsdf_upload_frame / _dev) and the brick passes
  *                       (clear / mark / update) run while the context's stream still works on the previous frame; the frame slots and the
  *                       brick state exist twice and alternate
- *   the context's stream  integrate(), depth limits, march, shading (and every collective / export)
- *   the fill lane       fillColors() of a draw runs beside the next frame's integrate(); two pyramids alternate per draw
- * integrate() / draws wait (on the GPU) for the lane ahead, every download and tsdf_sync() for all three.  Results are identical either
- * way.  The lane ahead is not used after an explicit frame-slot call (tsdf_select_frame_slot, tsdf_frame_staging, tsdf_upload_frame_async)
+ *   the integrate lane  integrate() of frame f + 1 runs beside the draw of frame f: the volume, its tile classes and the tile lists exist
+ *                       twice and alternate per integrate() (the TSDF is rebuilt from scratch every frame, recon_integration.cpp:249-250,
+ *                       so nothing is carried from one set to the other).  Whole-volume contexts with dense storage; twice the volume
+ *                       memory, allocated on the first integrate(); RR_DEEP=0 in the environment at creation keeps integrate() on the
+ *                       context's stream and one volume
+ *   the context's stream  depth limits, march, shading (and every collective / export)
+ *   the fill lane       fillColors() of a draw runs beside the next frame's integrate() / draw; two pyramids alternate per draw
+ * integrate() / draws wait (on the GPU) for the lanes they depend on, every download and tsdf_sync() for all of them.  Results are
+ * identical either way.  The lane ahead is not used after an explicit frame-slot call (tsdf_select_frame_slot, tsdf_frame_staging, tsdf_upload_frame_async)
  * or with the pre-processing path.  tsdf_set_stage_overlap(ctx, 0) puts everything back on the one stream (synchronises first);
  * tsdf_timer_end_after_fill records a caller timer's end behind the hole filling in flight (a frame's latency). */
 int32_t tsdf_set_stage_overlap(tsdf_ctx* ctx, int32_t on);
 int32_t tsdf_timer_end_after_fill(tsdf_ctx* ctx, const char* name);
 int32_t tsdf_timer_samples(tsdf_ctx* ctx, const char* name, float* out_ms, uint32_t capacity, uint32_t* count);
+/* where every invocation of `name` since the last reset lies on the device's clock: begin and end in ms after the first begin of timer
+ * `origin` (a timeline of the lanes; does not reset the timers) */
+int32_t tsdf_timer_spans(tsdf_ctx* ctx, const char* name, const char* origin, float* begin_ms, float* end_ms, uint32_t capacity, uint32_t* count);
 int32_t tsdf_timer_ms(tsdf_ctx* ctx, const char* name, float* last_ms);   /* synchronises on that timer */
 /* every invocation since the previous call: count and summed device time; resets the timer */
 int32_t tsdf_timer_stats(tsdf_ctx* ctx, const char* name, uint32_t* count, float* total_ms);

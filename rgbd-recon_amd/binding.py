@@ -375,6 +375,13 @@ class ReconIntegrationHip:
 
     def fillColors(self): self._ck(self._L.tsdf_fill_colors(self._c))
     def drawF(self, mv, proj): self._ck(self._L.tsdf_draw_f(self._c, _fp(_f32(mv)), _fp(_f32(proj))))
+
+    def frame_dev(self, mv, proj, new_frame=None, complete=True):
+        """one frame of the client's loop in ONE call (tsdf_frame_dev): [the re-layout of a frame that arrived in device memory -- new_frame =
+        (depth_rg, quality, silhouette[, colour]) device pointers --,] clear / mark / update of the bricks, integrate, drawF"""
+        d, q, s, col = (tuple(new_frame) + (0,))[:4] if new_frame is not None else (0, 0, 0, 0)
+        self._ck(self._L.tsdf_frame_dev(self._c, C.c_void_p(d), C.c_void_p(q), C.c_void_p(s), C.c_void_p(col), C.c_uint32(1 if complete else 0),
+                                        _fp(_f32(mv)), _fp(_f32(proj))))
     def setTsdfLimit(self, v): self._ck(self._L.tsdf_set_tsdf_limit(self._c, C.c_float(v)))
 
     def setVoxelSize(self, size):
@@ -514,6 +521,12 @@ class ReconIntegrationHip:
         out, n = np.zeros(capacity, np.float32), C.c_uint32()
         self._ck(self._L.tsdf_timer_samples(self._c, name.encode(), _fp(out), capacity, C.byref(n)))
         return out[:n.value].copy()
+
+    def timer_spans(self, name, origin, capacity=8192):
+        """(begin, end) in ms after the first begin of timer `origin`, for every invocation of `name` since the last reset"""
+        b, e, n = np.zeros(capacity, np.float32), np.zeros(capacity, np.float32), C.c_uint32()
+        self._ck(self._L.tsdf_timer_spans(self._c, name.encode(), origin.encode(), _fp(b), _fp(e), capacity, C.byref(n)))
+        return b[:n.value].copy(), e[:n.value].copy()
 
     def timer_stats(self, name):
         n, ms = C.c_uint32(), C.c_float()

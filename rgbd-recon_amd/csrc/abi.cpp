@@ -4,6 +4,7 @@
 // ViewLod::setResolution (framework/rendering/view_lod.cpp:24-50), the per-frame call order of
 // source/kinect_client.cpp:569-599,614.  All device work goes to one HIP stream.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -81,9 +82,7 @@ void release_view(tsdf_ctx* c) {
   c->atlas.color = nullptr; c->atlas.depth = nullptr; c->d_peels = nullptr; c->d_nsamples = nullptr; c->d_fb_c = nullptr; c->d_fb_d = nullptr;
 }
 void release_bricks(tsdf_ctx* c) {
-  hipFree(c->d_counters[0]); hipFree(c->d_counters[1]);
-  for (int k = 0; k < 2; ++k) { hipFree(c->d_flags[k]); hipFree(c->d_occupied[k]); c->d_flags[k] = nullptr; c->d_occupied[k] = nullptr; }
-  c->d_counters[0] = c->d_counters[1] = nullptr;
+  for (int k = 0; k < 2; ++k) { hipFree(c->d_counters[k]); hipFree(c->d_flags[k]); hipFree(c->d_occupied[k]); c->d_counters[k] = nullptr; c->d_flags[k] = nullptr; c->d_occupied[k] = nullptr; }
   c->br.counters = nullptr; c->br.flags = nullptr; c->br.num_occupied = nullptr; c->br.occupied = nullptr;
   for (int a = 0; a < 3; ++a) {
     hipFree(c->d_vox_first[a]); hipFree(c->d_vox_count[a]); hipFree(c->d_tile_b0[a]); hipFree(c->d_tile_b1[a]); hipFree(c->d_tile_full[a]); c->d_tile_full[a] = nullptr;
@@ -242,6 +241,7 @@ int32_t setup_bricks(tsdf_ctx* c, const float req[3]) {
   B.counters = c->d_counters[0];
   if (!c->d_occ_counts) HIP_TRY(c, hipMalloc(&c->d_occ_counts, 3 * sizeof(uint32_t)));
   HIP_TRY(c, hipMemset(c->d_occ_counts, 0, 3 * sizeof(uint32_t)));      // a new grid: no occupied list yet
+  c->occ_counts_stale = false;
   B.num_occupied = c->d_occ_counts + c->occ_parity;
   for (int k = 0; k < 2; ++k) {
     HIP_TRY(c, hipMalloc(&c->d_flags[k], (size_t)B.n));
@@ -291,6 +291,7 @@ hipError_t join_fill(tsdf_ctx* c) {
 }
 // ---- the lane ahead (see tsdf_ctx::pre_stream)
 bool pipelined(const tsdf_ctx* c) { return c->overlap_fill && !c->pipeline_blocked; }
+inline int alt_of(int x) { return x ^ 1; }
 hipStream_t pre_enter(tsdf_ctx* c) {
   if (!pipelined(c)) return c->stream;
   if (!c->pre_stream) {                                                   // (a context created with RR_OVERLAP_FILL=0 and switched on later)
@@ -816,7 +817,7 @@ int32_t tsdf_set_calibration(tsdf_ctx* c, uint32_t i, const float* inv, const ui
 // (it flips to them here instead): one launch and one dependent step less on the lane.
 static uint32_t* counters_for_upload(tsdf_ctx* c, hipStream_t lane) {
   if (lane == c->stream || c->counters_zeroed || !c->d_counters[0]) return nullptr;
-  if (!c->counters_flipped && c->counters_in_use) { c->counters_cur ^= 1; c->br.counters = c->d_counters[c->counters_cur]; }
+  if (!c->counters_flipped && c->counters_in_use) { c->counters_cur = alt_of(c->counters_cur); c->br.counters = c->d_counters[c->counters_cur]; }
   c->counters_flipped = true; c->counters_in_use = false; c->counters_zeroed = true; c->spare_clean = false;
   return c->br.counters;
 }
@@ -827,7 +828,7 @@ static int32_t begin_slot_write(tsdf_ctx* c, hipStream_t lane, bool keep_colour)
   c->slot_flipped = true;
   if (!c->slot_in_use) return TSDF_OK;                                   // nothing queued reads the current slot (the first frame): in place
   c->slot_in_use = false;
-  const int old = c->cur_slot, t = old ^ 1;
+  const int old = c->cur_slot, t = alt_of(old);
   if (int32_t rc = alloc_frame_slot(c, t)) return rc;
   if (keep_colour) {                                                     // "colour may be NULL (keeps the previous one)": the previous one lives in the other slot
     const size_t nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
@@ -930,7 +931,7 @@ int32_t tsdf_upload_frame_async(tsdf_ctx* c, const float* depth_rg, const float*
   if (quality && quality != sq) memcpy(sq, quality, np * 4);
   if (silhouette && silhouette != ss) memcpy(ss, silhouette, np * 4);
   if (colour && colour != sc) { memcpy(sc, colour, nc * 3); with_colour = 1; }
-  const int k = c->stage_k, t = c->cur_slot ^ 1;
+  const int k = c->stage_k, t = alt_of(c->cur_slot);
   tsdf_ctx::FrameSlot& S = c->slots[t];
   if (S.in_use) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, S.released, 0));   // the path's reads of slot t were all queued before `released`
   const size_t bytes = np * 16 + (with_colour ? nc * 3 : 0);
@@ -1151,13 +1152,13 @@ int32_t tsdf_clear_bricks(tsdf_ctx* c) {
   const hipStream_t lane = pre_enter(c);
   timer_begin_on(c, "bricks", lane);
   if (lane != c->stream) {                                               // the lane ahead: the other counter buffer (the previous frame's draw may still read this one)
-    if (!c->counters_flipped && c->counters_in_use) { c->counters_cur ^= 1; c->br.counters = c->d_counters[c->counters_cur]; }
+    if (!c->counters_flipped && c->counters_in_use) { c->counters_cur = alt_of(c->counters_cur); c->br.counters = c->d_counters[c->counters_cur]; }
     c->counters_flipped = true; c->counters_in_use = false;
     c->spare_clean = false;
     if (c->counters_zeroed) c->counters_zeroed = false;                  // the frame's re-layout launch cleared them (a second clear of the frame fills again)
     else HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), lane));
   } else if (c->spare_clean) {                                           // the other buffer was zeroed by the last integrate(): swap
-    c->counters_cur ^= 1;
+    c->counters_cur = alt_of(c->counters_cur);
     c->br.counters = c->d_counters[c->counters_cur];
     c->spare_clean = false;
   } else HIP_TRY(c, hipMemsetAsync(c->br.counters, 0, c->counter_words * sizeof(uint32_t), c->stream));
@@ -1172,7 +1173,7 @@ int32_t tsdf_mark_bricks(tsdf_ctx* c) {
   const hipStream_t lane = pre_enter(c);
   uint32_t* zero_word = nullptr;
   if (lane != c->stream) {                                               // the count of the occupancy set the coming update flips to (or stays on)
-    zero_word = c->d_occ_counts + ((!c->occ_flipped && c->occ_in_use) ? (c->occ_parity ^ 1) : c->occ_parity);
+    zero_word = c->d_occ_counts + ((!c->occ_flipped && c->occ_in_use) ? alt_of(c->occ_parity) : c->occ_parity);
     c->occ_count_zeroed = true;
   }
   launch_mark_bricks(lane, c->luts, c->frame, c->br, zero_word);
@@ -1187,17 +1188,21 @@ int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
   if (lane != c->stream) {
     // the lane ahead: the other occupancy set (flags, list, count) -- the previous frame's integrate / draw may still read this one --, its
     // count zeroed here instead of by the previous update (which would zero the word the context's stream is reading)
-    if (!c->occ_flipped && c->occ_in_use) c->occ_parity ^= 1;
-    c->occ_flipped = true; c->occ_in_use = false;
+    if (!c->occ_flipped && c->occ_in_use) c->occ_parity = alt_of(c->occ_parity);
+    c->occ_flipped = true; c->occ_in_use = false; c->occ_counts_stale = true;
     c->br.num_occupied = c->d_occ_counts + c->occ_parity; c->br.flags = c->d_flags[c->occ_parity]; c->br.occupied = c->d_occupied[c->occ_parity];
     if (c->occ_count_zeroed) c->occ_count_zeroed = false;                // the frame's marking launch cleared the count (a second update of the frame fills again)
     else HIP_TRY(c, hipMemsetAsync(c->br.num_occupied, 0, sizeof(uint32_t), lane));
     launch_update_occupied(lane, c->br, c->min_voxels, c->d_occ_counts + 2);          // (a third word takes the kernel's re-arming store)
   } else {
-    c->occ_parity ^= 1;
-    c->br.num_occupied = c->d_occ_counts + c->occ_parity;            // zero since the previous update (or creation) re-armed it
+    c->occ_parity = alt_of(c->occ_parity);
+    c->br.num_occupied = c->d_occ_counts + c->occ_parity;            // zero since the previous update (or creation) re-armed it ...
+    if (c->occ_counts_stale) {                                           // ... unless the lane ahead has used the words in between (it zeroes its own and re-arms none)
+      HIP_TRY(c, hipMemsetAsync(c->br.num_occupied, 0, sizeof(uint32_t), c->stream));
+      c->occ_counts_stale = false;
+    }
     c->br.flags = c->d_flags[c->occ_parity]; c->br.occupied = c->d_occupied[c->occ_parity];
-    launch_update_occupied(c->stream, c->br, c->min_voxels, c->d_occ_counts + (c->occ_parity ^ 1));
+    launch_update_occupied(c->stream, c->br, c->min_voxels, c->d_occ_counts + alt_of(c->occ_parity));
   }
   HIP_TRY(c, hipGetLastError());
   timer_end_on(c, "bricks", lane);
@@ -1275,7 +1280,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     }
   }
   if (c->use_bricks && !c->full_classify && !c->spare_clean && !pipelined(c)) {   // ... and zero the spare counter buffer for the next clearOccupiedBricks() (the lane ahead clears its own)
-    pc.zero = c->d_counters[c->counters_cur ^ 1]; pc.zero_words = (uint32_t)c->counter_words;
+    pc.zero = c->d_counters[alt_of(c->counters_cur)]; pc.zero_words = (uint32_t)c->counter_words;
     c->spare_clean = true;
   }
   launch_integrate(lane, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, c->full_classify ? 1 : 0, c->frame_stamp, 1, &pc);
@@ -1537,6 +1542,37 @@ int32_t tsdf_draw_f(tsdf_ctx* c, const float* mv, const float* pr) {
   if (c->fill_holes && (rc = fill_colors_impl(c, &last))) return rc;
   timer_end_on(c, "3recon", last);
   return TSDF_OK;
+}
+int32_t tsdf_frame_dev(tsdf_ctx* c, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour, uint32_t flags, const float* mv, const float* pr) {
+  CHECK_CTX(c);
+  int32_t rc;
+  static const bool prof = getenv("RR_HOST_PROFILE") != nullptr;          // (measurement hook: host time of each step, printed every 1000 frames)
+  if (prof) {
+    using clk = std::chrono::steady_clock;
+    static double acc[6] = {0, 0, 0, 0, 0, 0}; static int n = 0;
+    auto t0 = clk::now();
+    auto lap = [&](int k) { auto t1 = clk::now(); acc[k] += std::chrono::duration<double, std::micro>(t1 - t0).count(); t0 = t1; };
+    if (depth_rg && (rc = tsdf_upload_frame_dev(c, depth_rg, quality, silhouette, colour, flags))) return rc;
+    lap(0);
+    if ((rc = tsdf_clear_bricks(c))) return rc;
+    if ((rc = tsdf_mark_bricks(c))) return rc;
+    lap(1);
+    if ((rc = tsdf_update_occupied(c, nullptr))) return rc;
+    lap(2);
+    if ((rc = tsdf_integrate(c))) return rc;
+    lap(3);
+    if ((rc = raymarch_impl(c, mv, pr, true))) return rc;
+    lap(4);
+    hipStream_t last = c->stream;
+    if (c->fill_holes && (rc = fill_colors_impl(c, &last))) return rc;
+    timer_end_on(c, "3recon", last);
+    lap(5);
+    if (++n % 1000 == 0) { fprintf(stderr, "host us per frame: upload %.1f clear+mark %.1f update %.1f integrate %.1f draw %.1f fill %.1f\n", acc[0] / 1000, acc[1] / 1000, acc[2] / 1000, acc[3] / 1000, acc[4] / 1000, acc[5] / 1000); for (double& a : acc) a = 0; }
+    return TSDF_OK;
+  }
+  if (depth_rg && (rc = tsdf_upload_frame_dev(c, depth_rg, quality, silhouette, colour, flags))) return rc;
+  if ((rc = tsdf_clear_bricks(c)) || (rc = tsdf_mark_bricks(c)) || (rc = tsdf_update_occupied(c, nullptr)) || (rc = tsdf_integrate(c))) return rc;
+  return tsdf_draw_f(c, mv, pr);
 }
 int32_t tsdf_set_stage_overlap(tsdf_ctx* c, int32_t on) {
   CHECK_CTX(c);
@@ -1896,6 +1932,23 @@ int32_t tsdf_timer_samples(tsdf_ctx* c, const char* name, float* out_ms, uint32_
   }
   *count = (uint32_t)n;
   t.used = 0;
+  return TSDF_OK;
+}
+int32_t tsdf_timer_spans(tsdf_ctx* c, const char* name, const char* origin, float* begin_ms, float* end_ms, uint32_t capacity, uint32_t* count) {
+  CHECK_CTX(c);
+  if (!name || !origin || !count || ((!begin_ms || !end_ms) && capacity)) return TSDF_ERR_INVALID_ARGUMENT;
+  *count = 0;
+  auto it = c->timers.find(name), io = c->timers.find(origin);
+  if (it == c->timers.end() || io == c->timers.end() || io->second.used == 0) return TSDF_OK;
+  Timer& t = it->second;
+  const hipEvent_t zero = io->second.ev[0].first;
+  const size_t n = std::min<size_t>(t.used, capacity);
+  for (size_t i = 0; i < n; ++i) {
+    HIP_TRY(c, hipEventSynchronize(t.ev[i].second));
+    HIP_TRY(c, hipEventElapsedTime(&begin_ms[i], zero, t.ev[i].first));
+    HIP_TRY(c, hipEventElapsedTime(&end_ms[i], zero, t.ev[i].second));
+  }
+  *count = (uint32_t)n;
   return TSDF_OK;
 }
 int32_t tsdf_timer_stats(tsdf_ctx* c, const char* name, uint32_t* count, float* total_ms) {

@@ -145,7 +145,8 @@ struct tsdf_ctx {
   // the first upload of a frame), the brick counters (flip at clearOccupiedBricks), flags + occupied list + count (flip at
   // updateOccupiedBricks).  Two events tie the lanes: pre_done (integrate / draw wait for the lane) and pre_gate (recorded on the context's
   // stream at the lane's first call of a frame, waited for at its first call of the NEXT frame: what the lane overwrites then was last read
-  // two frames ago).  Off with stage overlap off, after an explicit frame-slot call (tsdf_select_frame_slot, tsdf_upload_frame_async) and for
+  // two frames ago).  (A third copy of everything, letting the lane run two frames ahead, was built and measured: the lanes then crowd each
+  // other -- every stage stretches -- and the frame takes 140 instead of 121 us: DESIGN.md section 5.)  Off with stage overlap off, after an explicit frame-slot call (tsdf_select_frame_slot, tsdf_upload_frame_async) and for
   // the pre-processing path.
   hipStream_t pre_stream = nullptr; hipEvent_t pre_done = nullptr, pre_gate = nullptr, src_ready = nullptr;
   bool pre_pending = false, pre_gate_recorded = false, main_since_gate = true, pipeline_blocked = false;
@@ -153,6 +154,7 @@ struct tsdf_ctx {
   bool slot_in_use = false, counters_in_use = false, occ_in_use = false;        // ... and only when a consumer has been queued since the buffer was last written
   bool counters_zeroed = false, occ_count_zeroed = false;                       // the re-layout launch / the marking launch has cleared them already (no fill launch of its own)
   uint8_t* d_flags[2]{}; uint32_t* d_occupied[2]{};                             // the two occupancy sets (Bricks::flags / occupied point at the latest update's)
+  bool occ_counts_stale = false;                                                // the lane ahead has used the count words: the context's stream zeroes its word itself once
   // native multi-GPU exchange (comm.cpp): one RCCL communicator per context, every collective on the context's stream
   struct Comm {
     void* comm = nullptr;                     // ncclComm_t

@@ -289,6 +289,9 @@ class SlabDriver:
 
     def _frame(self, mv, proj, new_frame=None):
         b = self.b
+        if self.is_worker and not self.exchanging and not self.preprocess:   # one rank, nothing to exchange: the whole frame in one call into the library
+            b.frame_dev(mv, proj, new_frame)
+            return
         if self.is_worker and new_frame is not None:
             b.upload_frame_dev(*new_frame, complete=True)
         if self.is_worker:

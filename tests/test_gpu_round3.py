@@ -266,6 +266,8 @@ def test_two_volume_sets_alternate_without_a_trace(rr, monkeypatch):
 
     run(7, "moving scene")
     run(3, "occupied ratio read back", ratio=True)
+    hip.set_stage_overlap(False); run(4, "everything on one stream (after the lanes have used the rotating buffers)")
+    hip.set_stage_overlap(True); run(5, "lanes again")
     both(lambda o: o.setTsdfLimit(0.045)); run(4, "another limit")
     both(lambda o: o.setTsdfLimit(0.03)); run(3, "the first limit again")
     vol = orc.tsdf().copy(); vol[20:40, 30:50, 10:30] = np.float32(0.01)
