@@ -399,7 +399,7 @@ def main():
     # The stage and kernel timers -- and with them the roofline -- come from NON-overlapped passes: by default fillColors() of frame f runs on
     # its own stream beside the brick passes and the integrate of frame f + 1 (stage overlap), which stretches every kernel it shares the
     # machine with; tsdf_set_stage_overlap(0) queues everything on the one stream for these passes, the timed region runs as shipped
-    overlap = os.environ.get("RR_OVERLAP_FILL", "1") != "0" and cfg["fill_holes"] and args.frames_in_flight == 1
+    overlap = os.environ.get("RR_OVERLAP_FILL", "1") != "0" and args.frames_in_flight == 1      # (without hole filling -- c1 -- the lane ahead and the integrate lane still apply)
     every = slots if not slabs_mode else [drv]
     stages = {}
     dom = None
@@ -452,6 +452,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(slots[i % len(slots)], i // len(slots) if len(slots) > 1 else i)
+    t_issued = time.perf_counter() - t0                   # (the host's share: every call of the loop has returned; the device may still be working)
     barrier()
     dt = time.perf_counter() - t0
     dom_ms_insitu = None
@@ -523,6 +524,23 @@ def main():
         rh.close()
         resident = {"value": args.steps / dr, "ms_per_step": dr / args.steps * 1e3,
                     "note": "two frames already in the kernels' layout alternate (tsdf_select_frame_slot; brick passes on the context's stream): the definition of `value` in rounds 1 and 2"}
+    # the same loop without the integrate lane (RR_DEEP=0 at creation: integrate() on the context's stream, one volume -- three lanes)
+    three_lanes = None
+    if nsc > 1 and repack and not slabs_mode and overlap and os.environ.get("RR_DEEP", "1") != "0":
+        os.environ["RR_DEEP"] = "0"
+        th = make_ctx(sparse=args.sparse_pool)
+        del os.environ["RR_DEEP"]
+        for i in range(300):
+            th.frame_dev(mv, pr, raw[i % nsc][1])
+        th.sync()
+        tt0 = time.perf_counter()
+        for i in range(args.steps):
+            th.frame_dev(mv, pr, raw[i % nsc][1])
+        th.sync()
+        dtl = time.perf_counter() - tt0
+        th.close()
+        three_lanes = {"value": args.steps / dtl, "ms_per_step": dtl / args.steps * 1e3,
+                       "note": "a context created with RR_DEEP=0: lane ahead + the context's stream (integrate, march, shade) + fill lane, one volume"}
     long_run = None
     if args.long_steps and args.frames_in_flight == 1:
         dl = timed(args.long_steps, lambda i: step(drv, i))
@@ -572,6 +590,12 @@ def main():
                                   + ("collectives called from inside the library (comm.cpp)" if args.exchange == "native" else "collectives through torch.distributed")
                                   + ("; every new frame is broadcast from rank 0 inside the step" if bcast else "; both frames resident on every rank")},
         "stage_overlap": bool(overlap),
+        "lanes": ("lane ahead (re-layout + brick passes of frame f+2) | integrate lane (classify, pair masks, integrate of f+1; two alternating volume sets) | "
+                  "the context's stream (depth limits, march, shade of f) | fill lane (hole filling of f-1)") if overlap and os.environ.get("RR_DEEP", "1") != "0" and not slabs_mode
+                 else ("lane ahead | the context's stream (integrate, depth limits, march, shade) | fill lane" if overlap else "one stream"),
+        "host_issue_ms_per_step": t_issued / args.steps * 1e3,
+        "hole_filling": dict(zip(("passes", "by_dirty_tiles"), hip.fill_stats())),
+        "three_lanes": three_lanes,
         "serial": serial,
         "static": static,
         "resident_frames": resident,

@@ -368,7 +368,7 @@ int32_t tsdf_timer_end(tsdf_ctx* ctx, const char* name);
  *                       brick state exist twice and alternate
  *   the integrate lane  integrate() of frame f + 1 runs beside the draw of frame f: the volume, its tile classes and the tile lists exist
  *                       twice and alternate per integrate() (the TSDF is rebuilt from scratch every frame, recon_integration.cpp:249-250,
- *                       so nothing is carried from one set to the other).  Whole-volume contexts with dense storage; twice the volume
+ *                       so nothing is carried from one set to the other).  Dense storage (whole volume, or a Z-slab that recomputes its halo); twice the volume
  *                       memory, allocated on the first integrate(); RR_DEEP=0 in the environment at creation keeps integrate() on the
  *                       context's stream and one volume
  *   the context's stream  depth limits, march, shading (and every collective / export)

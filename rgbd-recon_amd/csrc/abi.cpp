@@ -292,6 +292,7 @@ hipError_t join_fill(tsdf_ctx* c) {
 // ---- the lane ahead (see tsdf_ctx::pre_stream)
 bool pipelined(const tsdf_ctx* c) { return c->overlap_fill && !c->pipeline_blocked; }
 inline int alt_of(int x) { return x ^ 1; }
+bool deep_ok(const tsdf_ctx* c);
 hipStream_t pre_enter(tsdf_ctx* c) {
   if (!pipelined(c)) return c->stream;
   if (!c->pre_stream) {                                                   // (a context created with RR_OVERLAP_FILL=0 and switched on later)
@@ -299,13 +300,17 @@ hipStream_t pre_enter(tsdf_ctx* c) {
         hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess) { c->pipeline_blocked = true; return c->stream; }
   }
   if (c->main_since_gate) {                                               // the lane's first call of a new frame
-    if (c->pre_gate_recorded) hipStreamWaitEvent(c->pre_stream, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
+    // which stream: the lane ahead's own -- or, with the integrate lane in use, that one: a frame's preparation and its integrate() then
+    // follow each other without a cross-stream hand-over (15-35 us each on this machine) at the price of not
+    // overlapping the preparation of frame f + 2 with the integrate of frame f + 1
+    c->pre_lane = (c->pre_on_integ && deep_ok(c)) ? c->integ_stream : c->pre_stream;
+    if (c->pre_gate_recorded) hipStreamWaitEvent(c->pre_lane, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
     hipEventRecord(c->pre_gate, c->stream);
     c->pre_gate_recorded = true; c->main_since_gate = false;
     c->slot_flipped = c->counters_flipped = c->occ_flipped = false;
     c->counters_zeroed = c->occ_count_zeroed = false;
   }
-  return c->pre_stream;
+  return c->pre_lane;
 }
 hipError_t pre_leave(tsdf_ctx* c, hipStream_t lane) {
   if (lane != c->stream) c->pre_pending = true;                          // (the event is recorded once, when a consumer asks: every record costs the lane ~4 us)
@@ -316,7 +321,7 @@ hipError_t join_pre(tsdf_ctx* c) {
   c->slot_in_use = c->counters_in_use = c->occ_in_use = true;
   if (!c->pre_pending) return hipSuccess;
   c->pre_pending = false;
-  const hipError_t e = hipEventRecord(c->pre_done, c->pre_stream);
+  const hipError_t e = hipEventRecord(c->pre_done, c->pre_lane);
   return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->pre_done, 0);
 }
 // leave the pipelined mode for good (explicit frame-slot calls, the pre-processing path): drain the lanes, everything on the context's stream from now on
@@ -337,8 +342,9 @@ hipError_t join_integ(tsdf_ctx* c) {
   return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->integ_done, 0);
 }
 bool deep_ok(const tsdf_ctx* c) {
+  // (a Z-slab context too, when it recomputes its halo layers itself: an EXCHANGED halo is written into the volume from outside between integrate() and the draw)
   const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
-  return c->deep && !c->deep_failed && pipelined(c) && c->integ_stream && whole && !c->vol.slot && c->proj_budget == 0;
+  return c->deep && !c->deep_failed && pipelined(c) && c->integ_stream && (whole || c->cfg.slab_recompute_halo != 0) && !c->vol.slot && c->proj_budget == 0;
 }
 // exchange the set in use with the other one (host pointers only: kernels already queued keep the pointers they were launched with)
 void swap_volume_set(tsdf_ctx* c) {
@@ -617,6 +623,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   }
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
   if (const char* e = getenv("RR_OVERLAP_FILL")) c->overlap_fill = atoi(e) != 0;
+  if (const char* e = getenv("RR_PRE_ON_INTEG")) c->pre_on_integ = atoi(e) != 0;
   if (const char* e = getenv("RR_DEEP")) c->deep = atoi(e) != 0;          // A/B and test hook: integrate() on the context's stream, one volume
   {
     uint64_t mib = cfg->proj_cache_mib;                                   // 0: off (the default: measured slower than the LUT kernel)
@@ -1243,8 +1250,8 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
     c->slot_in_use = c->counters_in_use = c->occ_in_use = true;
     if (c->pre_pending) {
       c->pre_pending = false;
-      HIP_TRY(c, hipEventRecord(c->pre_done, c->pre_stream));
-      HIP_TRY(c, hipStreamWaitEvent(lane, c->pre_done, 0));
+      HIP_TRY(c, hipEventRecord(c->pre_done, c->pre_lane));
+      if (c->pre_lane != lane) HIP_TRY(c, hipStreamWaitEvent(lane, c->pre_done, 0));
       HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pre_done, 0));
     } else {
       HIP_TRY(c, hipEventRecord(c->integ_gate, c->stream));

@@ -138,6 +138,7 @@ struct tsdf_ctx {
   hipStream_t integ_stream = nullptr; hipEvent_t integ_done = nullptr, integ_gate = nullptr, draw_done[2] = {nullptr, nullptr};
   bool integ_pending = false, draw_pending[2] = {false, false}, draw_unrecorded = false, deep = true, deep_failed = false;
   int vol_set = 0;
+  hipStream_t pre_lane = nullptr; bool pre_on_integ = false;   // the stream the current frame's preparation runs on (pre_stream, or integ_stream: RR_PRE_ON_INTEG)
   bool overlap_fill = true;      // RR_OVERLAP_FILL=0 / tsdf_set_stage_overlap(ctx, 0): everything on the one stream, as in rounds 1 and 2
   // ... and a third lane AHEAD of the context's stream (round 3): what a new frame needs before integrate() can run -- its re-layout and the
   // brick passes (clear / mark / update) -- reads only the new frame and writes state nobody else writes, so it runs on `pre_stream` while

@@ -321,3 +321,30 @@ def test_fourth_lane_back_to_back_frames(rr, monkeypatch, use_bricks):
     (dc, dd), (oc, od) = deep.framebuffer(), orc.framebuffer()
     assert_same(dd, od, "framebuffer depth vs oracle"); assert_same(dc, oc, "framebuffer colour vs oracle")
     assert (od < 1).sum() > 500
+
+
+def test_frame_in_one_call_equals_the_separate_calls(rr):
+    """tsdf_frame_dev (upload_frame_dev + clear / mark / update + integrate + drawF in one call into the library) against the calls
+    one by one and against the oracle; tsdf_timer_spans puts the stages of those frames on one clock."""
+    import torch
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    scs = [rr.scene.make_scene(**mk), rr.scene.make_scene(**mk, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2))]
+    kw = dict(res=(96, 96, 96), brick_size=[2.0 / 12, 2.2 / 12, 2.0 / 12], limit=0.03, view=(320, 180))
+    mv, pr = rr.scene.default_view(*kw["view"])
+    one, sep, orc = rr.ReconIntegrationHip(scs[0], **kw), rr.ReconIntegrationHip(scs[0], **kw), OracleRecon(scs[0], **kw)
+    raw = [[torch.from_numpy(np.ascontiguousarray(sc[k])).cuda() for k in ("depth", "quality", "silhouette", "color")] for sc in scs]
+    torch.cuda.synchronize()
+    one.enable_timers(True)
+    for k in (0, 1, 1, 0, 1):
+        ptrs = [t.data_ptr() for t in raw[k]]
+        one.frame_dev(mv, pr, ptrs)
+        sep.upload_frame_dev(*ptrs, complete=True); frame_nosync(sep, mv, pr)
+    one.frame_dev(mv, pr)                                  # no new frame: the bricks, the volume and the picture again from the frame in place
+    frame_nosync(sep, mv, pr)
+    orc.upload_frame(scs[1]); frame(orc, mv, pr)
+    assert_same(one.tsdf(), sep.tsdf(), "volume, one call vs separate calls"); assert_same(one.tsdf(), orc.tsdf(), "volume vs oracle")
+    compare_images(one, orc, "one call")
+    (b0, e0), (b1, e1), (b2, e2) = one.timer_spans("0repack", "0repack"), one.timer_spans("2integrate", "0repack"), one.timer_spans("holefill", "0repack")
+    assert len(b0) == 5 and len(b1) == 6 and len(b2) == 6 and b0[0] == 0.0
+    assert (e0 > b0).all() and (e1 > b1).all() and (b1[:5] >= e0).all() and (b2 >= e1).all()      # re-layout -> integrate -> hole filling of a frame, in that order
+    assert (np.diff(b1) > 0).all()

@@ -35,6 +35,27 @@ int main() {
   unsigned long long* st; CK(hipMalloc(&st, R * 4 * sizeof(unsigned long long)));
   unsigned int* flag; CK(hipMalloc(&flag, 8)); CK(hipMemset(flag, 0, 8));
   std::vector<unsigned long long> h(R * 4);
+  // what a barrier packet costs a stream even when nothing has to be waited for: A ; [record | wait on a long-complete event | both] ; B on ONE stream
+  {
+    hipEvent_t done; CK(hipEventCreateWithFlags(&done, hipEventDisableTiming)); CK(hipEventRecord(done, s1)); CK(hipDeviceSynchronize());
+    const char* what[4] = {"nothing", "a record", "a satisfied wait", "a record and two satisfied waits"};
+    for (int v = 0; v < 4; ++v) {
+      CK(hipMemset(st, 0, R * 4 * sizeof(unsigned long long))); CK(hipDeviceSynchronize());
+      for (int r = 0; r < R; ++r) {
+        hipLaunchKernelGGL(k_work, dim3(2048), dim3(256), 0, s0, p, n, 600, st + r * 4);
+        if (v == 1 || v == 3) hipEventRecord(e, s0);
+        if (v == 2 || v == 3) hipStreamWaitEvent(s0, done, 0);
+        if (v == 3) hipStreamWaitEvent(s0, done, 0);
+        hipLaunchKernelGGL(k_work, dim3(2048), dim3(256), 0, s0, p, n, 600, st + r * 4 + 2);
+      }
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(h.data(), st, R * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      std::vector<double> gap;
+      for (int r = 20; r < R - 1; ++r) gap.push_back(((double)h[r * 4 + 2] - (double)h[r * 4 + 1]) / 100.0);
+      std::sort(gap.begin(), gap.end());
+      printf("one stream, %s between A and B: A end -> B begin median %.1f us (p10 %.1f, p90 %.1f)\n", what[v], gap[gap.size() / 2], gap[gap.size() / 10], gap[gap.size() * 9 / 10]);
+    }
+  }
   const char* names[3] = {"same stream", "event", "flag"};
   for (int mode = 0; mode < 3; ++mode) {
     for (int busy = 0; busy < 2; ++busy) {                       // busy: A' keeps s0 busy behind A (like a lane that runs on)
