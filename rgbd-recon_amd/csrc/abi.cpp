@@ -601,21 +601,21 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   c->device = cfg->device;
   auto fail = [&](int32_t code) { g_create_error = c->err; tsdf_destroy(c); return code; };
   if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(TSDF_ERR_HIP); }
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
+  // RR_LANE_PRIORITY (A/B hook): "pre,fill,integ,main" stream priorities: -1 = high, 0 = normal, 1 = low
+  int lo = 0, hi = 0, ppre = 1, pfill = 0, pinteg = 0, pmain = 0;          // default: the lane ahead below the others (its re-layout and brick marking are bandwidth / atomics work that otherwise takes the machine from the march: 115 against 120 us per c2 frame)
+  hipDeviceGetStreamPriorityRange(&lo, &hi);                             // (least, greatest): numerically greatest <= least
+  if (const char* e = getenv("RR_LANE_PRIORITY")) sscanf(e, "%d,%d,%d,%d", &ppre, &pfill, &pinteg, &pmain);
+  auto prio = [&](int rel) { return rel < 0 ? hi : (rel > 0 ? lo : (lo + hi) / 2); };
+  if (hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio(pmain)) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   c->stream = c->own_stream;
   // The three lanes of a context (stage overlap) are created together: the HIP runtime deals its hardware queues (4 by default,
   // GPU_MAX_HW_QUEUES) to streams in creation order, and two lanes that share a queue do not overlap at all
   if (getenv("RR_OVERLAP_FILL") == nullptr || atoi(getenv("RR_OVERLAP_FILL")) != 0) {
-    // RR_LANE_PRIORITY (A/B hook): "pre,fill" stream priorities relative to the context's stream: -1 = higher, 0 = equal, 1 = lower
-    int lo = 0, hi = 0, ppre = 0, pfill = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);                           // (least, greatest): numerically greatest <= least
-    if (const char* e = getenv("RR_LANE_PRIORITY")) sscanf(e, "%d,%d", &ppre, &pfill);
-    auto prio = [&](int rel) { return rel < 0 ? hi : (rel > 0 ? lo : (lo + hi) / 2); };
     const bool two_lanes = getenv("RR_LANES") && atoi(getenv("RR_LANES")) == 2;   // (A/B hook) the lane ahead and the fill lane share one stream
     if (hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, prio(ppre)) != hipSuccess ||
         (two_lanes ? (c->fill_stream = c->pre_stream, hipSuccess) : hipStreamCreateWithPriority(&c->fill_stream, hipStreamNonBlocking, prio(pfill))) != hipSuccess ||
         hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->integ_stream, hipStreamNonBlocking, prio(0)) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->integ_stream, hipStreamNonBlocking, prio(pinteg)) != hipSuccess ||
         hipEventCreateWithFlags(&c->draw_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->draw_done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->integ_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->integ_gate, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->fill_done[0], hipEventDisableTiming) != hipSuccess ||

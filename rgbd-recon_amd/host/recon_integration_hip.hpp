@@ -83,6 +83,15 @@ class ReconIntegrationHip {
   void uploadFrame(const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour_rgb) {
     check(tsdf_upload_frame(m_ctx, depth_rg, quality, silhouette, colour_rgb));
   }
+  // a frame that is already in device memory (a decoder / pre-process on the GPU): one re-layout launch, no copy
+  void uploadFrameDev(const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour_rgb, bool arrays_complete) {
+    check(tsdf_upload_frame_dev(m_ctx, depth_rg, quality, silhouette, colour_rgb, arrays_complete ? TSDF_FRAME_ARRAYS_COMPLETE : 0u));
+  }
+  // the client's per-frame sequence (kinect_client.cpp:586-599 update + draw: new frame -> clear / mark / update bricks -> integrate() -> drawF())
+  // in ONE call into the library: issuing a frame costs the host about as long as the GPU needs for it, every call boundary counts
+  void frameDev(const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour_rgb) {
+    check(tsdf_frame_dev(m_ctx, depth_rg, quality, silhouette, colour_rgb, TSDF_FRAME_ARRAYS_COMPLETE, m_mv, m_proj));
+  }
   void setMatrices(const float modelview[16], const float projection[16]) {
     std::memcpy(m_mv, modelview, sizeof(m_mv));
     std::memcpy(m_proj, projection, sizeof(m_proj));

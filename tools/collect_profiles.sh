@@ -5,12 +5,12 @@ TAG=$1; NAME=$2
 R=$(cd "$(dirname "$0")/.." && pwd)
 G=$R/gpurun_out/$TAG
 find_stats() { find $G/$1 -name '*kernel_stats.csv' | head -n 1; }
-# the kernel stats the roofline figures agree with: one stream (RR_OVERLAP_FILL=0); the three-lane run's stats beside them
+# the kernel stats the roofline figures agree with: one stream (RR_OVERLAP_FILL=0); the run with all lanes (as shipped) beside them
 cp $(find_stats c2_serial) $R/profiles/${NAME}_c2_kernel_stats.csv
-cp $(find_stats c2_lanes) $R/profiles/${NAME}_c2_three_lanes_kernel_stats.csv
+cp $(find_stats c2_lanes) $R/profiles/${NAME}_c2_all_lanes_kernel_stats.csv
 cp $(find_stats c1_serial) $R/profiles/${NAME}_c1_kernel_stats.csv
 cp $G/bench_stats_c2_serial.json $R/profiles/${NAME}_bench_c2_under_rocprof.json
-cp $G/bench_stats_c2_lanes.json $R/profiles/${NAME}_bench_c2_three_lanes_under_rocprof.json
+cp $G/bench_stats_c2_lanes.json $R/profiles/${NAME}_bench_c2_all_lanes_under_rocprof.json
 cp $G/bench_stats_c1_serial.json $R/profiles/${NAME}_bench_c1_under_rocprof.json
 for c in c2 c1; do
   for p in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do cp $G/pmc_${p}_$c.csv $R/profiles/${NAME}_pmc_${p}_$c.csv; done

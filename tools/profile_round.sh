@@ -2,7 +2,7 @@
 # tools/profile_round.sh TAG : on the GPU box -- kernel-trace stats + FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (separate runs) of
 # bench.py for c2 and c1, then the plain bench lines.  The --pmc passes are reduced to one row per (kernel, counter) by
 # tools/pmc_aggregate.py (the raw CSVs hold one row per launch, megabytes per pass).
-# Round 3: the kernel-trace stats are taken twice for c2 -- as shipped (three lanes: kernels stretched by their co-runners) and with
+# Round 3: the kernel-trace stats are taken twice for c2 -- as shipped (all lanes: kernels stretched by their co-runners) and with
 # RR_OVERLAP_FILL=0 (one stream: the kernel times bench.py's roofline uses); the counter passes run on one stream.
 set -e
 TAG=$1
