@@ -602,11 +602,16 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   auto fail = [&](int32_t code) { g_create_error = c->err; tsdf_destroy(c); return code; };
   if (hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(TSDF_ERR_HIP); }
   // RR_LANE_PRIORITY (A/B hook): "pre,fill,integ,main" stream priorities: -1 = high, 0 = normal, 1 = low
-  int lo = 0, hi = 0, ppre = 1, pfill = 0, pinteg = 0, pmain = 0;          // default: the lane ahead below the others (its re-layout and brick marking are bandwidth / atomics work that otherwise takes the machine from the march: 115 against 120 us per c2 frame)
+  // All normal by default.  The lane ahead BELOW the others ("1,0,0,0") is worth 4 % at c2 with one context (115 against 120 us per frame: its re-layout and
+  // brick marking otherwise take the machine from the march) -- but a low-priority stream changes how the runtime deals its hardware queues: three contexts
+  // in flight fall from 7 120 to 4 210 frames/s, and beside RCCL's kernels the lane starves (1 010 against 3 470 frames/s in the one-rank exchange rehearsal)
+  int lo = 0, hi = 0, ppre = 0, pfill = 0, pinteg = 0, pmain = 0;
   hipDeviceGetStreamPriorityRange(&lo, &hi);                             // (least, greatest): numerically greatest <= least
   if (const char* e = getenv("RR_LANE_PRIORITY")) sscanf(e, "%d,%d,%d,%d", &ppre, &pfill, &pinteg, &pmain);
   auto prio = [&](int rel) { return rel < 0 ? hi : (rel > 0 ? lo : (lo + hi) / 2); };
-  if (hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio(pmain)) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
+  // (the context's own stream: created WITHOUT a priority unless the hook asks for one -- streams created through the priority call are dealt
+  //  their hardware queues differently: several contexts' streams then share one, 4 250 instead of 7 080 frames/s with three contexts in flight)
+  if ((pmain != 0 ? hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio(pmain)) : hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   c->stream = c->own_stream;
   // The three lanes of a context (stage overlap) are created together: the HIP runtime deals its hardware queues (4 by default,
   // GPU_MAX_HW_QUEUES) to streams in creation order, and two lanes that share a queue do not overlap at all
