@@ -4,7 +4,11 @@
 // ViewLod::setResolution (framework/rendering/view_lod.cpp:24-50), the per-frame call order of
 // source/kinect_client.cpp:569-599,614.  All device work goes to one HIP stream.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -279,10 +283,66 @@ void timer_end(tsdf_ctx* c, const char* name) {
 void timer_begin_on(tsdf_ctx* c, const char* name, hipStream_t st) { hipStream_t keep = c->stream; c->stream = st; timer_begin(c, name); c->stream = keep; }
 void timer_end_on(tsdf_ctx* c, const char* name, hipStream_t st) { hipStream_t keep = c->stream; c->stream = st; timer_end(c, name); c->stream = keep; }
 
+// ---- the helper thread that issues the fill lane's calls (see tsdf_ctx::fill_worker)
+}  // namespace rrhost
+struct tsdf_ctx::FillWorker {
+  struct Job { Atlas atlas; const uint8_t* tile_mask; uint8_t* lvl_mask[2]; int vw, vh; float4* fb_c; float* fb_d; int mask_mode, keep; hipEvent_t wait_ev, done_ev; };
+  static constexpr uint64_t kRing = 16;
+  Job ring[kRing];
+  std::atomic<uint64_t> submitted{0}, issued{0};
+  std::atomic<bool> stop{false}, asleep{false};
+  std::atomic<int> hip_error{0};
+  std::mutex m; std::condition_variable cv;
+  int device = 0; hipStream_t stream = nullptr;
+  std::thread th;
+  static void relax() { __builtin_ia32_pause(); }
+  void run() {
+    (void)hipSetDevice(device);
+    uint64_t done = 0;
+    for (;;) {
+      int spins = 0;
+      while (submitted.load(std::memory_order_acquire) == done) {
+        if (stop.load()) return;
+        if (++spins < 20000) { relax(); continue; }                       // ~1 ms of spinning, then sleep until the next job is announced
+        std::unique_lock<std::mutex> lk(m);
+        asleep.store(true);
+        cv.wait_for(lk, std::chrono::milliseconds(10), [&] { return submitted.load() != done || stop.load(); });
+        asleep.store(false);
+        spins = 0;
+      }
+      const Job& j = ring[done % kRing];
+      hipError_t e = hipStreamWaitEvent(stream, j.wait_ev, 0);
+      rr::launch_inpaint_pyramid(stream, j.atlas, j.tile_mask, j.lvl_mask);
+      rr::launch_colorfill(stream, j.atlas, j.vw, j.vh, j.fb_c, j.fb_d, j.mask_mode, j.keep, j.tile_mask);
+      const hipError_t e2 = hipEventRecord(j.done_ev, stream), e3 = hipGetLastError();
+      if (e == hipSuccess) e = e2 != hipSuccess ? e2 : e3;
+      if (e != hipSuccess) hip_error.store((int)e);
+      ++done;
+      issued.store(done, std::memory_order_release);
+    }
+  }
+  uint64_t submit(const Job& j) {
+    const uint64_t n = submitted.load(std::memory_order_relaxed);
+    while (n - issued.load(std::memory_order_acquire) >= kRing) relax();
+    ring[n % kRing] = j;
+    submitted.store(n + 1);
+    if (asleep.load()) { { std::lock_guard<std::mutex> lk(m); } cv.notify_one(); }
+    return n + 1;
+  }
+  void wait_issued(uint64_t n) const { while (issued.load(std::memory_order_acquire) < n) relax(); }
+  void drain() const { wait_issued(submitted.load()); }
+};
+namespace rrhost {
+static hipError_t fill_worker_error(tsdf_ctx* c) {
+  if (!c->fill_worker) return hipSuccess;
+  const int e = c->fill_worker->hip_error.exchange(0);
+  return (hipError_t)e;
+}
 // stage overlap: GPU-side join (the context's stream waits for the hole filling that is still in flight) and host-side sync of both streams
 hipError_t join_fill_of(tsdf_ctx* c, int pyramid) {
   if (!c->fill_pending[pyramid]) return hipSuccess;
   c->fill_pending[pyramid] = false;
+  if (c->fill_worker) { c->fill_worker->wait_issued(c->fill_job_no[pyramid]); const hipError_t e = fill_worker_error(c); if (e != hipSuccess) return e; }   // (its record must have been issued before this wait is)
   return hipStreamWaitEvent(c->stream, c->fill_done[pyramid], 0);
 }
 hipError_t join_fill(tsdf_ctx* c) {
@@ -383,6 +443,7 @@ hipError_t sync_ctx(tsdf_ctx* c) {
   hipError_t e = hipStreamSynchronize(c->stream);
   if (c->integ_stream) { const hipError_t f = hipStreamSynchronize(c->integ_stream); if (e == hipSuccess) e = f; c->integ_pending = false; c->draw_pending[0] = c->draw_pending[1] = false; }
   if (c->pre_stream) { const hipError_t f = hipStreamSynchronize(c->pre_stream); if (e == hipSuccess) e = f; c->pre_pending = false; }
+  if (c->fill_worker) { c->fill_worker->drain(); const hipError_t f = fill_worker_error(c); if (e == hipSuccess) e = f; }
   if (c->fill_stream) { const hipError_t f = hipStreamSynchronize(c->fill_stream); if (e == hipSuccess) e = f; }
   c->fill_pending[0] = c->fill_pending[1] = false;
   return e;
@@ -628,6 +689,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   }
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
   if (const char* e = getenv("RR_OVERLAP_FILL")) c->overlap_fill = atoi(e) != 0;
+  if (const char* e = getenv("RR_FILL_THREAD")) c->fill_thread = atoi(e) != 0;
   if (const char* e = getenv("RR_PRE_ON_INTEG")) c->pre_on_integ = atoi(e) != 0;
   if (const char* e = getenv("RR_DEEP")) c->deep = atoi(e) != 0;          // A/B and test hook: integrate() on the context's stream, one volume
   {
@@ -701,6 +763,13 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   if (c->pre_done) hipEventDestroy(c->pre_done);
   if (c->pre_gate) hipEventDestroy(c->pre_gate);
   if (c->src_ready) hipEventDestroy(c->src_ready);
+  if (c->fill_worker) {
+    c->fill_worker->stop.store(true);
+    { std::lock_guard<std::mutex> lk(c->fill_worker->m); }
+    c->fill_worker->cv.notify_one();
+    if (c->fill_worker->th.joinable()) c->fill_worker->th.join();
+    delete c->fill_worker; c->fill_worker = nullptr;
+  }
   if (c->fill_stream) hipStreamDestroy(c->fill_stream);
   if (c->integ_stream) hipStreamDestroy(c->integ_stream);
   for (hipEvent_t e : {c->integ_done, c->integ_gate, c->draw_done[0], c->draw_done[1]}) if (e) hipEventDestroy(e);
@@ -1244,6 +1313,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   if (deep_ok(c) && ensure_alt_set(c, c->integ_stream)) {
     lane = c->integ_stream;
     if (c->draw_unrecorded) {                                            // a draw without hole filling behind it: mark its end now
+      if (c->fill_worker) c->fill_worker->wait_issued(c->draw_wait_job[c->vol_set]);
       HIP_TRY(c, hipEventRecord(c->draw_done[c->vol_set], c->stream));
       c->draw_pending[c->vol_set] = true; c->draw_unrecorded = false;
     }
@@ -1521,19 +1591,34 @@ static int32_t fill_colors_impl(tsdf_ctx* c, hipStream_t* used) {
       for (hipEvent_t& e : c->fill_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     for (hipEvent_t& e : c->draw_done) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (c->fill_worker) c->fill_worker->wait_issued(c->draw_wait_job[c->vol_set]);   // (a job that waits for the event's PREVIOUS record must have issued that wait)
     HIP_TRY(c, hipEventRecord(c->draw_done[c->vol_set], c->stream));      // everything the caller queued so far: the march / composite into level 0
     c->draw_pending[c->vol_set] = true; c->draw_unrecorded = false;
-    HIP_TRY(c, hipStreamWaitEvent(c->fill_stream, c->draw_done[c->vol_set], 0));
     fs = c->fill_stream;
   }
-  timer_begin_on(c, "holefill", fs);
   const bool by_tiles = c->fill_tiles && c->draw_masks_valid && c->fb_consistent && c->color_mask_mode == 0 && !c->keep_color;
   const uint8_t* tile_mask = by_tiles ? c->d_fill_mask[c->atlas_parity] : nullptr;
   ++c->n_fills; c->n_fills_by_tiles += by_tiles ? 1 : 0;
-  launch_inpaint_pyramid(fs, c->atlas, tile_mask, c->d_lvl_mask);
-  launch_colorfill(fs, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0, tile_mask);
   c->fb_consistent = c->color_mask_mode == 0 && !c->keep_color;         // the framebuffer is this pass's now: background wherever no tile was dirty
   c->draw_masks_valid = false;                                           // (consumed: a second fillColors() of the same draw, e.g. after a composite, goes through every tile)
+  if (c->overlap_fill && c->fill_thread && !c->timers_on) {              // the helper thread issues the lane's calls (tsdf_ctx::fill_worker)
+    if (!c->fill_worker) {
+      c->fill_worker = new tsdf_ctx::FillWorker();
+      c->fill_worker->device = c->device; c->fill_worker->stream = c->fill_stream;
+      c->fill_worker->th = std::thread([w = c->fill_worker] { w->run(); });
+    }
+    tsdf_ctx::FillWorker::Job j{c->atlas, tile_mask, {c->d_lvl_mask[0], c->d_lvl_mask[1]}, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0,
+                                c->draw_done[c->vol_set], c->fill_done[c->atlas_parity]};
+    c->fill_job_no[c->atlas_parity] = c->draw_wait_job[c->vol_set] = c->fill_worker->submit(j);
+    c->fill_pending[c->atlas_parity] = true;
+    if (used) *used = c->fill_stream;
+    return TSDF_OK;
+  }
+  if (c->fill_worker) { c->fill_worker->drain(); HIP_TRY(c, fill_worker_error(c)); }   // (earlier jobs first: the lane is in order)
+  if (c->overlap_fill) HIP_TRY(c, hipStreamWaitEvent(c->fill_stream, c->draw_done[c->vol_set], 0));
+  timer_begin_on(c, "holefill", fs);
+  launch_inpaint_pyramid(fs, c->atlas, tile_mask, c->d_lvl_mask);
+  launch_colorfill(fs, c->atlas, c->vw, c->vh, c->d_fb_c, c->d_fb_d, (int)c->color_mask_mode, c->keep_color ? 1 : 0, tile_mask);
   timer_end_on(c, "holefill", fs);
   if (c->overlap_fill) { HIP_TRY(c, hipEventRecord(c->fill_done[c->atlas_parity], fs)); c->fill_pending[c->atlas_parity] = true; }
   HIP_TRY(c, hipGetLastError());
@@ -1926,6 +2011,7 @@ int32_t tsdf_timer_end(tsdf_ctx* c, const char* name) { CHECK_CTX(c); if (!name)
 int32_t tsdf_timer_end_after_fill(tsdf_ctx* c, const char* name) {
   CHECK_CTX(c);
   if (!name) return TSDF_ERR_INVALID_ARGUMENT;
+  if (c->fill_worker) c->fill_worker->drain();
   timer_end_on(c, name, (c->fill_pending[0] || c->fill_pending[1]) ? c->fill_stream : c->stream);
   return TSDF_OK;
 }

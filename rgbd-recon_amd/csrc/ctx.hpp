@@ -125,6 +125,12 @@ struct tsdf_ctx {
   // passes and the integrate of frame f + 1 do not touch the pyramid or the framebuffer --, tied to the context's stream by two events:
   // draw_done (below: the fill waits for the march) and fill_done (the next writer / reader of the pyramid or the framebuffer waits for it).
   hipStream_t fill_stream = nullptr; hipEvent_t fill_done[2] = {nullptr, nullptr}; bool fill_pending[2] = {false, false};   // (per pyramid)
+  // The fill lane's calls are ISSUED by a helper thread (abi.cpp: FillWorker): issuing a c2 frame costs the calling thread ~100 us of HIP runtime
+  // calls -- as long as the device needs for the frame --, 28 of them for the hole filling's 6 launches and 2 event operations, and nothing the caller
+  // does next depends on them having been issued.  fillColors() records draw_done on the context's stream itself and hands the rest over as a job;
+  // whoever needs fill_done[p] first waits (host side, spinning) until the helper has issued that job's record.  Off while timers are on (their
+  // bookkeeping is the caller's thread's) and with RR_FILL_THREAD=0.
+  struct FillWorker; FillWorker* fill_worker = nullptr; uint64_t fill_job_no[2] = {0, 0}, draw_wait_job[2] = {0, 0}; bool fill_thread = true;
   // ... and a fourth lane (round 3): integrate() of frame f + 1 on `integ_stream` beside the draw of frame f on the context's stream.  Everything
   // integrate() writes and the draw reads -- the volume, its tile classes, the lists / stamps / counts of the incremental classification --
   // exists twice and alternates per integrate(): `alt` holds the set not in use (allocated on the first such integrate), and each set evolves

@@ -348,3 +348,43 @@ def test_frame_in_one_call_equals_the_separate_calls(rr):
     assert len(b0) == 5 and len(b1) == 6 and len(b2) == 6 and b0[0] == 0.0
     assert (e0 > b0).all() and (e1 > b1).all() and (b1[:5] >= e0).all() and (b2 >= e1).all()      # re-layout -> integrate -> hole filling of a frame, in that order
     assert (np.diff(b1) > 0).all()
+
+
+def test_fill_lane_issued_by_the_helper_thread(rr, monkeypatch):
+    """The hole filling's launches are issued by a helper thread of the context (not while timers are on: then the calling thread issues
+    them itself).  Frames queued back to back, switching between the two ways every few frames, reads and re-draws in between, against a
+    context without the thread (RR_FILL_THREAD=0) and the oracle; creating and destroying contexts with a live helper."""
+    import torch
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    scs = [rr.scene.make_scene(**mk), rr.scene.make_scene(**mk, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2)), rr.scene.make_scene(**mk, sphere_c=(-0.3, 1.3, 0.2))]
+    kw = dict(res=(96, 96, 96), brick_size=[2.0 / 12, 2.2 / 12, 2.0 / 12], limit=0.03, view=(320, 180))
+    pr = rr.scene.gl_flat(rr.scene.perspective(50.0, 16.0 / 9.0, 0.1, 200.0))
+    mvs = [rr.scene.gl_flat(rr.scene.look_at(e, (0.0, 1.1, 0.0))) for e in [(0.0, 1.1, 3.0), (1.6, 1.4, 2.4), (-2.2, 0.6, 1.2)]]
+    raw = [[torch.from_numpy(np.ascontiguousarray(sc[k])).cuda() for k in ("depth", "quality", "silhouette", "color")] for sc in scs]
+    torch.cuda.synchronize()
+    monkeypatch.setenv("RR_FILL_THREAD", "0")
+    plain = rr.ReconIntegrationHip(scs[0], **kw)
+    monkeypatch.setenv("RR_FILL_THREAD", "1")
+    thr, orc = rr.ReconIntegrationHip(scs[0], **kw), OracleRecon(scs[0], **kw)
+    k = 0
+    for rounds in range(6):
+        thr.enable_timers(rounds % 2 == 1)                 # odd rounds: the calling thread issues the lane's calls (behind the helper's pending jobs)
+        for _ in range(5):
+            ptrs = [t.data_ptr() for t in raw[k % 3]]
+            for o in (thr, plain):
+                o.frame_dev(mvs[k % 3], pr, ptrs)
+            if k % 4 == 3:                                 # a second draw of the same volume (two pyramids, one volume set), then a read right behind it
+                for o in (thr, plain):
+                    o.drawF(mvs[(k + 1) % 3], pr)
+                (tc, td), (pc, pd) = thr.framebuffer(), plain.framebuffer()
+                assert_same(td, pd, f"depth, frame {k}"); assert_same(tc, pc, f"colour, frame {k}")
+            k += 1
+    orc.upload_frame(scs[(k - 1) % 3]); frame(orc, mvs[(k - 1) % 3], pr)
+    assert_same(thr.tsdf(), orc.tsdf(), "volume vs oracle")
+    compare_images(thr, orc, "helper thread")
+    compare_images(plain, orc, "no helper thread")
+    for _ in range(3):                                     # contexts that come and go with a helper that has work behind it
+        t2 = rr.ReconIntegrationHip(scs[0], **kw)
+        for n in range(4):
+            t2.frame_dev(mvs[n % 3], pr, [t.data_ptr() for t in raw[n % 3]])
+        t2.close()
