@@ -56,8 +56,8 @@ int main() {
       printf("one stream, %s between A and B: A end -> B begin median %.1f us (p10 %.1f, p90 %.1f)\n", what[v], gap[gap.size() / 2], gap[gap.size() / 10], gap[gap.size() * 9 / 10]);
     }
   }
-  const char* names[3] = {"same stream", "event", "flag"};
-  for (int mode = 0; mode < 3; ++mode) {
+  const char* names[4] = {"same stream", "event", "flag", "flag + event"};   // flag + event: the event orders (always correct), the flag kernel only keeps the consumer's queue spinning until the event is complete
+  for (int mode = 0; mode < 4; ++mode) {
     for (int busy = 0; busy < 2; ++busy) {                       // busy: A' keeps s0 busy behind A (like a lane that runs on)
       CK(hipMemset(st, 0, R * 4 * sizeof(unsigned long long)));
       CK(hipDeviceSynchronize());
@@ -66,6 +66,12 @@ int main() {
         hipStream_t sb = mode == 0 ? s0 : s1;
         if (mode == 1) { hipEventRecord(e, s0); hipStreamWaitEvent(s1, e, 0); }
         if (mode == 2) { hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, s0, flag, (unsigned)(mode * 100000 + busy * 1000 + r + 1)); hipLaunchKernelGGL(k_wait, dim3(1), dim3(64), 0, s1, flag, (unsigned)(mode * 100000 + busy * 1000 + r + 1), flag + 1); }
+        if (mode == 3) {
+          hipEventRecord(e, s0);
+          hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, s0, flag, (unsigned)(mode * 100000 + busy * 1000 + r + 1));
+          hipLaunchKernelGGL(k_wait, dim3(1), dim3(64), 0, s1, flag, (unsigned)(mode * 100000 + busy * 1000 + r + 1), flag + 1);
+          hipStreamWaitEvent(s1, e, 0);
+        }
         if (busy) hipLaunchKernelGGL(k_work, dim3(2048), dim3(256), 0, s0, p, n, 600, st + R * 4 - 2);   // (stamps thrown away)
         hipLaunchKernelGGL(k_work, dim3(2048), dim3(256), 0, sb, p, n, 600, st + r * 4 + 2);
         if (mode != 0) { hipEventRecord(back, s1); hipStreamWaitEvent(s0, back, 0); }                    // next round's A behind this B
