@@ -681,7 +681,11 @@ def main():
             ms = dt / args.steps * 1e3
             out["roofline_frame"] = {"bound": "hbm", "bytes": fb, "stage_bytes": parts, "ms_per_step": ms, "achieved": fb / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "note": "sum of the stages' algorithmic bytes (SURVEY.md section 8d; culled launches by the units they process) / the timed step"}
+                                     "traffic": measured_traffic(args.config, "frame"), "traffic_if_streaming": measured_traffic(args.config, "frame", "hbm_bytes_if_streaming"),
+                                     "note": "sum of the stages' algorithmic bytes (SURVEY.md section 8d; culled launches by the units they process) / the timed step; "
+                                             "traffic = FETCH_SIZE + WRITE_SIZE summed over the frame's kernels (separate --pmc passes on one stream, profiles/traffic.json; "
+                                             "FETCH_SIZE counts half of a coalesced stream: traffic_if_streaming doubles it) -- below the algorithmic figure because the hole "
+                                             "filling keeps to the dirty screen tiles while the formula counts every pixel of every level"}
     if world > 1:
         # N > 1: the same object for the slowest slab launch (every rank that owns a slab measures its own; counters -- `traffic` -- were
         # only collected on one GPU).  Only culled integrate launches: the units are the slab's active tiles (halo layers it recomputes included)

@@ -32,6 +32,18 @@ def per_kernel(path, counter=None):
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in agg.items()}     # steady-state launches
 
 
+def per_frame(path):
+    """sum over the frame's kernels of (value per launch x launches per frame) from an aggregated pass (tools/pmc_aggregate.py: one row per kernel with its
+    launch count); a frame = one k_mark_bricks launch; set-up kernels (fewer launches than frames) are left out"""
+    rows = list(csv.DictReader(open(path)))
+    if not rows or "Launches" not in rows[0]:
+        return None
+    frames = max((int(r["Launches"]) for r in rows if "k_mark_bricks" in r["Kernel_Name"]), default=0)
+    if not frames:
+        return None
+    return sum(float(r["Counter_Value"]) * int(r["Launches"]) / frames for r in rows if r["Kernel_Name"].startswith(("rr::", "void rr::")) and int(r["Launches"]) >= frames // 2)
+
+
 def main():
     cfg, fetch, write = sys.argv[1:4]
     f, w = per_kernel(fetch), per_kernel(write)
@@ -43,6 +55,9 @@ def main():
         out[name] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb, "hbm_bytes_if_streaming": 2 * fb + wb}
         if v:
             out[name]["valu_insts"] = sum(x for k, x in v.items() if any(p in k for p in parts))
+    ff, wf = per_frame(fetch), per_frame(write)
+    if ff is not None and wf is not None:       # the whole frame (bench.py: roofline_frame.traffic); the re-layout kernel streams (FETCH_SIZE counts half of it), the rest gathers
+        out["frame"] = {"fetch_bytes": ff * 1024, "write_bytes": wf * 1024, "hbm_bytes": (ff + wf) * 1024, "hbm_bytes_if_streaming": (2 * ff + wf) * 1024}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[cfg] = out
