@@ -339,14 +339,27 @@ def test_frame_in_one_call_equals_the_separate_calls(rr):
         ptrs = [t.data_ptr() for t in raw[k]]
         one.frame_dev(mv, pr, ptrs)
         sep.upload_frame_dev(*ptrs, complete=True); frame_nosync(sep, mv, pr)
+    for a_, b_ in zip(one.bricks(), sep.bricks()):
+        assert_same(a_, b_, "brick counters / flags, one call vs separate calls")
+    # the two ways mixed on ONE context
+    for n, k in enumerate((1, 0, 0, 1, 0, 1, 1)):
+        ptrs = [t.data_ptr() for t in raw[k]]
+        if n in (1, 2, 5):
+            one.upload_frame_dev(*ptrs, complete=True); frame_nosync(one, mv, pr)
+        else:
+            one.frame_dev(mv, pr, ptrs)
+        sep.upload_frame_dev(*ptrs, complete=True); frame_nosync(sep, mv, pr)
+        if n in (2, 4, 6):
+            for a_, b_ in zip(one.bricks(), sep.bricks()):
+                assert_same(a_, b_, f"brick counters / flags, mixed calls, frame {n}")
     one.frame_dev(mv, pr)                                  # no new frame: the bricks, the volume and the picture again from the frame in place
     frame_nosync(sep, mv, pr)
     orc.upload_frame(scs[1]); frame(orc, mv, pr)
     assert_same(one.tsdf(), sep.tsdf(), "volume, one call vs separate calls"); assert_same(one.tsdf(), orc.tsdf(), "volume vs oracle")
     compare_images(one, orc, "one call")
     (b0, e0), (b1, e1), (b2, e2) = one.timer_spans("0repack", "0repack"), one.timer_spans("2integrate", "0repack"), one.timer_spans("holefill", "0repack")
-    assert len(b0) == 5 and len(b1) == 6 and len(b2) == 6 and b0[0] == 0.0
-    assert (e0 > b0).all() and (e1 > b1).all() and (b1[:5] >= e0).all() and (b2 >= e1).all()      # re-layout -> integrate -> hole filling of a frame, in that order
+    assert len(b0) == 12 and len(b1) == 13 and len(b2) == 13 and b0[0] == 0.0
+    assert (e0 > b0).all() and (e1 > b1).all() and (b1[:12] >= e0).all() and (b2 >= e1).all()      # re-layout -> integrate -> hole filling of a frame, in that order
     assert (np.diff(b1) > 0).all()
 
 
