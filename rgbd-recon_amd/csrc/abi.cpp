@@ -75,7 +75,7 @@ Mat4 to_mat4(const double* d) { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (f
 void release_view(tsdf_ctx* c) {
   for (int k = 0; k < 2; ++k) { hipFree(c->atlas_color[k]); hipFree(c->atlas_depth[k]); c->atlas_color[k] = nullptr; c->atlas_depth[k] = nullptr; }
   c->atlas_parity = 0;
-  hipFree(c->d_peels); hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
+  hipFree(c->d_peels); hipFree(c->d_peels_alt); c->d_peels_alt = nullptr; c->last_alt_peels = false; hipFree(c->d_nsamples); hipFree(c->d_fb_c); hipFree(c->d_fb_d);
   hipFree(c->d_long); c->d_long = nullptr;
   hipFree(c->d_tri_z); hipFree(c->d_tri_acc); c->d_tri_z = nullptr; c->d_tri_acc = nullptr;
   for (int k = 0; k < 3; ++k) { hipFree(c->d_touched[k]); c->d_touched[k] = nullptr; }
@@ -118,6 +118,7 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   HIP_TRY(c, hipMalloc(&A.depth, na * sizeof(float)));
   c->atlas_color[0] = A.color; c->atlas_depth[0] = A.depth; c->atlas_parity = 0;    // (the second pyramid: on the first overlapped draw)
   HIP_TRY(c, hipMalloc(&c->d_peels, nv * sizeof(float4)));
+  HIP_TRY(c, hipMalloc(&c->d_peels_alt, nv * sizeof(float4)));
   HIP_TRY(c, hipMalloc(&c->d_nsamples, nv * sizeof(float)));
   HIP_TRY(c, hipMalloc(&c->d_fb_c, nv * sizeof(float4)));
   HIP_TRY(c, hipMalloc(&c->d_fb_d, nv * sizeof(float)));
@@ -141,6 +142,7 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   launch_clear_image(c->stream, A.color, A.depth, na, make_float4(0.0f, 1.0f, 0.0f, 0.0f), 1.0f);
   launch_clear_image(c->stream, c->d_fb_c, c->d_fb_d, nv, make_float4(0, 0, 0, 0), 1.0f);
   HIP_TRY(c, hipMemsetAsync(c->d_peels, 0, nv * sizeof(float4), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_peels_alt, 0, nv * sizeof(float4), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_nsamples, 0, nv * sizeof(float), c->stream));
   return TSDF_OK;
 }
@@ -1257,7 +1259,15 @@ int32_t tsdf_mark_bricks(tsdf_ctx* c) {
     zero_word = c->d_occ_counts + ((!c->occ_flipped && c->occ_in_use) ? alt_of(c->occ_parity) : c->occ_parity);
     c->occ_count_zeroed = true;
   }
-  launch_mark_bricks(lane, c->luts, c->frame, c->br, zero_word);
+  // the peel tiles the coming draw would reset first -- those the draw before the previous one touched, in the peel image that draw used (two alternate
+  // while the lanes are on) --: reset here, on the lane ahead, beside the previous frame's kernels
+  PeelClear pc{};
+  if (lane != c->stream && c->use_bricks && c->skip_space && c->use_tile_history && c->tile_history && c->last_alt_peels && c->d_peels_alt) {
+    pc.peels = (uint4*)c->d_peels_alt; pc.touched_prev = c->d_touched[(c->touched_idx + 1) % 3];
+    pc.w = c->vw; pc.h = c->vh; pc.ntx = (c->vw + 7) / 8; pc.n_tiles = pc.ntx * ((c->vh + 7) / 8);
+    c->peels_cleared = true;
+  }
+  launch_mark_bricks(lane, c->luts, c->frame, c->br, zero_word, pc.peels ? &pc : nullptr);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
@@ -1355,7 +1365,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   PeelClear pc{};
   {
     const bool whole = (c->vol.own_tz0 == 0 && c->vol.own_tz1 == (c->res[2] + 7) / 8);
-    if (!deep && c->use_bricks && !c->full_classify && c->skip_space && whole && c->use_tile_history && c->tile_history && c->d_peels) {   // (the fourth lane runs beside the previous draw, which reads the peels)
+    if (!deep && !pipelined(c) && c->use_bricks && !c->full_classify && c->skip_space && whole && c->use_tile_history && c->tile_history && !c->last_alt_peels && c->d_peels) {   // (with the lanes on the reset rides on the lane ahead: tsdf_mark_bricks)
       pc.peels = (uint4*)c->d_peels; pc.touched_prev = c->d_touched[(c->touched_idx + 2) % 3];     // the previous draw's tiles
       pc.w = c->vw; pc.h = c->vh; pc.ntx = (c->vw + 7) / 8; pc.n_tiles = pc.ntx * ((c->vh + 7) / 8);
       c->peels_cleared = true;
@@ -1441,12 +1451,19 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   const bool use_tiles = P.skip && c->use_tile_history && !shifted && !masked_direct(c);
   if (P.skip) {
     timer_begin(c, "brickdraw");
+    // two peel images alternate per tiled draw while the lanes are on (tsdf_ctx::d_peels_alt); a change of that mode starts a new tile history
+    const bool alt_peels = use_tiles && pipelined(c) && c->d_peels_alt;
+    if (alt_peels != c->last_alt_peels) c->tile_history = false;
     if (use_tiles && !c->tile_history) {
       const size_t n_img_tiles = (size_t)((c->vw + 7) / 8) * ((c->vh + 7) / 8);
       for (int k = 0; k < 3; ++k) HIP_TRY(c, hipMemsetAsync(c->d_touched[k], 0, n_img_tiles, c->stream));
+      if (alt_peels) launch_clear_peels(c->stream, c->d_peels_alt, c->vw * c->vh);   // (the other image: all clear, like the one this draw resets in full)
+      c->peels_cleared = false;
     }
+    if (alt_peels && c->tile_history) std::swap(c->d_peels, c->d_peels_alt);          // the image of the draw before the previous one: its tiles are in the oldest mask
+    c->last_alt_peels = alt_peels;
     launch_depth_limits(c->stream, P, c->br, c->d_peels, use_tiles ? c->d_touched[c->touched_idx] : nullptr,
-                        use_tiles && c->tile_history ? c->d_touched[(c->touched_idx + 2) % 3] : nullptr, use_tiles && c->tile_history && c->peels_cleared ? 1 : 0);
+                        use_tiles && c->tile_history ? c->d_touched[(c->touched_idx + (alt_peels ? 1 : 2)) % 3] : nullptr, use_tiles && c->tile_history && c->peels_cleared ? 1 : 0);
     timer_end(c, "brickdraw");
   }
   c->peels_cleared = false;                                              // consumed (or void: this draw did its own reset)

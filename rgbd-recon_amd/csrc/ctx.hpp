@@ -88,6 +88,10 @@ struct tsdf_ctx {
   int vw = 0, vh = 0;
   Atlas atlas{};
   float4* d_peels = nullptr; float* d_nsamples = nullptr;
+  // While the lanes are on, TWO peel images alternate per (tiled) draw: the one the coming draw uses was last written two draws ago, so its touched tiles can
+  // be reset on the lane ahead (a block range of the brick marking launch, k_mark_bricks) instead of by a launch of its own on the context's stream --
+  // 12 + 6 us of the lane that bounds the frame.  d_peels is the latest draw's (what tsdf_download_image returns)
+  float4* d_peels_alt = nullptr; bool last_alt_peels = false;
   void* d_hits = nullptr; uint32_t* d_hit_counters = nullptr; int hit_parity = 0;
   // image-space dirty tiles (k_raymarch.hip): three masks in rotation -- d_touched[touched_idx] is the coming draw's, (idx + 2) % 3 the
   // previous draw's (peels, sample counts), (idx + 1) % 3 the one before (the other pyramid when two alternate; recycled by the march).

@@ -112,8 +112,17 @@ void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n) {
 }
 
 // One thread per depth pixel and stream (pre_normal.fs:22-33 runs per fragment of every layer).
-__global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages F, Bricks B, uint32_t* __restrict__ zero_word) {
+__global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages F, Bricks B, uint32_t* __restrict__ zero_word, PeelClear PC) {
   if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *zero_word = 0u;   // the count the coming updateOccupiedBricks() adds to
+  if ((int)blockIdx.z == T.n) {                                           // ---- (optional) one more layer of blocks: the peel tiles the coming draw would reset (k_clear_peel_tiles, k_raymarch.hip)
+    const int lane = threadIdx.x & 63, nb = (int)(gridDim.x * gridDim.y);
+    for (int t = ((int)(blockIdx.y * gridDim.x + blockIdx.x)) * 4 + (int)(threadIdx.x >> 6); t < PC.n_tiles; t += nb * 4) {
+      if (!PC.touched_prev[t]) continue;
+      const int px = (t % PC.ntx) * 8 + (lane & 7), py = (t / PC.ntx) * 8 + (lane >> 3);
+      if (px < PC.w && py < PC.h) PC.peels[(size_t)py * PC.w + px] = make_uint4(__float_as_uint(1.0f), 0u, __float_as_uint(1.0f), 0u);   // clear (1,0,1,0)
+    }
+    return;
+  }
   const int px = blockIdx.x * 64 + (threadIdx.x & 63);
   const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int layer = blockIdx.z;
@@ -132,9 +141,9 @@ __global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages 
   wave_count(B.counters, id_nbr, nbr);
   wave_count(B.counters, id_own, own);
 }
-void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B, uint32_t* zero_word) {
-  dim3 grid((F.w + 63) / 64, (F.h + 3) / 4, T.n);
-  hipLaunchKernelGGL(k_mark_bricks, grid, dim3(256), 0, st, T, F, B, zero_word);
+void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B, uint32_t* zero_word, const PeelClear* pc) {
+  dim3 grid((F.w + 63) / 64, (F.h + 3) / 4, T.n + (pc ? 1 : 0));
+  hipLaunchKernelGGL(k_mark_bricks, grid, dim3(256), 0, st, T, F, B, zero_word, pc ? *pc : PeelClear{});
 }
 
 // flags[b] = counter[b] >= min_voxels, the compacted occupied list and its length (one atomic per wave)

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64) void k_depth_limits(ViewParams P, Bricks B, uin
     }
   }
 }
+void launch_clear_peels(hipStream_t st, float4* peels, int n) { hipLaunchKernelGGL(k_clear_peels, dim3((n + 255) / 256), dim3(256), 0, st, (uint4*)peels, n); }
 void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels, uint8_t* touched_cur, const uint8_t* touched_prev, int already_cleared) {
   const int n = P.w * P.h, ntx = (P.w + 7) / 8, n_tiles = ntx * ((P.h + 7) / 8);
   // touched_prev == nullptr: no tile history (first frame, resized view, ...): reset every peel

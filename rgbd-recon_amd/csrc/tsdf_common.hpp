@@ -214,7 +214,8 @@ void launch_pack_frame_fused(hipStream_t st, const float* depth_rg, const float*
                              int n_streams, int w, int h, const uint8_t* rgb, uchar4* rgba, size_t n_color_px,
                              uint32_t* zero = nullptr, uint32_t zero_words = 0);   // zero: a word buffer (multiple of 4 words) the launch clears as well (the coming frame's brick counters)
 void launch_fill_u32(hipStream_t st, uint32_t* p, uint32_t v, size_t n);
-void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B, uint32_t* zero_word = nullptr);   // zero_word: a device word the launch clears as well
+struct PeelClear;
+void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B, uint32_t* zero_word = nullptr, const PeelClear* pc = nullptr);   // zero_word: a device word the launch clears as well; pc: peel tiles to reset (one more layer of blocks)
 void launch_update_occupied(hipStream_t st, const Bricks& B, uint32_t min_voxels, uint32_t* next_count);
 // full_classify: 1 = walk every tile (first frame, after anything that may have left non-clear data outside the previous active
 // list); 0 = scatter from the occupied bricks + check the previous list only (work follows the scene, not the volume)
@@ -234,6 +235,7 @@ int integrate_row_cap();
 void launch_mark_all_mixed(hipStream_t st, const TileState& S);
 void launch_volume_to_linear(hipStream_t st, const Volume& V, float* linear);
 void launch_volume_from_linear(hipStream_t st, const Volume& V, const float* linear);
+void launch_clear_peels(hipStream_t st, float4* peels, int n);   // every peel to the clear value (1,0,1,0)
 void launch_depth_limits(hipStream_t st, const ViewParams& P, const Bricks& B, float4* peels, uint8_t* touched_cur = nullptr, const uint8_t* touched_prev = nullptr,
                          int already_cleared = 0);
 struct LongRay { uint32_t pix, n, max_n; float prev; float x, y, z, pad; };   // state of a ray handed to k_march_long
