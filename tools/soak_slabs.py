@@ -24,7 +24,16 @@ scene_b = rr.scene.make_scene(sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2),
 ext = scene["bbox_max"] - scene["bbox_min"]
 hip = rr.ReconIntegrationHip(scene, res=(RES,) * 3, brick_size=[float(ext[a]) / RES * 8 for a in range(3)], limit=0.01, view=VIEW,
                              slab=mg.worker_slab_range(RES, rank, world), recompute_halo=True)
-hip.select_frame_slot(1); hip.upload_frame(scene_b); hip.select_frame_slot(0)
+# round 3: every frame ARRIVES (device arrays -> tsdf_upload_frame_dev on the ranks that own a slab), so each worker's lanes -- lane ahead, integrate lane on two
+# volume sets of the slab, the context's stream -- and the compositor's fill lane run against each other for the whole soak; SOAK_SLOTS=1: round 2's flow
+# (two resident frames, explicit frame slots: one stream)
+SLOTS = os.environ.get("SOAK_SLOTS") == "1"
+if SLOTS:
+    hip.select_frame_slot(1); hip.upload_frame(scene_b); hip.select_frame_slot(0)
+else:
+    raw = [[torch.from_numpy(np.ascontiguousarray(sc[k])).cuda() for k in ("depth", "quality", "silhouette", "color")] for sc in (scene, scene_b)]
+    ptr = [[t.data_ptr() for t in r] for r in raw]
+    torch.cuda.synchronize()
 drv = mg.SlabDriver(hip, rank, world, "cuda:0", view=VIEW, halo="recompute", composite="compact", compositor="dedicated")
 views = [rr.scene.default_view(*VIEW), (rr.scene.gl_flat(rr.scene.look_at((1.6, 1.4, 2.4), (0.0, 1.1, 0.0))), rr.scene.default_view(*VIEW)[1])]
 
@@ -38,10 +47,13 @@ def digest():
 
 first, bad, t0 = {}, 0, time.time()
 for f in range(N):
-    kind = (f & 1, (f >> 1) & 1)                          # (frame slot, view)
-    hip.select_frame_slot(kind[0])
-    drv.frame(*views[kind[1]])
-    if f % CHECK < 4 or f == N - 1:                        # four consecutive frames = all four kinds
+    kind = ((f >> 1) & 1, (f >> 2) & 1)                   # (frame, view): A A B B ... so that each of a worker's two volume sets sees both frames
+    if SLOTS:
+        hip.select_frame_slot(kind[0])
+        drv.frame(*views[kind[1]])
+    else:
+        drv.frame(*views[kind[1]], new_frame=ptr[kind[0]])
+    if f % CHECK < 8 or f == N - 1:                        # eight consecutive frames = all four kinds, on either volume set
         drv.finish()
         if rank == 0:
             d = digest()
