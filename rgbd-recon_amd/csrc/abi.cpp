@@ -1922,6 +1922,7 @@ int32_t tsdf_halo_pack_dev(tsdf_ctx* c, void* lo, void* hi) {
   CHECK_CTX(c);
   if (c->vol.slot) FAIL(c, TSDF_ERR_STATE, "halo exchange is not available with a sparse tile pool (use slab_recompute_halo)");
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, join_integ(c));                                             // (the volume: behind an integrate() in flight on the integrate lane)
   const Volume& V = c->vol;
   const size_t layer = (size_t)V.nty * V.ntx * TILE_VOX, n = (size_t)c->halo_layers * layer * sizeof(float);
   if (lo) HIP_TRY(c, hipMemcpyAsync(lo, V.data + (size_t)(V.own_tz0 - V.tz0) * layer, n, hipMemcpyDeviceToDevice, c->stream));
@@ -1932,6 +1933,7 @@ int32_t tsdf_halo_unpack_dev(tsdf_ctx* c, const void* below, const void* above) 
   CHECK_CTX(c);
   if (c->vol.slot) FAIL(c, TSDF_ERR_STATE, "halo exchange is not available with a sparse tile pool (use slab_recompute_halo)");
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, join_integ(c));
   const Volume& V = c->vol;
   const size_t layer = (size_t)V.nty * V.ntx * TILE_VOX;
   if (below && V.tz0 < V.own_tz0) {
