@@ -842,7 +842,12 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
   }
   if (phase == 3) return;
   if (use_bricks) {
-    const dim3 grid(S.n < 4096 ? S.n : 4096);
+    // Workgroups of the culled launch (they stride over the work list).  2048 = the 8 x 256 a MI355X holds at once: beside the other lanes' kernels (stage overlap)
+    // a c2 frame takes 112 - 113 us with it against 119 with 4096 (the launch alone 43.9 against 42.9 us: queued workgroups of this kernel no longer take the slots
+    // a co-runner's workgroups wait for), c3 the same either way; the 25 000-tile launch of a 1024^3 volume wants the larger grid (c4: 2 834 against 2 551 frames/s).
+    static const int forced = [] { const char* e = getenv("RR_K1_GRID"); return e ? atoi(e) : 0; }();                  // A/B hook
+    const int cap = forced > 0 ? forced : (S.n <= 262144 ? 2048 : 4096);
+    const dim3 grid(S.n < cap ? S.n : cap);
     if (cached) {
       hipLaunchKernelGGL((k_integrate_cached<true, RR_K1C_CHUNK>), dim3(RR_K1C_GRID), dim3(64), 0, st, T.n, F, V, B, S, pvc, S.count, S.list, pair_masks, PC.items, PC);
       hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
