@@ -272,8 +272,9 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 // voxel takes the same branch of the fusion rule -- the tile projects onto background pixels (silhouette 0 and no depth: "carve if
 // untouched"), or lies wholly in front of the measured surface (-limit), or wholly behind it (nothing) -- and the per-voxel image
 // gather only confirms it.  That can be PROVEN per tile and stream from bounds, without touching a voxel:
-//   * the trilinear filter returns a convex combination of the texels of the tile's LUT box, so (u, v, z) of every voxel lies within the
-//     per-component min / max over the box (plus a rounding slack: three nested fp32 lerps are within a few ulps of the exact value);
+//   * (u, v, z) of a voxel depends on the calibration volume and the voxel grid only, so its min / max over the tile's 512 voxels is a static
+//     table (k_tile_bounds evaluates the very expression the integrate kernels evaluate; the rounding slack added on top of it dates from
+//     rounds 2 / 3, when the table held the hull of the tile's LUT texel box, and is kept: it costs nothing);
 //   * the image taps of all voxels then lie in one pixel rectangle, and k_frame_ranges (k_bricks.hip) holds min / max of depth and
 //     silhouette per 8x8-pixel cell: a silhouette range of exactly {0} (or {1}) makes every bilinear silhouette exactly 0 (or 1), and a
 //     depth range bounds sdist = z - depth for every voxel, nearest texel included.
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_integrate_tiles(StreamTable T, FrameIma
 // The classes of a launch are worked out by a pass of its own (k_pair_masks, below) and read by the integrate kernels with one scalar
 // load per work item.
 constexpr int kPairFull = 0, kPairCarve = 1, kPairNeg = 2, kPairNop = 3;
-// Per (tile, stream) the (u, v, z) range over the tile's LUT texel box -- static: it depends on the calibration volume and the voxel
+// Per (tile, stream) the (u, v, z) range over the tile's voxels -- static: it depends on the calibration volume and the voxel
 // grid only -- is computed once (k_tile_bounds, below) as two float4 {u0, u1, v0, v1}, {z0, z1, -, -}; NaN marks a box with a
 // non-finite or far-away texel.  The class of (tile, stream) for THIS frame is worked out by a half wave (two streams per call, up to
 // 32 range cells each: a lane loads one cell of the rectangle, DPP row shifts and one row broadcast reduce them).
@@ -330,7 +331,11 @@ __device__ __forceinline__ int pair_class(const PairCell& c, float limit) {
   if (sil1 && all_ge) return kPairNop;                                 // behind the surface: nothing
   return kPairFull;
 }
-// the static half: one wave per (stored tile, stream) reduces min / max of (u, v, z) over the tile's LUT texel box
+// the static half: one wave per (stored tile, stream) reduces min / max of (u, v, z) = texture(cv_xyz_inv[i], voxel centre).xyz over the tile's 512
+// voxels -- the very values the integrate kernels compute (same coordinates, same taps, same x -> y -> z lerps: tex3d_rgba_xyz), so the bounds are
+// tight (round 4).  Rounds 2 / 3 took the hull of the tile's LUT texel box instead: up to 1.5 x wider per axis at a 4:1 LUT, which left fewer uniform
+// pairs (the dense c1 launch 118.5 -> 104.2 us with the tight bounds, c2 43.8 -> 42.5, c4 194.5 -> 188.0: profiles/r04_k1_rect_negative.txt, A/B 3).
+// Built once per calibration (8 trilinear fetches per lane and stream; c2: 1 M wave-items).
 __global__ __launch_bounds__(256) void k_tile_bounds(StreamTable T, Volume V, float4* __restrict__ bounds, int n_tiles) {
   const int ln = threadIdx.x & 63;
   const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -338,21 +343,15 @@ __global__ __launch_bounds__(256) void k_tile_bounds(StreamTable T, Volume V, fl
   const int tile = (int)(item / T.n), i = (int)(item % T.n);
   const int t3[3] = {tile % V.ntx, (tile / V.ntx) % V.nty, V.tz0 + tile / (V.ntx * V.nty)};
   const StreamLut& L = T.s[i];
-  int m[3], d[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {                                         // the same index arithmetic as phase A of the integrate kernels
-    const float step = 1.0f / (float)V.res[a];
-    const Axis lo = axis_linear(((float)min(t3[a] * 8, V.res[a] - 1) + 0.5f) * step, L.inv_res[a]);
-    const Axis hi = axis_linear(((float)min(t3[a] * 8 + 7, V.res[a] - 1) + 0.5f) * step, L.inv_res[a]);
-    m[a] = lo.i0; d[a] = hi.i1 - lo.i0 + 1;
-  }
+  const float sx = 1.0f / (float)V.res[0], sy = 1.0f / (float)V.res[1], sz = 1.0f / (float)V.res[2];   // volume_sampler.cpp:36-38
+  // padding voxels reuse the last real coordinate, as in phase A of the integrate kernels
+  const float px = ((float)min(t3[0] * 8 + (ln & 7), V.res[0] - 1) + 0.5f) * sx, py = ((float)min(t3[1] * 8 + (ln >> 3), V.res[1] - 1) + 0.5f) * sy;
   const float inf = __builtin_inff();
   float u0 = inf, u1 = -inf, v0 = inf, v1 = -inf, z0 = inf, z1 = -inf;
   bool bad = false;
-  const int n = d[0] * d[1] * d[2];
-  for (int e = ln; e < n; e += 64) {
-    const int bx = e % d[0], by = (e / d[0]) % d[1], bz = e / (d[0] * d[1]);
-    const float4 t = L.inv[(uint32_t)__mul24(__mul24(m[2] + bz, L.inv_res[1]) + (m[1] + by), L.inv_res[0]) + (uint32_t)(m[0] + bx)];
+  for (int kz = 0; kz < 8; ++kz) {
+    const float pz = ((float)min(t3[2] * 8 + kz, V.res[2] - 1) + 0.5f) * sz;
+    const float3 t = tex3d_rgba_xyz(L.inv, L.inv_res, px, py, pz);
     bad |= !(fabsf(t.x) < 1.0e4f && fabsf(t.y) < 1.0e4f && fabsf(t.z) < 1.0e4f);        // NaN, infinities, far-away garbage
     u0 = fminf(u0, t.x); u1 = fmaxf(u1, t.x); v0 = fminf(v0, t.y); v1 = fmaxf(v1, t.y); z0 = fminf(z0, t.z); z1 = fmaxf(z1, t.z);
   }
