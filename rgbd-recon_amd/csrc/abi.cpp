@@ -674,16 +674,39 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   auto prio = [&](int rel) { return rel < 0 ? hi : (rel > 0 ? lo : (lo + hi) / 2); };
   // (the context's own stream: created WITHOUT a priority unless the hook asks for one -- streams created through the priority call are dealt
   //  their hardware queues differently: several contexts' streams then share one, 4 250 instead of 7 080 frames/s with three contexts in flight)
-  if ((pmain != 0 ? hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio(pmain)) : hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
+  // Space sharing of the lanes (round 4): RR_LANE_XCDS = "pre,fill,integ,main", each a hex mask of the XCDs (bit x = XCD x) the lane's stream may run on
+  // (0 / absent = all), or RR_LANE_CUS = "a-b,a-b,a-b,a-b": the CU slots [a, b] of EVERY XCD (0 - 31).  Bit i of a HIP CU mask is CU slot i / 8 of XCD i % 8
+  // on this part (tools/probes/cumask_probe.hip).
+  uint32_t lane_mask[4][8]; bool lane_masked[4] = {false, false, false, false};
+  {
+    unsigned xm[4] = {0, 0, 0, 0}; int lo4[4] = {0, 0, 0, 0}, hi4[4] = {31, 31, 31, 31};
+    const char* ex = getenv("RR_LANE_XCDS"); const char* ec = getenv("RR_LANE_CUS");
+    if (ex) sscanf(ex, "%x,%x,%x,%x", &xm[0], &xm[1], &xm[2], &xm[3]);
+    if (ec) sscanf(ec, "%d-%d,%d-%d,%d-%d,%d-%d", &lo4[0], &hi4[0], &lo4[1], &hi4[1], &lo4[2], &hi4[2], &lo4[3], &hi4[3]);
+    for (int l = 0; l < 4; ++l) {
+      lane_masked[l] = (ex && (xm[l] & 0xffu) != 0u && (xm[l] & 0xffu) != 0xffu) || (ec && (lo4[l] > 0 || hi4[l] < 31));
+      for (int k = 0; k < 8; ++k) lane_mask[l][k] = 0u;
+      for (int i = 0; i < 256; ++i) {
+        const int xcd = i & 7, cu = i >> 3;
+        const bool on = (!ex || (xm[l] & 0xffu) == 0u || ((xm[l] >> xcd) & 1u)) && cu >= lo4[l] && cu <= hi4[l];
+        if (on) lane_mask[l][i >> 5] |= 1u << (i & 31);
+      }
+    }
+  }
+  auto make_stream = [&](hipStream_t* st, int lane, int rel, bool with_priority) -> hipError_t {
+    if (lane_masked[lane]) return hipExtStreamCreateWithCUMask(st, 8, lane_mask[lane]);
+    return with_priority ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio(rel)) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  };
+  if (make_stream(&c->own_stream, 3, pmain, pmain != 0) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   c->stream = c->own_stream;
   // The three lanes of a context (stage overlap) are created together: the HIP runtime deals its hardware queues (4 by default,
   // GPU_MAX_HW_QUEUES) to streams in creation order, and two lanes that share a queue do not overlap at all
   if (getenv("RR_OVERLAP_FILL") == nullptr || atoi(getenv("RR_OVERLAP_FILL")) != 0) {
     const bool two_lanes = getenv("RR_LANES") && atoi(getenv("RR_LANES")) == 2;   // (A/B hook) the lane ahead and the fill lane share one stream
-    if (hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, prio(ppre)) != hipSuccess ||
-        (two_lanes ? (c->fill_stream = c->pre_stream, hipSuccess) : hipStreamCreateWithPriority(&c->fill_stream, hipStreamNonBlocking, prio(pfill))) != hipSuccess ||
+    if (make_stream(&c->pre_stream, 0, ppre, true) != hipSuccess ||
+        (two_lanes ? (c->fill_stream = c->pre_stream, hipSuccess) : make_stream(&c->fill_stream, 1, pfill, true)) != hipSuccess ||
         hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->integ_stream, hipStreamNonBlocking, prio(pinteg)) != hipSuccess ||
+        make_stream(&c->integ_stream, 2, pinteg, true) != hipSuccess ||
         hipEventCreateWithFlags(&c->draw_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->draw_done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->integ_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->integ_gate, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->fill_done[0], hipEventDisableTiming) != hipSuccess ||
