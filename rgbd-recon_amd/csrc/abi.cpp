@@ -367,6 +367,14 @@ hipStream_t pre_enter(tsdf_ctx* c) {
     // overlapping the preparation of frame f + 2 with the integrate of frame f + 1
     c->pre_lane = (c->pre_on_integ && deep_ok(c)) ? c->integ_stream : c->pre_stream;
     if (c->pre_gate_recorded) hipStreamWaitEvent(c->pre_lane, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
+    // ... on the context's stream, which waits for an integrate() on the fourth lane only when a DRAW joins it.  Frames integrated back to back with no
+    // draw in between leave that integrate out of every gate, while it may still read the frame slot / brick counters / occupancy set this frame is about to
+    // overwrite (the copies alternate): the lane waits for the integrate lane itself then.  (In the per-frame order upload .. integrate, draw the flag is
+    // clear here -- the draw has joined the lane -- and nothing is added.)
+    if (c->integ_pending && c->integ_stream && c->pre_lane != c->integ_stream) {
+      hipEventRecord(c->integ_done, c->integ_stream);
+      hipStreamWaitEvent(c->pre_lane, c->integ_done, 0);
+    }
     hipEventRecord(c->pre_gate, c->stream);
     c->pre_gate_recorded = true; c->main_since_gate = false;
     c->slot_flipped = c->counters_flipped = c->occ_flipped = false;

@@ -39,16 +39,16 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;
 };
-Rccl* rccl() {
-  static Rccl R;
-  static bool tried = false;
-  if (tried) return R.lib ? &R : nullptr;
-  tried = true;
+// Thread-safe (C++11 magic static: the object is complete before any caller sees it; "one process (or thread) per GPU" makes concurrent first
+// calls the normal case).  RR_TEST_NO_RCCL (test hook): behave as if the library could not be loaded.
+static Rccl load_rccl() {
+  Rccl R;
+  if (getenv("RR_TEST_NO_RCCL")) { R.why = "librccl.so not loaded (RR_TEST_NO_RCCL is set)"; return R; }
   const char* names[] = {"librccl.so.1", "librccl.so"};
   for (int pass = 0; pass < 2 && !R.lib; ++pass)                        // first a copy that is already in the process (torch's), then the system's
     for (const char* n : names)
       if (!R.lib) R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
-  if (!R.lib) { R.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return nullptr; }
+  if (!R.lib) { const char* e = dlerror(); R.why = std::string("librccl.so not found: ") + (e ? e : "no loader message"); return R; }   // (dlerror() clears itself: one call)
   bool ok = true;
   auto sym = [&](const char* n) { void* p = dlsym(R.lib, n); if (!p) { ok = false; R.why = std::string("librccl lacks ") + n; } return p; };
   R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
@@ -61,12 +61,16 @@ Rccl* rccl() {
   R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
   R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
   R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
-  if (!ok) { R.lib = nullptr; return nullptr; }
-  return &R;
+  if (!ok) R.lib = nullptr;
+  return R;
 }
-std::string g_rccl_error;
+static Rccl& rccl_state() { static Rccl R = load_rccl(); return R; }
+Rccl* rccl() { Rccl& R = rccl_state(); return R.lib ? &R : nullptr; }
+const char* rccl_why() { return rccl_state().why.c_str(); }            // why rccl() is null
 
 #define NCCL_TRY(c, expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { FAIL(c, TSDF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl()->GetErrorString(_r), __FILE__, __LINE__); } } while (0)
+// inside ncclGroupStart / ncclGroupEnd: an error closes the group before it returns (an open group would swallow every later collective of the thread)
+#define NCCL_TRY_IN_GROUP(c, expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { rccl()->GroupEnd(); FAIL(c, TSDF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl()->GetErrorString(_r), __FILE__, __LINE__); } } while (0)
 #define NEED_COMM(c) do { CHECK_CTX(c); if (!(c)->comm.comm) FAIL(c, TSDF_ERR_STATE, "no communicator (tsdf_comm_init)"); } while (0)
 
 bool is_worker(const tsdf_ctx* c) { return !(c->comm.dedicated && c->comm.rank == 0); }
@@ -131,9 +135,9 @@ int32_t exchange_hits(tsdf_ctx* c, uint32_t cap, bool first, uint64_t f) {
   if (M.world > 1) {
     NCCL_TRY(c, R->GroupStart());
     if (M.rank == 0) {
-      for (int r = 1; r < M.world; ++r) NCCL_TRY(c, R->Recv(M.d_hitparts + (size_t)r * M.hit_floats, n, ncclFloat, r, (ncclComm_t)M.comm, c->stream));
+      for (int r = 1; r < M.world; ++r) NCCL_TRY_IN_GROUP(c, R->Recv(M.d_hitparts + (size_t)r * M.hit_floats, n, ncclFloat, r, (ncclComm_t)M.comm, c->stream));
     } else {
-      NCCL_TRY(c, R->Send(M.d_hitbuf, n, ncclFloat, 0, (ncclComm_t)M.comm, c->stream));
+      NCCL_TRY_IN_GROUP(c, R->Send(M.d_hitbuf, n, ncclFloat, 0, (ncclComm_t)M.comm, c->stream));
     }
     NCCL_TRY(c, R->GroupEnd());
   }
@@ -151,7 +155,7 @@ int32_t tsdf_comm_unique_id(uint8_t id[TSDF_COMM_ID_BYTES]) {
   if (!id) return TSDF_ERR_INVALID_ARGUMENT;
   static_assert(TSDF_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id is RCCL's");
   Rccl* R = rccl();
-  if (!R) return TSDF_ERR_STATE;
+  if (!R) { g_create_error = std::string("RCCL is not available in this process: ") + rccl_why(); return TSDF_ERR_STATE; }   // (no context here: tsdf_last_error(NULL) returns it)
   ncclUniqueId u;
   if (R->GetUniqueId(&u) != ncclSuccess) return TSDF_ERR_HIP;
   memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
@@ -165,7 +169,7 @@ int32_t tsdf_comm_init(tsdf_ctx* c, const uint8_t id[TSDF_COMM_ID_BYTES], uint32
   if (dedicated && world < 2) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "a dedicated compositor needs at least one worker rank");
   if (c->comm.comm) FAIL(c, TSDF_ERR_STATE, "the context already has a communicator (tsdf_comm_destroy first)");
   Rccl* R = rccl();
-  if (!R) { static Rccl none; FAIL(c, TSDF_ERR_STATE, "RCCL is not available in this process"); }
+  if (!R) FAIL(c, TSDF_ERR_STATE, "RCCL is not available in this process: %s", rccl_why());
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, sync_ctx(c));
   ncclUniqueId u;

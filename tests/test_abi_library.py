@@ -72,3 +72,27 @@ def test_product_does_not_reference_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
                     txt = open(os.path.join(d, f), errors="ignore").read()
                     assert "tsdf_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(d, f)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """with librccl not loadable (a C++ host without torch and without /opt/rocm/lib on the loader path) tsdf_comm_unique_id
+    must return TSDF_ERR_STATE with a message, not crash on a second dlerror().  RR_TEST_NO_RCCL forces that path; a child process,
+    because the loader's state is decided once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import torch, rgbd_recon_amd as rr\n"
+        "L = rr.load_library()\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "rc = L.tsdf_comm_unique_id(buf)\n"
+        "L.tsdf_last_error.restype = ctypes.c_char_p\n"
+        "print(rc, L.tsdf_last_error(None).decode())\n"
+    )
+    env = dict(os.environ, RR_TEST_NO_RCCL="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rc, msg = p.stdout.strip().split(" ", 1)
+    assert int(rc) == -4 and "RCCL is not available" in msg and "RR_TEST_NO_RCCL" in msg

@@ -1,0 +1,89 @@
+"""-m gpu: round 4.
+
+  * frames integrated back to back with NO draw and no host read in between (the lane ahead must not overwrite what the
+    integrate lane still reads), and the occupied ratio read back between mark and update (the count word the marking launch cleared);
+  * the tile bounds behind the uniform-pair shortcut are taken over the tile's own voxels (k_tile_bounds): dense and culled launches with
+    LUTs whose boxes are much wider than the tile, images with arbitrary (non-binary) silhouettes and negative qualities.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_same
+from oracle.oracle import OracleRecon
+
+pytestmark = pytest.mark.gpu
+
+
+def scenes(rr, **mk):
+    return [rr.scene.make_scene(**mk), rr.scene.make_scene(**mk, sphere_c=(0.4, 0.7, -0.3), box_c=(-0.5, 1.5, 0.2)), rr.scene.make_scene(**mk, sphere_c=(-0.3, 1.3, 0.2))]
+
+
+@pytest.mark.parametrize("use_bricks", [True, False])
+def test_integrates_back_to_back_without_a_draw(rr, use_bricks):
+    """upload, clear, mark, update, integrate -- repeated for new frames with no draw and no synchronisation: every integrate() runs on the
+    fourth lane, every preparation on the lane ahead, and only the copies' alternation keeps them apart.  The volume after the last frame
+    (and after every prefix length) must be the oracle's."""
+    scs = scenes(rr, n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    kw = dict(res=(128, 128, 128), brick_size=[2.0 / 16, 2.2 / 16, 2.0 / 16], limit=0.03, view=(160, 90))
+    mv, pr = rr.scene.default_view(*kw["view"])
+    for n_frames in (3, 4, 7):
+        hip, orc = rr.ReconIntegrationHip(scs[0], **kw), OracleRecon(scs[0], **kw)
+        for o in (hip, orc):
+            o.setUseBricks(use_bricks)
+        order = [1, 2, 0, 1, 0, 2, 1][:n_frames]
+        for k in order:                                     # the HIP side first, all of it queued before anything is read
+            hip.upload_frame(scs[k]); hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate()   # (False: no ratio read back, nothing synchronises)
+        for k in order:
+            orc.upload_frame(scs[k]); orc.clearOccupiedBricks(); orc.markBricks(); orc.updateOccupiedBricks(); orc.integrate()
+        assert_same(hip.tsdf(), orc.tsdf(), f"volume after {n_frames} undrawn frames (use_bricks {use_bricks})")
+        for o in (hip, orc):
+            o.drawF(mv, pr)
+        (hc, hd), (oc, od) = hip.framebuffer(), orc.framebuffer()
+        assert_same(hd, od, "framebuffer depth after the undrawn frames"); assert_same(hc, oc, "framebuffer colour after the undrawn frames")
+        assert (hd < 1).sum() > 50
+
+
+def test_occupied_ratio_between_mark_and_update(rr):
+    """tsdf_occupied_ratio() between markBricks() and updateOccupiedBricks() joins the lane ahead in the middle of a frame's preparation: the
+    update that follows starts a new lane frame and must clear the count word it flips to itself.  Ratio, occupied list and volume stay the
+    oracle's over a moving scene."""
+    scs = scenes(rr, n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    kw = dict(res=(96, 96, 96), brick_size=[2.0 / 12, 2.2 / 12, 2.0 / 12], limit=0.03, view=(160, 90))
+    mv, pr = rr.scene.default_view(*kw["view"])
+    hip, orc = rr.ReconIntegrationHip(scs[0], **kw), OracleRecon(scs[0], **kw)
+    prev = None
+    for k in range(6):
+        for o in (hip, orc):
+            o.upload_frame(scs[k % 3]); o.clearOccupiedBricks(); o.markBricks()
+        stale = hip.occupiedRatio()                         # the previous update's count (the reference's host vector is untouched by mark)
+        if prev is not None:
+            assert stale == prev
+        r_h = hip.updateOccupiedBricks(True); r_o = orc.updateOccupiedBricks()
+        assert r_h == r_o and r_h > 0
+        prev = r_h
+        for o in (hip, orc):
+            o.integrate(); o.drawF(mv, pr)
+        assert_same(hip.tsdf(), orc.tsdf(), f"volume, frame {k}")
+    assert_same(hip.framebuffer()[1], orc.framebuffer()[1], "framebuffer depth")
+
+
+@pytest.mark.parametrize("use_bricks", [True, False])
+@pytest.mark.parametrize("inv_res,res", [(16, (96, 96, 96)), (48, (64, 64, 64)), (24, (100, 84, 92))])
+def test_voxel_exact_tile_bounds_keep_the_shortcut_exact(rr, use_bricks, inv_res, res):
+    """The uniform-pair shortcut decides per (tile, stream) from static bounds of (u, v, z) over the tile.  Round 4 takes them over the
+    tile's own voxels -- tighter than the LUT box hull, so MORE pairs skip the per-voxel evaluation -- at LUT : volume ratios from 6 : 1 to
+    4 : 3 and a volume that does not fill its last tiles; images with arbitrary silhouettes / negative qualities make no pair uniform."""
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=inv_res)
+    scs = scenes(rr, **mk)
+    kw = dict(res=res, brick_size=[2.0 / 8, 2.2 / 8, 2.0 / 8], limit=0.04, view=(160, 90))
+    hip, orc = rr.ReconIntegrationHip(scs[0], **kw), OracleRecon(scs[0], **kw)
+    rng = np.random.default_rng(7)
+    weird = dict(scs[1])
+    weird["silhouette"] = rng.uniform(0.0, 1.0, scs[1]["silhouette"].shape).astype(np.float32)
+    weird["quality"] = (scs[1]["quality"] * rng.choice(np.float32([1.0, -1.0]), scs[1]["quality"].shape)).astype(np.float32)
+    for o in (hip, orc):
+        o.setUseBricks(use_bricks)
+    for k, sc in enumerate([scs[0], scs[1], weird, scs[2], weird]):
+        hip.upload_frame(sc); hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate()
+        orc.upload_frame(sc); orc.clearOccupiedBricks(); orc.markBricks(); orc.updateOccupiedBricks(); orc.integrate()
+        assert_same(hip.tsdf(), orc.tsdf(), f"volume, frame {k} (inv_res {inv_res}, res {res}, use_bricks {use_bricks})")
