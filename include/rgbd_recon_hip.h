@@ -219,6 +219,11 @@ int32_t tsdf_download_raw_frame(tsdf_ctx* ctx, float* depth_raw, uint8_t* colour
  * pre_normal.fs (which also calls mark_brick(): call it between tsdf_clear_bricks and tsdf_update_occupied, like
  * process_textures() in source/kinect_client.cpp:569-577, and do NOT call tsdf_mark_bricks as well), pre_quality.fs. */
 int32_t tsdf_upload_raw_frame(tsdf_ctx* ctx, const float* depth_raw_m, const uint8_t* colour_rgb);
+/* the same with both arrays already in DEVICE memory (a decoder's or a camera SDK's buffer): no copy, the passes read depth_raw_m where it lies.
+ * flags as for tsdf_upload_frame_dev (0 / TSDF_FRAME_ARRAYS_COMPLETE); the arrays must stay untouched until work queued on the context's stream
+ * after the next tsdf_integrate() / draw call runs.  Round 4: the raw upload, tsdf_upload_wire_frame and tsdf_process_textures run on the lane
+ * ahead (as tsdf_upload_frame / tsdf_mark_bricks do), beside the integrate and the draw of the previous frames. */
+int32_t tsdf_upload_raw_frame_dev(tsdf_ctx* ctx, const float* depth_raw_m, const uint8_t* colour_rgb, uint32_t flags);
 int32_t tsdf_set_depth_limits(tsdf_ctx* ctx, uint32_t stream, float cv_min_d, float cv_max_d);   /* CalibVolumes::getDepthLimits, CalibVolumes.cpp:91-93 */
 int32_t tsdf_set_camera_position(tsdf_ctx* ctx, uint32_t stream, const float xyz[3]);            /* CalibVolumes::getCameraPositions, :224-230 */
 /* filterTextures / useProcessedDepths / refineBoundary, NetKinectArray.cpp:466-480 (all default true, :63-69) */
@@ -247,6 +252,9 @@ int32_t tsdf_draw_f(tsdf_ctx* ctx, const float modelview[16], const float projec
  * is of the order of the frame itself.  Stops at the first failing step and returns its code. */
 int32_t tsdf_frame_dev(tsdf_ctx* ctx, const float* depth_rg, const float* quality, const float* silhouette, const uint8_t* colour_rgb, uint32_t flags,
                        const float modelview[16], const float projection[16]);
+/* ... and from the RAW frame, NetKinectArray::update() + processTextures() in front of the path (kinect_client.cpp:569-577): [tsdf_upload_raw_frame_dev
+ * when depth_raw_m is not NULL,] clearOccupiedBricks, tsdf_process_textures (which marks the bricks), updateOccupiedBricks, integrate, drawF. */
+int32_t tsdf_frame_raw_dev(tsdf_ctx* ctx, const float* depth_raw_m, const uint8_t* colour_rgb, uint32_t flags, const float modelview[16], const float projection[16]);
 
 /* ---- setters mirroring recon_integration.hpp:43-49,57 and reconstruction.hpp:20-23 --------------- */
 int32_t tsdf_set_tsdf_limit(tsdf_ctx* ctx, float limit);

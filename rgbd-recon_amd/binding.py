@@ -295,6 +295,10 @@ class ReconIntegrationHip:
     def upload_raw_frame(self, scene):
         col = np.ascontiguousarray(scene["color"], np.uint8)
         self._ck(self._L.tsdf_upload_raw_frame(self._c, _fp(_f32(scene["depth_raw"])), col.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self.set_preprocess_calibration(scene)
+
+    def set_preprocess_calibration(self, scene):
+        """what processTextures() needs beside the LUTs: CalibVolumes::getDepthLimits / getCameraPositions of every sensor"""
         for i in range(self.n):
             self._ck(self._L.tsdf_set_depth_limits(self._c, i, C.c_float(float(scene["depth_limits"][0])), C.c_float(float(scene["depth_limits"][1]))))
             self._ck(self._L.tsdf_set_camera_position(self._c, i, _fp(_f32(scene["camera_positions"][i]))))
@@ -382,6 +386,17 @@ class ReconIntegrationHip:
         d, q, s, col = (tuple(new_frame) + (0,))[:4] if new_frame is not None else (0, 0, 0, 0)
         self._ck(self._L.tsdf_frame_dev(self._c, C.c_void_p(d), C.c_void_p(q), C.c_void_p(s), C.c_void_p(col), C.c_uint32(1 if complete else 0),
                                         _fp(_f32(mv)), _fp(_f32(proj))))
+
+    def upload_raw_frame_dev(self, depth_raw_ptr, colour_ptr, complete=False):
+        """the RAW frame (depth in metres [N][H][W] float32, colour RGB8) is in device memory already: processTextures() reads it where it lies"""
+        self._ck(self._L.tsdf_upload_raw_frame_dev(self._c, C.c_void_p(int(depth_raw_ptr)), C.c_void_p(int(colour_ptr)), C.c_uint32(1 if complete else 0)))
+
+    def frame_raw_dev(self, mv, proj, new_frame=None, complete=True):
+        """one frame of the client's loop from the RAW frame in ONE call (tsdf_frame_raw_dev): [new_frame = (depth_raw, colour) device pointers,]
+        clearOccupiedBricks, processTextures (marks the bricks), updateOccupiedBricks, integrate, drawF"""
+        d, col = tuple(new_frame) if new_frame is not None else (0, 0)
+        self._ck(self._L.tsdf_frame_raw_dev(self._c, C.c_void_p(d), C.c_void_p(col), C.c_uint32(1 if complete else 0), _fp(_f32(mv)), _fp(_f32(proj))))
+
     def setTsdfLimit(self, v): self._ck(self._L.tsdf_set_tsdf_limit(self._c, C.c_float(v)))
 
     def setVoxelSize(self, size):

@@ -796,6 +796,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   if (c->pre_done) hipEventDestroy(c->pre_done);
   if (c->pre_gate) hipEventDestroy(c->pre_gate);
   if (c->src_ready) hipEventDestroy(c->src_ready);
+  if (c->normals_read) hipEventDestroy(c->normals_read);
   if (c->fill_worker) {
     c->fill_worker->stop.store(true);
     { std::lock_guard<std::mutex> lk(c->fill_worker->m); }
@@ -1087,23 +1088,51 @@ static int32_t ensure_pre_buffers(tsdf_ctx* c) {
     HIP_TRY(c, hipMalloc(&c->d_lab, np * sizeof(float4)));
     HIP_TRY(c, hipMalloc(&c->d_depth_b, np * sizeof(float2)));
     HIP_TRY(c, hipMalloc(&c->d_normal, np * sizeof(float4)));
-    HIP_TRY(c, hipMemsetAsync((void*)F.dqs, 0, np * sizeof(float4), c->stream));
   }
   return TSDF_OK;
 }
+// The raw frame (NetKinectArray::update(): depth + colour of every sensor) goes through the lane ahead like a pre-processed one does (round 4): its
+// colour is re-laid out into the frame slot the lane writes, its depth is what tsdf_process_textures() -- on the same lane -- starts from.
 int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour) {
   CHECK_CTX(c);
   if (!depth_raw || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "raw depth and colour are required");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, block_pipeline(c));                                          // the pre-processing passes write the images AND mark the bricks: one stream
+  if (int32_t rc = ensure_pre_buffers(c)) return rc;
+  const hipStream_t lane = pre_enter(c);
+  if (int32_t rc = begin_slot_write(c, lane, false)) return rc;
   const FrameImages& F = c->frame;
   const size_t np = (size_t)c->cfg.num_streams * F.w * F.h, nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
-  if (int32_t rc = ensure_pre_buffers(c)) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_raw, depth_raw, np * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, c->stream));
-  launch_pack_color(c->stream, c->d_stage_col, (uchar4*)F.color, nc);
+  HIP_TRY(c, hipMemcpyAsync(c->d_raw, depth_raw, np * sizeof(float), hipMemcpyHostToDevice, lane));
+  HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, lane));
+  launch_pack_color(lane, c->d_stage_col, (uchar4*)F.color, nc);
   HIP_TRY(c, hipGetLastError());
-  c->have_raw = true;
+  c->raw_src = c->d_raw; c->have_raw = true;
+  HIP_TRY(c, pre_leave(c, lane));
+  return TSDF_OK;
+}
+// ... and with both arrays in device memory already (a decoder, a camera SDK's buffer): no copy -- the passes read depth_raw where it lies.  flags as
+// for tsdf_upload_frame_dev; the arrays must stay untouched until work queued on the context's stream AFTER the next tsdf_integrate() / draw call runs.
+int32_t tsdf_upload_raw_frame_dev(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour, uint32_t flags) {
+  CHECK_CTX(c);
+  if (!depth_raw || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "raw depth and colour are required");
+  if (((uintptr_t)depth_raw & 3u) || ((uintptr_t)colour & 3u)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "device arrays must be 4-byte aligned");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int32_t rc = ensure_pre_buffers(c)) return rc;
+  const hipStream_t lane = pre_enter(c);
+  if (lane != c->stream && !(flags & TSDF_FRAME_ARRAYS_COMPLETE)) {      // the producer may be work on the context's stream: behind all of it
+    if (!c->src_ready) HIP_TRY(c, hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->src_ready, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(lane, c->src_ready, 0));
+  }
+  if (int32_t rc = begin_slot_write(c, lane, false)) return rc;
+  const FrameImages& F = c->frame;
+  const size_t nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
+  timer_begin_on(c, "0repack", lane);
+  launch_pack_color(lane, colour, (uchar4*)F.color, nc);
+  timer_end_on(c, "0repack", lane);
+  HIP_TRY(c, hipGetLastError());
+  c->raw_src = depth_raw; c->have_raw = true;
+  HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
 int32_t tsdf_set_depth_limits(tsdf_ctx* c, uint32_t i, float mn, float mx) {
@@ -1160,7 +1189,6 @@ int32_t tsdf_upload_wire_frame(tsdf_ctx* c, const void* message, uint64_t bytes,
   const uint64_t want = (cs + ds) * c->cfg.num_streams;
   if (!message || bytes != want) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "wire message must be %llu bytes (%u x (colour %llu + depth %llu)), got %llu", (unsigned long long)want, c->cfg.num_streams, (unsigned long long)cs, (unsigned long long)ds, (unsigned long long)bytes);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, block_pipeline(c));
   if (int32_t rc = ensure_pre_buffers(c)) return rc;
   if (c->wire_capacity < want) {
     HIP_TRY(c, sync_ctx(c));
@@ -1179,18 +1207,21 @@ int32_t tsdf_upload_wire_frame(tsdf_ctx* c, const void* message, uint64_t bytes,
   if (c->wire_pending[k]) HIP_TRY(c, hipEventSynchronize(c->wire_done[k]));
   memcpy(c->h_wire[k], message, want);                                   // readLoop's memcpy into the mapped PBO, :516-520
   if (timestamp) memcpy(timestamp, c->h_wire[k], sizeof(double));        // the first 8 bytes of the message, :510
-  HIP_TRY(c, hipMemcpyAsync(c->d_wire, c->h_wire[k], want, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipEventRecord(c->wire_done[k], c->stream));
+  const hipStream_t lane = pre_enter(c);                                 // (round 4) the lane ahead: copy, unpack / DXT decode and the passes that follow
+  if (int32_t rc = begin_slot_write(c, lane, false)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_wire, c->h_wire[k], want, hipMemcpyHostToDevice, lane));
+  HIP_TRY(c, hipEventRecord(c->wire_done[k], lane));
   c->wire_pending[k] = true;
   WireLayout L{};
   L.msg = c->d_wire; L.rec = (uint32_t)(cs + ds); L.cs = (uint32_t)cs; L.n = (int)c->cfg.num_streams;
   L.cw = c->frame.cw; L.ch = c->frame.ch; L.w = c->frame.w; L.h = c->frame.h;
   L.cfmt = (int)c->color_format; L.dfmt = (int)c->depth_format;
-  timer_begin(c, "0ingest");
-  launch_wire_unpack(c->stream, L, (uchar4*)c->frame.color, c->d_raw);
-  timer_end(c, "0ingest");
+  timer_begin_on(c, "0ingest", lane);
+  launch_wire_unpack(lane, L, (uchar4*)c->frame.color, c->d_raw);
+  timer_end_on(c, "0ingest", lane);
   HIP_TRY(c, hipGetLastError());
-  c->have_raw = true;
+  c->raw_src = c->d_raw; c->have_raw = true;
+  HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
 int32_t tsdf_download_raw_frame(tsdf_ctx* c, float* depth_raw, uint8_t* colour_rgba) {
@@ -1199,7 +1230,7 @@ int32_t tsdf_download_raw_frame(tsdf_ctx* c, float* depth_raw, uint8_t* colour_r
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, sync_ctx(c));
   const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h, nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
-  if (depth_raw) HIP_TRY(c, hipMemcpy(depth_raw, c->d_raw, np * 4, hipMemcpyDeviceToHost));
+  if (depth_raw) HIP_TRY(c, hipMemcpy(depth_raw, c->raw_src, np * 4, hipMemcpyDeviceToHost));
   if (colour_rgba) HIP_TRY(c, hipMemcpy(colour_rgba, c->frame.color, nc * 4, hipMemcpyDeviceToHost));
   return TSDF_OK;
 }
@@ -1216,20 +1247,28 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
     if (!c->have_limits[i] || !c->have_cam[i]) FAIL(c, TSDF_ERR_STATE, "stream %u needs tsdf_set_depth_limits and tsdf_set_camera_position", i);
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, block_pipeline(c));
+  // Round 4: on the lane ahead, like markBricks() -- the passes read the raw frame and write only what the lane owns (the frame slot it flipped to,
+  // the brick counters clearOccupiedBricks() flipped to, its own intermediate images), so they run beside the previous frames' integrate and draw.
+  const hipStream_t lane = pre_enter(c);
+  if (int32_t rc = begin_slot_write(c, lane, true)) return rc;          // (already done by the raw upload of this frame; a re-run of an old raw frame takes the colour along)
+  if (c->normals_read_pending) {                                         // the point / triangle-grid back-ends read the normal image this call rewrites
+    if (lane != c->stream) HIP_TRY(c, hipStreamWaitEvent(lane, c->normals_read, 0));
+    c->normals_read_pending = false;
+  }
   PreParams& P = c->pre;
   P.W = c->frame.w; P.H = c->frame.h; P.N = (int)c->cfg.num_streams;
   for (int a = 0; a < 3; ++a) { P.bbox_min[a] = c->cfg.bbox_min[a]; P.bbox_max[a] = c->cfg.bbox_max[a]; }
   PreBuffers B{};
-  B.raw = c->d_raw; B.depth2 = c->d_depth2; B.fdepth = c->use_processed_depth ? c->d_depth2 : c->d_raw;
+  B.raw = c->raw_src; B.depth2 = c->d_depth2; B.fdepth = c->use_processed_depth ? c->d_depth2 : c->raw_src;
   B.depth_rg = c->d_depth_rg; B.lab = c->d_lab; B.depth_b = c->d_depth_b; B.normal = c->d_normal;
   B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
-  timer_begin(c, "1preprocess");
-  launch_preprocess(c->stream, P, B, c->luts, c->frame, c->br);
-  launch_frame_ranges(c->stream, c->frame.dqs, (int)c->cfg.num_streams, c->frame.w, c->frame.h, c->slots[c->cur_slot].ranges);
-  timer_end(c, "1preprocess");
+  timer_begin_on(c, "1preprocess", lane);
+  launch_preprocess(lane, P, B, c->luts, c->frame, c->br);
+  launch_frame_ranges(lane, c->frame.dqs, (int)c->cfg.num_streams, c->frame.w, c->frame.h, c->slots[c->cur_slot].ranges);
+  timer_end_on(c, "1preprocess", lane);
   HIP_TRY(c, hipGetLastError());
   c->slots[c->cur_slot].have = true;
+  HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
 int32_t tsdf_download_preprocessed(tsdf_ctx* c, float* depth2, float* depth_rg, float* lab, float* depth_b, float* sil, float* normals, float* quality) {
@@ -1594,6 +1633,11 @@ int32_t tsdf_draw_points(tsdf_ctx* c, const float* mv, const float* pr) {
   c->fb_consistent = false;
   launch_draw_points(c->stream, P, Q, c->luts, F, c->d_comp_key, c->d_fb_c, c->d_fb_d);
   timer_end(c, "points");
+  if (c->d_normal && pipelined(c)) {                                     // the next tsdf_process_textures() on the lane ahead rewrites the normal image
+    if (!c->normals_read) HIP_TRY(c, hipEventCreateWithFlags(&c->normals_read, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->normals_read, c->stream));
+    c->normals_read_pending = true;
+  }
   HIP_TRY(c, hipGetLastError());
   return TSDF_OK;
 }
@@ -1717,6 +1761,14 @@ int32_t tsdf_frame_dev(tsdf_ctx* c, const float* depth_rg, const float* quality,
   }
   if (depth_rg && (rc = tsdf_upload_frame_dev(c, depth_rg, quality, silhouette, colour, flags))) return rc;
   if ((rc = tsdf_clear_bricks(c)) || (rc = tsdf_mark_bricks(c)) || (rc = tsdf_update_occupied(c, nullptr)) || (rc = tsdf_integrate(c))) return rc;
+  return tsdf_draw_f(c, mv, pr);
+}
+// The same from the RAW frame: NetKinectArray::update() + processTextures() in front of the path (kinect_client.cpp:569-577)
+int32_t tsdf_frame_raw_dev(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour, uint32_t flags, const float* mv, const float* pr) {
+  CHECK_CTX(c);
+  int32_t rc;
+  if (depth_raw && (rc = tsdf_upload_raw_frame_dev(c, depth_raw, colour, flags))) return rc;
+  if ((rc = tsdf_clear_bricks(c)) || (rc = tsdf_process_textures(c)) || (rc = tsdf_update_occupied(c, nullptr)) || (rc = tsdf_integrate(c))) return rc;
   return tsdf_draw_f(c, mv, pr);
 }
 int32_t tsdf_set_stage_overlap(tsdf_ctx* c, int32_t on) {

@@ -79,6 +79,8 @@ struct tsdf_ctx {
   PreParams pre{};
   float* d_raw = nullptr; float* d_depth2 = nullptr; float2* d_depth_rg = nullptr; float4* d_lab = nullptr; float2* d_depth_b = nullptr; float4* d_normal = nullptr;
   bool have_raw = false, use_processed_depth = true;
+  const float* raw_src = nullptr;   // the raw depth the passes read: d_raw (host upload, wire unpack) or the caller's device array (tsdf_upload_raw_frame_dev)
+  hipEvent_t normals_read = nullptr; bool normals_read_pending = false;   // recorded behind a point / triangle-grid draw: the lane ahead rewrites d_normal
   bool have_limits[TSDF_MAX_STREAMS]{}, have_cam[TSDF_MAX_STREAMS]{};
   // frame ingest (readLoop / update): wire formats, pinned double buffer (the reference's double_pbo), device copy of the message
   uint32_t color_format = TSDF_COLOR_RGB8, depth_format = TSDF_DEPTH_F32;

@@ -97,17 +97,24 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
     if (!P.filter_textures) od = make_float2(dn, 1.0f);
     else {
       const float dist_range_max = 0.35f * (depth / 4.5f), dist_range_max_inv = 1.0f / dist_range_max;   // :89-92
-      float depth_bf = 0.0f, w = 0.0f, w_range = 0.0f, num = 0.0f;
+      // The 169 taps in the shader's order (the three sums are fp32: their order is part of the result), fully unrolled: computeGaussSpace of a
+      // constant offset folds to a literal (round 3 evaluated an IEEE sqrt per tap at run time: 18 of its 42 vector instructions per tap),
+      // a rejected tap adds +0.0f -- the identity for every value these sums can take (they start at +0 and never become -0) -- instead of
+      // branching around the adds, and `num` counts every tap: 169, exactly.  16 vector instructions per tap.
+      float depth_bf = 0.0f, w = 0.0f, w_range = 0.0f;
+      const float num = 169.0f;
+#pragma unroll
       for (int dy = -6; dy < 7; ++dy)
+#pragma unroll
         for (int dx = -6; dx < 7; ++dx) {
-          num += 1.0f;
           const float ds = s_d[ly + 6 + dy][lx + 6 + dx];
           const float dr = fabsf(ds - depth);
-          if ((ds < mn) || (ds > mx) || (dr > dist_range_max)) continue;                               // is_outside, :74-76
-          const float gs = 1.0f - sqrtf((float)dx * (float)dx + (float)dy * (float)dy) * (1.0f / 6.0f); // computeGaussSpace
+          const bool skip = (ds < mn) || (ds > mx) || (dr > dist_range_max);                           // is_outside, :74-76
+          const float gs = 1.0f - __builtin_sqrtf((float)(dx * dx + dy * dy)) * (1.0f / 6.0f);         // computeGaussSpace (a compile-time constant)
           const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;                       // computeGaussRange
           const float ws = gs * gr;
-          depth_bf += ws * ds; w += ws; w_range += gr;
+          const float wd = ws * ds;
+          depth_bf += skip ? 0.0f : wd; w += skip ? 0.0f : ws; w_range += skip ? 0.0f : gr;
         }
       od = make_float2((depth_bf / w - mn) / (mx - mn), w_range / num);                                 // :124-126
     }
@@ -154,9 +161,7 @@ __global__ __launch_bounds__(256) void k_pre_boundary(PreParams P, PreBuffers B)
   } else d.y = 0.0f;
   B.depth_b[o] = d;
   B.depth_plane[o] = d.x;
-  float4 t = B.dqs[o];
-  t.x = d.x; t.z = sil; t.w = 0.0f;
-  B.dqs[o] = t;
+  B.dqs[o] = make_float4(d.x, 0.0f, sil, 0.0f);                                         // (quality: the last pass writes it)
 }
 
 // ---- pre_normal.fs :26-56 including the mark_brick() call (:32-33)
@@ -208,15 +213,22 @@ __global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, 
   float q = 0.0f;
   if (!(depth <= 0.0f || depth >= 1.0f)) {
     const float dist_range_max = 0.35f * (depth / 1.0f), dist_range_max_inv = 1.0f / dist_range_max;
-    float w_range = 0.0f, border = 0.0f, num = 0.0f;
+    // as in k_pre_filter: unrolled, branch-free; `border` and `num` count taps (integers below 2^24: exact in any order)
+    float w_range = 0.0f;
+    int n_border = 0;
+    const float num = 169.0f;
+#pragma unroll
     for (int dy = -6; dy < 7; ++dy)
+#pragma unroll
       for (int dx = -6; dx < 7; ++dx) {
-        num += 1.0f;
         const float ds = s_d[ly + 6 + dy][lx + 6 + dx];
         const float dr = fabsf(ds - depth);
-        if ((ds <= 0.0f || ds >= 1.0f) || dr > dist_range_max) { border += 1.0f; continue; }
-        w_range += 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+        const bool out = (ds <= 0.0f || ds >= 1.0f) || dr > dist_range_max;
+        n_border += out ? 1 : 0;
+        const float g = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+        w_range += out ? 0.0f : g;
       }
+    const float border = (float)n_border;
     const float lateral = 1.0f - border / num;
     q = powf(lateral, 6.0f);
     q *= powf(w_range / num, 6.0f);

@@ -87,3 +87,40 @@ def test_voxel_exact_tile_bounds_keep_the_shortcut_exact(rr, use_bricks, inv_res
         hip.upload_frame(sc); hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate()
         orc.upload_frame(sc); orc.clearOccupiedBricks(); orc.markBricks(); orc.updateOccupiedBricks(); orc.integrate()
         assert_same(hip.tsdf(), orc.tsdf(), f"volume, frame {k} (inv_res {inv_res}, res {res}, use_bricks {use_bricks})")
+
+
+def test_raw_frames_through_the_lanes(rr, monkeypatch):
+    """VERDICT r03 "next" 3: the RAW frame (tsdf_upload_raw_frame_dev) and processTextures() run on the lane ahead, beside the integrate and the
+    draw of the previous frames.  Eight moving frames queued back to back with no read in between must leave, bit for bit, what a context with
+    every kernel on one stream leaves (volume, pre-processing products, brick counters, framebuffer), and that context agrees with the oracle's
+    orc_process_textures + frame (products without pow() exactly; quality / Lab go through powf: the tolerances of test_gpu_preprocess)."""
+    import torch
+    from helpers import tsdf_close
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    scs = scenes(rr, **mk)
+    kw = dict(res=(96, 96, 96), brick_size=[2.0 / 12, 2.2 / 12, 2.0 / 12], limit=0.04, view=(160, 90))
+    pr = rr.scene.gl_flat(rr.scene.perspective(50.0, 16.0 / 9.0, 0.1, 200.0))
+    mvs = [rr.scene.gl_flat(rr.scene.look_at(e, (0.0, 1.1, 0.0))) for e in [(0.0, 1.1, 3.0), (1.6, 1.4, 2.4), (-2.2, 0.6, 1.2)]]
+    dev = [(torch.from_numpy(np.ascontiguousarray(sc["depth_raw"], np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(sc["color"], np.uint8)).cuda()) for sc in scs]
+    torch.cuda.synchronize()
+    lanes, serial, orc = rr.ReconIntegrationHip(scs[0], **kw), rr.ReconIntegrationHip(scs[0], **kw), OracleRecon(scs[0], **kw)
+    serial.set_stage_overlap(False)
+    lanes.set_preprocess_calibration(scs[0])
+    order = [0, 1, 2, 1, 0, 2, 2, 1]
+    for n, k in enumerate(order):
+        lanes.frame_raw_dev(mvs[n % 3], pr, new_frame=(dev[k][0].data_ptr(), dev[k][1].data_ptr()), complete=True)      # nothing is read until the end
+    for n, k in enumerate(order):
+        serial.upload_raw_frame(scs[k]); serial.clearOccupiedBricks(); serial.processTextures(); serial.updateOccupiedBricks(False); serial.integrate(); serial.drawF(mvs[n % 3], pr)
+        orc.upload_raw_frame(scs[k]); orc.clearOccupiedBricks(); orc.processTextures(); orc.updateOccupiedBricks(); orc.integrate(); orc.drawF(mvs[n % 3], pr)
+    a, b, o = lanes.preprocessed(), serial.preprocessed(), orc.preprocessed()
+    for key in a:
+        assert_same(a[key], b[key], f"{key}: lanes vs one stream")
+    np.testing.assert_array_equal(lanes.bricks()[0], serial.bricks()[0])
+    assert_same(lanes.tsdf(), serial.tsdf(), "volume: lanes vs one stream")
+    (lc, ld), (sc_, sd), (oc, od) = lanes.framebuffer(), serial.framebuffer(), orc.framebuffer()
+    assert_same(ld, sd, "framebuffer depth: lanes vs one stream"); assert_same(lc, sc_, "framebuffer colour: lanes vs one stream")
+    for key in ("depth2", "depth_rg", "depth_b", "silhouette", "normals"):
+        assert_same(b[key], o[key], f"{key} vs oracle")
+    np.testing.assert_array_equal(serial.bricks()[0], orc.counters())
+    assert tsdf_close(serial.tsdf(), orc.tsdf(), kw["limit"]).all()
+    assert ((sd < 1) != (od < 1)).mean() <= 2e-3 and (sd < 1).sum() > 100
