@@ -177,7 +177,7 @@ def main():
     args = ap.parse_args()
     if args.ingest:
         args.preprocess = True
-    if args.preprocess or args.frames_in_flight > 1:
+    if args.ingest or args.frames_in_flight > 1:
         args.scene = "static"
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner from inside
@@ -272,6 +272,9 @@ def main():
     # the frames as they arrive lie in HBM before anything is timed and every step re-lays one of them out (tsdf_upload_frame_dev) --
     # except in the pre-processing / ingest modes (they produce the images themselves) and the frames-in-flight throughput mode
     repack = not (args.preprocess or args.frames_in_flight > 1)
+    # --preprocess (round 4): the RAW frames (depth in metres, RGB8) lie in HBM and every step hands the other one to tsdf_frame_raw_dev -- the moving
+    # scene through processTextures() on the lane ahead, as `value`'s loop does with pre-processed frames
+    raw_repack = args.preprocess and not args.ingest and args.frames_in_flight == 1 and not (world > 1 or alone)
 
     def make_ctx(slab=(0, 0), recompute=False, sparse=0):
         h = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=VIEW, device=local, slab=slab,
@@ -279,18 +282,20 @@ def main():
         h.setUseBricks(cfg["use_bricks"]); h.setSpaceSkip(cfg["skip_space"]); h.setColorFilling(cfg["fill_holes"])
         if args.frames_in_flight > 1:
             h.set_stage_overlap(False)                    # several contexts already overlap whole frames: one stream each (three lanes each would fight over the hardware queues)
-        if not repack:                                    # the second resident frame (modes without a per-frame re-layout alternate the two frame slots;
+        if not repack and not raw_repack:                 # the second resident frame (modes without a per-frame re-layout alternate the two frame slots;
             for k, sc in enumerate(scenes[1:], 1):        #  an explicit frame-slot call switches the context's lane ahead off for good)
                 h.select_frame_slot(k); h.upload_frame(sc)
             h.select_frame_slot(0)
         return h
 
+    mem_free_before = torch.cuda.mem_get_info(local)[0]
     hip = make_ctx(slab, args.halo == "recompute" and slabs_mode, args.sparse_pool)
     # ONE explicit torch stream carries the context's kernels, the HIP event timers and the collectives (multigpu.py: the handle
     # of torch's default stream is 0 and cannot be handed over)
     stream = torch.cuda.Stream()
     if args.preprocess:
         hip.upload_raw_frame(scene)
+        hip.sync()
     drv = mg.SlabDriver(hip, rank, world, f"cuda:{local}", view=VIEW, halo=args.halo, composite=args.composite,
                         preprocess=args.preprocess, exchange_when_alone=alone, stream=stream, compositor="dedicated" if dedicated else "shared",
                         native=slabs_mode and args.exchange == "native")
@@ -303,6 +308,13 @@ def main():
             raw.append((ts, tuple(t.data_ptr() for t in ts)))
         torch.cuda.synchronize()
 
+    raw_dev = []
+    if raw_repack:
+        for sc in scenes:
+            ts = [torch.from_numpy(np.ascontiguousarray(sc["depth_raw"], np.float32)).to(f"cuda:{local}"), torch.from_numpy(np.ascontiguousarray(sc["color"], np.uint8)).to(f"cuda:{local}")]
+            raw_dev.append((ts, tuple(t.data_ptr() for t in ts)))
+        torch.cuda.synchronize()
+
     bcast = slabs_mode and repack and args.frames == "broadcast"
 
     def step(d, i):
@@ -312,6 +324,9 @@ def main():
             return
         if repack:
             d.frame(mv, pr, new_frame=raw[i % nsc][1])
+            return
+        if raw_repack:
+            d.frame(mv, pr, new_frame=raw_dev[i % nsc][1])
             return
         if nsc > 1:
             d.b.select_frame_slot(i % nsc)
@@ -375,9 +390,41 @@ def main():
         slab_check = (f"rank 0: raymarch colour/depth/sample counts and the hole-filled framebuffer of {nsc} frame(s) bit-identical to an unpartitioned context"
                       + (" (sample counts: at the hit pixels; the compositor does not march, the write-only count image holds 0 or the exact count elsewhere)" if dedicated and args.composite == "compact" else ""))
 
+    # ---- N = 1: what is timed is checked too (VERDICT r03 "next" 6).  Two fresh contexts -- the lanes as shipped, and everything on one stream
+    # (tsdf_set_stage_overlap(0)) -- are fed the same 8 moving frames from the start; the lanes' frames are queued back to back with no read; after
+    # frame 6 and after frame 7 volume, raymarch images and the hole-filled framebuffer must be equal bit for bit, or nothing is timed.
+    lane_check = None
+    if world == 1 and not alone and args.frames_in_flight == 1 and (repack or raw_repack) and os.environ.get("RR_OVERLAP_FILL", "1") != "0":
+        def frame_on(b, i):
+            if repack:
+                b.frame_dev(mv, pr, raw[i % nsc][1])
+            else:
+                b.frame_raw_dev(mv, pr, raw_dev[i % nsc][1])
+        la, se = make_ctx(sparse=args.sparse_pool), make_ctx(sparse=args.sparse_pool)
+        se.set_stage_overlap(False)
+        if raw_repack:
+            la.set_preprocess_calibration(scene); se.set_preprocess_calibration(scene)
+        whole_volume = cfg["res"][0] * cfg["res"][1] * cfg["res"][2] <= (1 << 28)      # (a 1024^3 volume is 4 GiB per download: images only)
+        ok, n_done = True, 0
+        for upto in (7, 8):
+            for i in range(n_done, upto):
+                frame_on(la, i); frame_on(se, i)
+            n_done = upto
+            (a_c, a_d, a_n, _), (a_fc, a_fd) = la.view_images(), la.framebuffer()
+            (b_c, b_d, b_n, _), (b_fc, b_fd) = se.view_images(), se.framebuffer()
+            ok &= same(np, a_c, b_c) and same(np, a_d, b_d) and same(np, a_n, b_n) and same(np, a_fc, b_fc) and same(np, a_fd, b_fd) and int((a_fd < 1).sum()) > 1000
+            if whole_volume:
+                ok &= same(np, la.tsdf(), se.tsdf())
+        la.close(); se.close()
+        del la, se
+        if not ok:
+            raise SystemExit("the four-lane frame loop does NOT reproduce the one-stream frames: refusing to time it")
+        lane_check = ("frames 6 and 7 of 8 moving frames queued back to back through the lanes: " + ("volume, " if whole_volume else "") +
+                      "raymarch colour / depth / sample counts and the hole-filled framebuffer bit-identical to a context with every kernel on one stream")
+
     # host -> device frame upload, outside the timed region (value = HBM-resident rate); reported for the PCIe-inclusive figure
     hip.sync()
-    if not repack:
+    if not repack and not raw_repack:
         hip.select_frame_slot(0)    # scene A's slot (the slab check above leaves the LAST slot current: uploading A there would overwrite frame B)
     tu0 = time.perf_counter()
     for _ in range(5):
@@ -489,13 +536,17 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t)
 
+    # the spread of `value`: four more windows of --steps frames of the same loop (a 20-step window is a 2.5 ms sample)
+    spread = [args.steps / dt] + [args.steps / timed(args.steps, lambda i: step(slots[i % len(slots)], i // len(slots) if len(slots) > 1 else i)) for _ in range(4)]
+    value_spread = {"windows": 5, "min": min(spread), "median": sorted(spread)[2], "max": max(spread),
+                    "note": "frames/s of the timed region and of four more windows of --steps frames right after it"}
     # the static scene (best case of the incremental bookkeeping: nothing churns), same number of steps
     static = None
     resident = None
     if nsc > 1:
         def st(i):
-            drv.frame(mv, pr, new_frame=raw[0][1] if repack else None)
-        if not repack:
+            drv.frame(mv, pr, new_frame=raw[0][1] if repack else (raw_dev[0][1] if raw_repack else None))
+        if not repack and not raw_repack:
             hip.select_frame_slot(0)
         timed(20, st)
         ds = timed(args.steps, st)
@@ -546,6 +597,40 @@ def main():
         dl = timed(args.long_steps, lambda i: step(drv, i))
         long_run = {"steps": args.long_steps, "value": args.long_steps / dl, "ms_per_step": dl / args.long_steps * 1e3,
                     "note": "a second, longer pass of the same loop (the contract's timed region above is exactly --steps)"}
+    # ---- the same loop from the RAW frames (f1, SURVEY.md section 8f: NetKinectArray::processTextures() in front of the path), an extra key, never `value`
+    with_pre = None
+    if world == 1 and not alone and repack and args.frames_in_flight == 1 and not args.sparse_pool:
+        ph = make_ctx()
+        ph.set_preprocess_calibration(scene)
+        rd = []
+        for sc in scenes:
+            ts = [torch.from_numpy(np.ascontiguousarray(sc["depth_raw"], np.float32)).to(f"cuda:{local}"), torch.from_numpy(np.ascontiguousarray(sc["color"], np.uint8)).to(f"cuda:{local}")]
+            rd.append((ts, tuple(t.data_ptr() for t in ts)))
+        torch.cuda.synchronize()
+        for i in range(300):
+            ph.frame_raw_dev(mv, pr, rd[i % nsc][1])
+        ph.sync()
+        tp0 = time.perf_counter()
+        for i in range(args.steps):
+            ph.frame_raw_dev(mv, pr, rd[i % nsc][1])
+        ph.sync()
+        dtp = time.perf_counter() - tp0
+        pre_ms = None
+        if not args.no_timers:
+            ph.set_stage_overlap(False)
+            ph.set_timer_filter(["1preprocess"]); ph.enable_timers(True)
+            for i in range(30):
+                ph.frame_raw_dev(mv, pr, rd[i % nsc][1])
+            ph.sync(); ph.enable_timers(False)
+            n, ms = ph.timer_stats("1preprocess")
+            pre_ms = ms / n if n else None
+        ph.close()
+        del ph, rd
+        with_pre = {"value": args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3, "preprocess_ms": pre_ms,
+                    "note": "tsdf_frame_raw_dev: every step takes the other RAW frame (depth in metres + RGB8, resident in HBM) through pre_morph / pre_depth (13 x 13 bilateral + "
+                            "RGB -> Lab) / pre_boundary / pre_normal (marks the bricks) / pre_quality on the lane ahead, then the frame as in `value`; preprocess_ms: the five "
+                            "passes + the range cells on one stream (HIP events)"}
+    device_mem_bytes = int(mem_free_before - torch.cuda.mem_get_info(local)[0])
     # per-frame device time distribution (SURVEY.md section 8d asks for median and p95): one event pair per frame, own short pass
     frame_ms = None
     if not args.no_timers:
@@ -553,7 +638,7 @@ def main():
         hip.set_timer_filter(["frame"])
         hip.enable_timers(True)
         for i in range(100):
-            if nsc > 1 and not repack:
+            if nsc > 1 and not repack and not raw_repack:
                 hip.select_frame_slot(i % nsc)
             hip.timer_begin("frame"); step(drv, i); hip.timer_end_after_fill("frame")
         barrier()
@@ -595,6 +680,12 @@ def main():
                  else ("lane ahead | the context's stream (integrate, depth limits, march, shade) | fill lane" if overlap else "one stream"),
         "host_issue_ms_per_step": t_issued / args.steps * 1e3,
         "hole_filling": dict(zip(("passes", "by_dirty_tiles"), hip.fill_stats())),
+        "value_spread": value_spread,
+        "lane_check": lane_check,
+        "with_preprocess": with_pre,
+        "device_mem_bytes": device_mem_bytes,
+        "device_mem_note": "device memory taken since just before the context was created (hipMemGetInfo): the context -- with the lanes on, TWO volume sets (tsdf_config / "
+                           "tsdf_set_stage_overlap), two frame slots, two pyramids -- plus this script's resident input frames",
         "three_lanes": three_lanes,
         "serial": serial,
         "static": static,
@@ -612,6 +703,7 @@ def main():
     if slabs_mode:
         out["slab_check"] = slab_check
         out["regathers"] = drv.regathers
+        out["overflowed_frames"] = drv.overflowed_frames   # frames composited from truncated record lists and not repaired: must be 0 (exit code below)
     # N > 1, an extra key, never `value`: what the same N GPUs deliver as N independent single-GPU frame streams (every frame rebuilds
     # the volume from scratch, so frames are independent units: no exchange at all, weak scaling by construction)
     if world > 1:
@@ -792,6 +884,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or alone:
         dist.destroy_process_group()
+    if slabs_mode and drv.overflowed_frames:
+        raise SystemExit(f"{drv.overflowed_frames} frame(s) were composited from truncated hit lists (SlabDriver.frame_status tells which): the rate above counts wrong frames")
 
 
 if __name__ == "__main__":

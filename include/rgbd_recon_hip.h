@@ -348,6 +348,11 @@ int32_t tsdf_composite_gather(tsdf_ctx* ctx);
 int32_t tsdf_composite_finish(tsdf_ctx* ctx, uint32_t* regathered);
 /* gathers that tsdf_composite_finish had to repeat / frames that were composited from truncated record lists (0 in a healthy run) */
 int32_t tsdf_comm_stats(tsdf_ctx* ctx, uint32_t* regathers, uint32_t* overflowed_frames);
+/* Round 4 (VERDICT r03 "next" 5): the per-frame verdict behind `overflowed_frames` -- was frame `frame` (counted from 0 at the first
+ * tsdf_composite_gather) composited from truncated record lists and not repaired?  *truncated 0 = complete, 1 = pixels may be missing.  Known at once
+ * for the latest three frames, from a ring of the last 64 otherwise; TSDF_ERR_STATE = not gathered yet / too old.  The reference has no counterpart
+ * (it renders on one GPU); multigpu.py's SlabDriver.frame_status is the same rule over torch.distributed. */
+int32_t tsdf_comm_frame_status(tsdf_ctx* ctx, uint64_t frame, int32_t* truncated);
 /* bounds of the per-frame gather size guess: at least min_records (default 4096), at most max_records (0: one per view pixel).  The frame
  * never depends on the guess (tsdf_composite_finish repairs a gather that was too small). */
 int32_t tsdf_comm_set_capacity_limits(tsdf_ctx* ctx, uint32_t min_records, uint32_t max_records);

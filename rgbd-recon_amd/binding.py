@@ -587,6 +587,12 @@ class ReconIntegrationHip:
 
     def comm_set_capacity_limits(self, min_records, max_records=0): self._ck(self._L.tsdf_comm_set_capacity_limits(self._c, int(min_records), int(max_records)))
 
+    def comm_frame_status(self, frame):
+        """True: frame `frame` of the native compact composite was built from truncated record lists and not repaired (tsdf_comm_frame_status)"""
+        t = C.c_int32()
+        self._ck(self._L.tsdf_comm_frame_status(self._c, C.c_uint64(int(frame)), C.byref(t)))
+        return bool(t.value)
+
     def comm_stats(self):
         a, b = C.c_uint32(), C.c_uint32()
         self._ck(self._L.tsdf_comm_stats(self._c, C.byref(a), C.byref(b)))

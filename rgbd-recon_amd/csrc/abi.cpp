@@ -662,6 +662,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   for (int a = 0; a < 3; ++a)
     if (!(cfg->bbox_max[a] > cfg->bbox_min[a])) { g_create_error = "empty bounding box"; return TSDF_ERR_INVALID_ARGUMENT; }
   if (cfg->depth_w < 1 || cfg->depth_h < 1 || cfg->color_w < 1 || cfg->color_h < 1) { g_create_error = "image size must be >= 1"; return TSDF_ERR_INVALID_ARGUMENT; }
+  if (cfg->depth_w > 65536 || cfg->depth_h > 65536 || cfg->color_w > 65536 || cfg->color_h > 65536) { g_create_error = "image sides above 65536 are not supported"; return TSDF_ERR_INVALID_ARGUMENT; }
   if ((uint64_t)cfg->depth_w * cfg->depth_h * cfg->num_streams >= (1ull << 24) * 16 || (uint64_t)cfg->depth_w * cfg->depth_h >= (1ull << 24) ||
       (uint64_t)cfg->color_w * cfg->color_h >= (1ull << 24)) { g_create_error = "images of 2^24 pixels or more are not supported (24-bit index arithmetic)"; return TSDF_ERR_INVALID_ARGUMENT; }
   int ndev = 0;
@@ -1104,8 +1105,7 @@ int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t
   const size_t np = (size_t)c->cfg.num_streams * F.w * F.h, nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
   HIP_TRY(c, hipMemcpyAsync(c->d_raw, depth_raw, np * sizeof(float), hipMemcpyHostToDevice, lane));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, lane));
-  launch_pack_color(lane, c->d_stage_col, (uchar4*)F.color, nc);
-  HIP_TRY(c, hipGetLastError());
+  c->pending_rgb = c->d_stage_col;                                       // its RGBA8 re-layout rides along in tsdf_process_textures' first launch
   c->raw_src = c->d_raw; c->have_raw = true;
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
@@ -1125,12 +1125,7 @@ int32_t tsdf_upload_raw_frame_dev(tsdf_ctx* c, const float* depth_raw, const uin
     HIP_TRY(c, hipStreamWaitEvent(lane, c->src_ready, 0));
   }
   if (int32_t rc = begin_slot_write(c, lane, false)) return rc;
-  const FrameImages& F = c->frame;
-  const size_t nc = (size_t)c->cfg.num_streams * F.cw * F.ch;
-  timer_begin_on(c, "0repack", lane);
-  launch_pack_color(lane, colour, (uchar4*)F.color, nc);
-  timer_end_on(c, "0repack", lane);
-  HIP_TRY(c, hipGetLastError());
+  c->pending_rgb = colour;                                               // its RGBA8 re-layout rides along in tsdf_process_textures' first launch
   c->raw_src = depth_raw; c->have_raw = true;
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
@@ -1224,10 +1219,21 @@ int32_t tsdf_upload_wire_frame(tsdf_ctx* c, const void* message, uint64_t bytes,
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
+// the raw frame's colour waits for tsdf_process_textures' first launch (tsdf_ctx::pending_rgb): whoever reads the frame slot's colour before that asks for it here
+static int32_t flush_pending_colour(tsdf_ctx* c) {
+  if (!c->pending_rgb) return TSDF_OK;
+  const hipStream_t lane = pre_enter(c);
+  launch_pack_color(lane, c->pending_rgb, (uchar4*)c->frame.color, (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch);
+  c->pending_rgb = nullptr;
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, pre_leave(c, lane));
+  return TSDF_OK;
+}
 int32_t tsdf_download_raw_frame(tsdf_ctx* c, float* depth_raw, uint8_t* colour_rgba) {
   CHECK_CTX(c);
   if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "no raw frame uploaded");
   HIP_TRY(c, hipSetDevice(c->device));
+  if (int32_t rc = flush_pending_colour(c)) return rc;
   HIP_TRY(c, sync_ctx(c));
   const size_t np = (size_t)c->cfg.num_streams * c->frame.w * c->frame.h, nc = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
   if (depth_raw) HIP_TRY(c, hipMemcpy(depth_raw, c->raw_src, np * 4, hipMemcpyDeviceToHost));
@@ -1263,8 +1269,9 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
   B.depth_rg = c->d_depth_rg; B.lab = c->d_lab; B.depth_b = c->d_depth_b; B.normal = c->d_normal;
   B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
   timer_begin_on(c, "1preprocess", lane);
-  launch_preprocess(lane, P, B, c->luts, c->frame, c->br);
-  launch_frame_ranges(lane, c->frame.dqs, (int)c->cfg.num_streams, c->frame.w, c->frame.h, c->slots[c->cur_slot].ranges);
+  launch_preprocess(lane, P, B, c->luts, c->frame, c->br, c->slots[c->cur_slot].ranges, c->pending_rgb, (uchar4*)c->frame.color,
+                    (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch);
+  c->pending_rgb = nullptr;
   timer_end_on(c, "1preprocess", lane);
   HIP_TRY(c, hipGetLastError());
   c->slots[c->cur_slot].have = true;

@@ -99,6 +99,11 @@ uint32_t max_hits(tsdf_ctx* c, uint64_t f) {
   for (int r = 0; r < c->comm.world; ++r) m = std::max(m, h[2 * r + 1]);
   return (uint32_t)m;
 }
+void set_verdict(tsdf_ctx* c, uint64_t f, bool truncated) {
+  tsdf_ctx::Comm& M = c->comm;
+  const int k = (int)(f % tsdf_ctx::Comm::kVerdicts);
+  M.verdict_frame[k] = f; M.verdict[k] = truncated ? 1 : 0; M.verdict_set[k] = true;
+}
 // records gathered per rank for frame f: 1.5 x the largest per-rank hit count of frame f - kLag (every rank computes the same number).
 // The frame whose counts are read here was gathered with caps[...]: if it hit more rays than that and was not the latest frame when
 // tsdf_composite_finish ran, it was composited from truncated lists -- counted, so that a caller can tell.
@@ -107,7 +112,9 @@ uint32_t capacity_for(tsdf_ctx* c, uint64_t f) {
   const uint32_t npx = M.max_capacity ? std::min(M.max_capacity, (uint32_t)(c->vw * c->vh)) : (uint32_t)(c->vw * c->vh);
   if (f < (uint64_t)kLag) return npx;                                   // no history yet: a slab cannot hit more rays than there are pixels
   const uint32_t m = max_hits(c, f - kLag);
-  if (m > M.caps[(f - kLag) % kRing]) ++M.overflowed_frames;
+  const bool truncated = m > M.caps[(f - kLag) % kRing];               // (tsdf_composite_finish raises the capacity of a frame it repairs)
+  if (truncated) ++M.overflowed_frames;
+  set_verdict(c, f - kLag, truncated);
   const uint32_t cap = std::max(M.min_capacity, ((m * 3u) / 2u + 1024u + 1023u) / 1024u * 1024u);
   return std::min(cap, npx);
 }
@@ -201,6 +208,26 @@ int32_t tsdf_comm_set_capacity_limits(tsdf_ctx* c, uint32_t min_records, uint32_
   c->comm.min_capacity = min_records; c->comm.max_capacity = max_records;
   return TSDF_OK;
 }
+// Was frame `frame` (0 = the first tsdf_composite_gather of this communicator's buffers) composited from TRUNCATED record lists and left that way?
+// A gather is sized from the hit counts of two frames earlier; a frame that hit more rays than that is repaired by tsdf_composite_finish only while
+// it is the latest frame.  *truncated: 0 = complete (or repaired), 1 = pixels of that frame may be missing (a caller that kept it must redraw).
+// The verdict of a frame is known once its counts have reached the host: at once for the latest three frames (the call waits for the pinned copy),
+// from a ring of the last 64 frames otherwise; TSDF_ERR_STATE: not gathered yet, or too old.
+int32_t tsdf_comm_frame_status(tsdf_ctx* c, uint64_t frame, int32_t* truncated) {
+  NEED_COMM(c);
+  if (!truncated) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "null argument");
+  tsdf_ctx::Comm& M = c->comm;
+  if (frame >= M.frame_no) FAIL(c, TSDF_ERR_STATE, "frame %llu has not been gathered yet (%llu frames so far)", (unsigned long long)frame, (unsigned long long)M.frame_no);
+  const int k = (int)(frame % tsdf_ctx::Comm::kVerdicts);
+  if (M.verdict_set[k] && M.verdict_frame[k] == frame) { *truncated = M.verdict[k]; return TSDF_OK; }
+  if (frame + kRing >= M.frame_no) {                                     // its counts are still in the ring of pinned copies
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool t = max_hits(c, frame) > M.caps[frame % kRing];
+    *truncated = t ? 1 : 0;                                              // (not stored: the latest frame may still be repaired by tsdf_composite_finish)
+    return TSDF_OK;
+  }
+  FAIL(c, TSDF_ERR_STATE, "the verdict of frame %llu is no longer kept (the last %d frames are)", (unsigned long long)frame, tsdf_ctx::Comm::kVerdicts);
+}
 int32_t tsdf_comm_stats(tsdf_ctx* c, uint32_t* regathers, uint32_t* overflowed_frames) {
   NEED_COMM(c);
   if (regathers) *regathers = c->comm.regathers;
@@ -276,6 +303,7 @@ int32_t tsdf_composite_gather(tsdf_ctx* c) {
       HIP_TRY(c, hipEventCreateWithFlags(&M.counts_evt[k], hipEventDisableTiming));
     }
     M.hit_floats = hf; M.frame_no = 0; M.have_last = false;
+    for (bool& b : M.verdict_set) b = false;
   }
   const uint64_t f = M.frame_no;
   const uint32_t cap = capacity_for(c, f);
@@ -302,6 +330,7 @@ int32_t tsdf_composite_finish(tsdf_ctx* c, uint32_t* regathered) {
       if (int32_t rc = exchange_hits(c, cap, false, M.last_frame)) return rc;
       M.caps[M.last_frame % kRing] = cap;
     }
+    set_verdict(c, M.last_frame, false);                                 // complete: gathered in full, or repaired just now
   }
   HIP_TRY(c, sync_ctx(c));
   return TSDF_OK;

@@ -79,6 +79,7 @@ struct tsdf_ctx {
   PreParams pre{};
   float* d_raw = nullptr; float* d_depth2 = nullptr; float2* d_depth_rg = nullptr; float4* d_lab = nullptr; float2* d_depth_b = nullptr; float4* d_normal = nullptr;
   bool have_raw = false, use_processed_depth = true;
+  const uint8_t* pending_rgb = nullptr;   // RGB8 colour of the raw frame uploaded last, still to be re-laid out into the frame slot (rides along in processTextures' first launch)
   const float* raw_src = nullptr;   // the raw depth the passes read: d_raw (host upload, wire unpack) or the caller's device array (tsdf_upload_raw_frame_dev)
   hipEvent_t normals_read = nullptr; bool normals_read_pending = false;   // recorded behind a point / triangle-grid draw: the lane ahead rewrites d_normal
   bool have_limits[TSDF_MAX_STREAMS]{}, have_cam[TSDF_MAX_STREAMS]{};
@@ -180,6 +181,9 @@ struct tsdf_ctx {
     uint32_t caps[3] = {0, 0, 0};             // capacity each of the ring's frames was gathered with
     uint64_t frame_no = 0; bool have_last = false; uint64_t last_frame = 0; uint32_t last_cap = 0;
     uint32_t regathers = 0, overflowed_frames = 0, min_capacity = 4096, max_capacity = 0;   // max_capacity: 0 = one record per pixel
+    // per-frame verdict of the compact composite (tsdf_comm_frame_status): 1 = the frame was composited from truncated record lists and not repaired
+    static constexpr int kVerdicts = 64;
+    uint64_t verdict_frame[kVerdicts] = {}; uint8_t verdict[kVerdicts] = {}; bool verdict_set[kVerdicts] = {};
     float* d_frame_stage = nullptr; size_t frame_stage_bytes = 0;                          // tsdf_broadcast_frame: the four arrays as delivered
   } comm;
   bool timers_on = false;

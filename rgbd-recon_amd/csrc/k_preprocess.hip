@@ -10,12 +10,41 @@
 namespace rr {
 
 __device__ __forceinline__ int clamp_tap(int v, int n) { return min(max(v, 0), n - 1); }
-// NEAREST fetch at pass_TexCoord + (dx,dy)*texSizeInv, written with the same fp32 coordinate arithmetic as the shader
-__device__ __forceinline__ int tap_x(int x, int dx, int W) { return axis_nearest(((float)x + 0.5f) / (float)W + (float)dx * (1.0f / (float)W), W); }
-__device__ __forceinline__ int tap_y(int y, int dy, int H) { return axis_nearest(((float)y + 0.5f) / (float)H + (float)dy * (1.0f / (float)H), H); }
+// NEAREST fetch at pass_TexCoord + (dx,dy)*texSizeInv = texel clamp(x + dx), clamp(y + dy): the coordinate (x + .5) / W + dx * (1 / W), evaluated in
+// fp32 as the shader does, is within W * 3e-7 texels of the centre of texel x + dx -- half a texel away from any border for every image this
+// library accepts (tsdf_create: sides <= 65536) --, so floor(u * W) needs no float arithmetic (round 3 evaluated two IEEE divisions per tap)
+__device__ __forceinline__ int tap_x(int x, int dx, int W) { return clamp_tap(x + dx, W); }
+__device__ __forceinline__ int tap_y(int y, int dy, int H) { return clamp_tap(y + dy, H); }
 
 // ---- pre_morph.fs: mode 0 = dilate(coords, 1) (:73-112, :123-127); mode 1 is a copy (:130-131)
-__global__ __launch_bounds__(256) void k_pre_morph(PreParams P, PreBuffers B) {
+// Two more layers of blocks ride along (round 4: what used to be launches of their own in front of the passes): layer N turns the frame's RGB8 colour
+// into the RGBA8 the kernels read (four pixels per thread, as k_pack_frame_fused does), layer N + 1 zeroes the brick counters clearOccupiedBricks()
+// flipped to.  Null pointers: nothing to do.
+struct PreExtra { const uint8_t* rgb; uchar4* rgba; uint32_t n_px; uint4* zero; uint32_t zero_quads; };
+__global__ __launch_bounds__(256) void k_pre_morph(PreParams P, PreBuffers B, PreExtra E) {
+  if ((int)blockIdx.z >= P.N) {
+    const uint32_t nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((int)blockIdx.z == P.N) {                                         // ---- colour
+      if (!E.rgb) return;
+      const uint32_t n_quads = (E.n_px + 3u) >> 2;
+      for (uint32_t q = b * blockDim.x + threadIdx.x; q < n_quads; q += nb * blockDim.x) {
+        if (4u * q + 4u > E.n_px) {                                       // the last, partial quad: byte by byte
+          for (uint32_t k = 4u * q; k < E.n_px; ++k) E.rgba[k] = make_uchar4(E.rgb[3 * k], E.rgb[3 * k + 1], E.rgb[3 * k + 2], 255);
+          continue;
+        }
+        const uint3 s3 = ((const uint3*)E.rgb)[q];                        // bytes r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+        uint4 o;
+        o.x = (s3.x & 0x00ffffffu) | 0xff000000u;
+        o.y = (s3.x >> 24) | ((s3.y & 0x0000ffffu) << 8) | 0xff000000u;
+        o.z = (s3.y >> 16) | ((s3.z & 0x000000ffu) << 16) | 0xff000000u;
+        o.w = (s3.z >> 8) | 0xff000000u;
+        ((uint4*)E.rgba)[q] = o;
+      }
+    } else if (E.zero) {                                                  // ---- brick counters
+      for (uint32_t i = b * blockDim.x + threadIdx.x; i < E.zero_quads; i += nb * blockDim.x) E.zero[i] = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), l = blockIdx.z;
   if (x >= P.W || y >= P.H) return;
   const float* __restrict__ src = B.raw + (size_t)l * P.W * P.H;
@@ -180,8 +209,8 @@ __global__ __launch_bounds__(256) void k_pre_normal(PreParams P, PreBuffers B, S
       const StreamLut& L = T.s[l];
       const float3 wp = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, depth);
       mark_brick_ids(BR, wp, own, id_own, nbr, id_nbr);
-      float dt = dp[(size_t)axis_nearest(v + tsy, P.H) * P.W + axis_nearest(u, P.W)], db = dp[(size_t)axis_nearest(v - tsy, P.H) * P.W + axis_nearest(u, P.W)];
-      float dl = dp[(size_t)axis_nearest(v, P.H) * P.W + axis_nearest(u - tsx, P.W)], dr = dp[(size_t)axis_nearest(v, P.H) * P.W + axis_nearest(u + tsx, P.W)];
+      float dt = dp[(size_t)tap_y(y, 1, P.H) * P.W + x], db = dp[(size_t)tap_y(y, -1, P.H) * P.W + x];
+      float dl = dp[(size_t)y * P.W + tap_x(x, -1, P.W)], dr = dp[(size_t)y * P.W + tap_x(x, 1, P.W)];
       dt = (dt <= 0.0f || dt >= 1.0f) ? depth : dt; db = (db <= 0.0f || db >= 1.0f) ? depth : db;
       dl = (dl <= 0.0f || dl >= 1.0f) ? depth : dl; dr = (dr <= 0.0f || dr >= 1.0f) ? depth : dr;
       const float3 wt = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v + tsy, dt), wb = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v - tsy, db);
@@ -196,7 +225,9 @@ __global__ __launch_bounds__(256) void k_pre_normal(PreParams P, PreBuffers B, S
 }
 
 // ---- pre_quality.fs bilateral_filter :65-119 with normal_angle :43-48; same LDS staging as the filter pass
-__global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, StreamTable T) {
+// Round 4: a wave is one 8 x 8-pixel cell of the block's 16 x 16 tile, and the pass -- the last writer of the packed texel -- also leaves the cell's
+// {min depth, max depth, min silhouette, max silhouette} (what k_frame_ranges computed in a launch of its own; same NaN rule).
+__global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, StreamTable T, float4* __restrict__ ranges, int rcw, int rch) {
   __shared__ float s_d[28][29];
   const int l = blockIdx.z, bx = blockIdx.x * 16, by = blockIdx.y * 16;
   const size_t base = (size_t)l * P.W * P.H;
@@ -206,12 +237,13 @@ __global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, 
     s_d[ty][tx] = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
   }
   __syncthreads();
-  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, x = bx + lx, y = by + ly;
-  if (x >= P.W || y >= P.H) return;
+  const int cell = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int lx = ((cell & 1) << 3) + (ln & 7), ly = ((cell >> 1) << 3) + (ln >> 3), x = bx + lx, y = by + ly;
+  const bool inside = x < P.W && y < P.H;
   const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
   const float depth = s_d[ly + 6][lx + 6];
   float q = 0.0f;
-  if (!(depth <= 0.0f || depth >= 1.0f)) {
+  if (inside && !(depth <= 0.0f || depth >= 1.0f)) {
     const float dist_range_max = 0.35f * (depth / 1.0f), dist_range_max_inv = 1.0f / dist_range_max;
     // as in k_pre_filter: unrolled, branch-free; `border` and `num` count taps (integers below 2^24: exact in any order)
     float w_range = 0.0f;
@@ -243,16 +275,33 @@ __global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, 
     const float angle = tc.x * wn.x + tc.y * wn.y + tc.z * wn.z;
     q *= powf(angle, 2.0f);
   }
-  B.dqs[base + (size_t)y * P.W + x].y = q;
+  const float inf = __builtin_inff();
+  float d0 = inf, d1 = -inf, s0 = inf, s1 = -inf;
+  bool nan = false;
+  if (inside) {
+    const size_t o = base + (size_t)y * P.W + x;
+    const float sil = B.dqs[o].z;                                       // (the boundary pass wrote {depth, 0, silhouette, 0})
+    B.dqs[o] = make_float4(depth, q, sil, 0.0f);
+    d0 = d1 = depth; s0 = s1 = sil;
+    nan = (depth != depth) || (sil != sil);
+  }
+  if (ranges) {
+    d0 = wave_min_f32(d0); d1 = wave_max_f32(d1); s0 = wave_min_f32(s0); s1 = wave_max_f32(s1);
+    if (__ballot(nan) != 0ull) { d0 = s0 = -inf; d1 = s1 = inf; }          // a NaN anywhere poisons the cell's range (k_frame_ranges)
+    const int cx = (bx >> 3) + (cell & 1), cy = (by >> 3) + (cell >> 1);
+    if (ln == 0 && cx < rcw && cy < rch) ranges[((size_t)l * rch + cy) * rcw + cx] = make_float4(d0, d1, s0, s1);
+  }
 }
 
-void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR) {
+void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR, float4* ranges,
+                       const uint8_t* rgb, uchar4* rgba, size_t n_color_px, uint32_t* zero, uint32_t zero_words) {
   const dim3 rows((P.W + 63) / 64, (P.H + 3) / 4, P.N), tiles((P.W + 15) / 16, (P.H + 15) / 16, P.N);
-  hipLaunchKernelGGL(k_pre_morph, rows, dim3(256), 0, st, P, B);
+  const PreExtra E{rgb, rgba, (uint32_t)n_color_px, (uint4*)zero, zero_words >> 2};
+  hipLaunchKernelGGL(k_pre_morph, dim3(rows.x, rows.y, P.N + ((rgb || zero) ? 2 : 0)), dim3(256), 0, st, P, B, E);
   hipLaunchKernelGGL(k_pre_filter, tiles, dim3(256), 0, st, P, B, T, F);
   hipLaunchKernelGGL(k_pre_boundary, rows, dim3(256), 0, st, P, B);
   hipLaunchKernelGGL(k_pre_normal, rows, dim3(256), 0, st, P, B, T, BR);
-  hipLaunchKernelGGL(k_pre_quality, tiles, dim3(256), 0, st, P, B, T);
+  hipLaunchKernelGGL(k_pre_quality, tiles, dim3(256), 0, st, P, B, T, ranges, (P.W + 7) / 8, (P.H + 7) / 8);
 }
 
 }  // namespace rr

@@ -204,7 +204,10 @@ struct WireLayout {
   int cfmt, dfmt;         // TSDF_COLOR_* / TSDF_DEPTH_*
 };
 void launch_wire_unpack(hipStream_t st, const WireLayout& L, uchar4* rgba, float* raw);
-void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR);
+// ranges: the frame slot's 8x8-pixel range cells (written by the last pass), or null; rgb -> rgba (n_color_px pixels) and zero (zero_words words, a multiple of
+// 4): the frame's colour re-layout and the brick counters' clear riding along in the first launch, or null
+void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR, float4* ranges,
+                       const uint8_t* rgb = nullptr, uchar4* rgba = nullptr, size_t n_color_px = 0, uint32_t* zero = nullptr, uint32_t zero_words = 0);
 
 // launchers (one per kernel family, defined in the .hip files)
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);

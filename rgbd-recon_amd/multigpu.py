@@ -140,6 +140,7 @@ class SlabDriver:
         self.regathers = 0                    # frames whose first gather was too small (finish() repaired them)
         self.min_capacity = int(min_capacity)
         self.overflowed_frames = 0            # frames that were composited from truncated record lists and were no longer the latest when finish() ran
+        self.verdicts = {}                    # frame -> was it left truncated (frame_status)
         if self.exchanging and self.native:
             ids = [backend.comm_unique_id() if rank == 0 else None]
             if world > 1:
@@ -218,11 +219,30 @@ class SlabDriver:
         if f < self.LAG:
             return self.npx                                # no history yet: a slab cannot hit more rays than there are pixels
         m = int(self._counts_of(f - self.LAG)[:, 1].max())
-        if m > self.caps.get(f - self.LAG, self.npx):      # that frame hit more rays than were gathered (finish() repairs the LATEST frame only)
+        truncated = m > self.caps.get(f - self.LAG, self.npx)   # that frame hit more rays than were gathered (finish() repairs the LATEST frame only)
+        if truncated:
             self.overflowed_frames += 1
+        self._set_verdict(f - self.LAG, truncated)
         self.caps.pop(f - self.LAG, None)
         cap = max(self.min_capacity, ((m * 3) // 2 + 1024 + 1023) // 1024 * 1024)
         return min(cap, self.npx)
+
+    def _set_verdict(self, f, truncated):
+        self.verdicts[f] = bool(truncated)
+        self.verdicts.pop(f - 64, None)                    # the last 64 frames are kept (comm.cpp keeps the same ring)
+
+    def frame_status(self, f):
+        """True: frame f (counted from 0) of the compact composite was built from truncated record lists and not repaired -- a caller that kept
+        that frame must redraw it.  Known at once for the latest LAG + 1 frames (waits for their counts), from the last 64 verdicts otherwise;
+        KeyError: not gathered yet / too old.  (tsdf_comm_frame_status is the same rule inside the library.)"""
+        if self.exchanging and self.native:
+            return self.b.comm_frame_status(f)
+        if f in self.verdicts:
+            return self.verdicts[f]
+        if f < self.frame_no and f + self.LAG + 1 >= self.frame_no:
+            cap = self.caps.get(f, self.last[1] if self.last is not None and self.last[0] == f else self.npx)
+            return int(self._counts_of(f)[:, 1].max()) > cap
+        raise KeyError(f"no verdict for frame {f} ({self.frame_no} frames gathered)")
 
     def _exchange_hits(self, cap, record_counts_of=None):
         """record_counts_of: the frame number on the frame's first exchange, None on a repeated one (finish()).  Rank 0's own records never
@@ -292,8 +312,14 @@ class SlabDriver:
         if self.is_worker and not self.exchanging and not self.preprocess:   # one rank, nothing to exchange: the whole frame in one call into the library
             b.frame_dev(mv, proj, new_frame)
             return
+        if self.is_worker and not self.exchanging and self.preprocess and new_frame is not None:   # ... and from the RAW frame (depth_raw, colour)
+            b.frame_raw_dev(mv, proj, new_frame)
+            return
         if self.is_worker and new_frame is not None:
-            b.upload_frame_dev(*new_frame, complete=True)
+            if self.preprocess:
+                b.upload_raw_frame_dev(*new_frame, complete=True)
+            else:
+                b.upload_frame_dev(*new_frame, complete=True)
         if self.is_worker:
             b.clearOccupiedBricks()
             if self.preprocess:
@@ -351,6 +377,7 @@ class SlabDriver:
                 self.caps[f] = min(self.npx, m)
                 with self._on_stream():
                     self._exchange_hits(min(self.npx, m))
+            self._set_verdict(f, False)                      # complete: gathered in full, or repaired just now
         if self.stream is not None:
             self.stream.synchronize()
         elif hasattr(self.b, "sync"):

@@ -19,8 +19,10 @@ VIEW = (8, 4)
 class FakeSlab:
     """Owns `own` tile layers plus `halo` layers either side (where a neighbour exists), like tsdf_ctx."""
 
-    def __init__(self, rank, world, own=3, halo=1):
+    def __init__(self, rank, world, own=3, halo=1, layer0=None, view=None):
         self.rank, self.world, self.own, self.halo = rank, world, own, halo
+        self.layer0 = rank * own if layer0 is None else layer0      # first global tile layer of the slab (uneven slabs pass it)
+        self.view = VIEW if view is None else view
         self.lo = halo if rank > 0 else 0
         self.hi = halo if rank < world - 1 else 0
         self.vol = np.full((self.lo + own + self.hi, TILE_LAYER), np.nan, np.float32)
@@ -36,7 +38,7 @@ class FakeSlab:
 
     def integrate(self):
         for l in range(self.own):                       # value encodes (global layer, voxel)
-            self.vol[self.lo + l] = (self.rank * self.own + l) * 1000.0 + np.arange(TILE_LAYER) % 7
+            self.vol[self.lo + l] = (self.layer0 + l) * 1000.0 + np.arange(TILE_LAYER) % 7
         self.calls.append("integrate")
 
     def halo_info(self): return self.halo, self.halo * TILE_LAYER * 4
@@ -54,7 +56,7 @@ class FakeSlab:
             ctypes.memmove(self.vol[self.lo + self.own:].ctypes.data, above_ptr, n)
 
     def draw(self, mv, proj):
-        npx = VIEW[0] * VIEW[1]
+        npx = self.view[0] * self.view[1]
         p = np.arange(npx)
         owner_hits = (p % 3 != 2)                       # a third of the pixels miss everywhere
         ns = np.where(owner_hits & (p % self.world == self.rank), (p + 1) * 0.0027, -(40 * 0.0027)).astype(np.float32)
@@ -67,7 +69,7 @@ class FakeSlab:
         ctypes.memmove(ptr, self.partial.ctypes.data, self.partial.nbytes)
 
     def composite_dev(self, ptr, n):
-        npx = VIEW[0] * VIEW[1]
+        npx = self.view[0] * self.view[1]
         buf = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_float)), shape=(n, npx * 6)).copy()
         ns = buf[:, npx * 5:]
         pos = np.where(ns > 0, ns, np.inf)
@@ -79,7 +81,7 @@ class FakeSlab:
 
     # compact exchange (tsdf_export_hits_dev / tsdf_composite_hits_dev): 32-byte header {written, hit, overflow} + 32-byte records
     def export_hits_dev(self, ptr, cap):
-        npx = VIEW[0] * VIEW[1]
+        npx = self.view[0] * self.view[1]
         ns = self.partial[npx * 5:]
         pix = np.nonzero(ns > 0)[0]
         if self.extra_hits:                                # frames with many more hits than the history predicts
@@ -97,7 +99,7 @@ class FakeSlab:
         self.exports.append((cap, int(pix.size)))
 
     def composite_hits_dev(self, ptr, n, stride_bytes):
-        npx = VIEW[0] * VIEW[1]
+        npx = self.view[0] * self.view[1]
         best = np.full(npx, np.inf)
         rank_of = np.full(npx, -1)
         colour = np.zeros(npx)
@@ -254,7 +256,7 @@ def test_capacity_rule():
     class D(mgpu.SlabDriver):
         def __init__(self, counts, npx, min_capacity):
             self.npx, self.min_capacity, self._c = npx, min_capacity, counts
-            self.caps, self.overflowed_frames = {}, 0
+            self.caps, self.overflowed_frames, self.verdicts = {}, 0, {}
 
         def _counts_of(self, f):
             return torch.tensor(self._c[f], dtype=torch.int32)
@@ -347,3 +349,81 @@ def test_balanced_slab_ranges():
         assert max(cost) <= 1.6 * sum(w) / world                              # no slab much heavier than its share
     assert mgpu.balanced_slab_ranges([0] * 63 + [1], 4, 512) == [(0, 488), (488, 496), (496, 504), (504, 512)]   # every slab at least one layer
     assert mgpu.balanced_slab_ranges([1, 1, 1], 3, 20) == [(0, 8), (8, 16), (16, 20)]
+
+
+# ------------------------------------------------------------------------------------------------ the shape of the first real run: world = 8
+VIEW8 = (128, 64)          # 8192 pixels: large enough that the capacity rule (1.5 x hits + 1024, rounded to 1024) gathers LESS than every pixel
+
+
+def _world8_worker(rank, world, port, q, halo, layers):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mgpu = import_module("rgbd-recon_amd.multigpu")
+        workers = world - 1
+        z0, z1 = mgpu.worker_slab_range(layers * 8, rank, world)        # uneven: 64 or 128 tile layers do not divide by 7
+        own = (z1 - z0) // 8
+        fake = FakeSlab(max(rank - 1, 0), workers, own=own, layer0=z0 // 8, view=VIEW8)
+        drv = mgpu.SlabDriver(fake, rank, world, "cpu", view=VIEW8, halo=halo, composite="compact", min_capacity=4, compositor="dedicated")
+        npx = VIEW8[0] * VIEW8[1]
+        p = np.arange(npx)
+        hits = p % 3 != 2
+
+        def check():
+            r = fake.result
+            return bool((r["rank_of_pixel"][hits] == (p % workers + 1)[hits]).all()) and bool((r["rank_of_pixel"][~hits] == -1).all()) and \
+                bool(np.allclose(r["ns"][hits], ((p + 1) * 0.0027)[hits])) and bool((r["colour"][hits] == (p % workers + 1)[hits]).all())
+
+        ok = True
+        for _ in range(4):
+            drv.frame(None, None)
+        drv.finish()
+        caps = [c for c, _ in fake.exports]
+        if rank > 0:
+            ok &= caps[:2] == [npx, npx] and all(c < npx for c in caps[2:])   # from frame LAG on the gather is sized from the history
+            ok &= fake.calls[-5:] == ["clear", "mark", "update", "integrate", "draw"]
+            if halo == "exchange":                                            # neighbours are worker ranks only
+                w = rank - 1
+                if w > 0:
+                    ok &= bool((fake.vol[0] == ((fake.layer0 - 1) * 1000.0 + np.arange(TILE_LAYER) % 7)).all())
+                if w < workers - 1:
+                    ok &= bool((fake.vol[-1] == ((fake.layer0 + own) * 1000.0 + np.arange(TILE_LAYER) % 7)).all())
+                ok &= not np.isnan(fake.vol).any()
+        else:
+            ok &= check() and set(fake.calls) == {"composite", "fill"}
+        ok &= drv.regathers == 0 and drv.overflowed_frames == 0 and not any(drv.frame_status(f) for f in range(4))
+        # frame 4: worker rank 3 hits far more rays than the history predicts.  Not the latest when finish() runs -> composited from truncated lists:
+        # counted AND marked (VERDICT r03 "next" 5: no silently wrong frame).  Frame 7 overflows too but IS the latest: finish() re-gathers it.
+        for f in range(4, 8):
+            fake.extra_hits = 4000 if (rank == 3 and f in (4, 7)) else 0
+            drv.frame(None, None)
+        drv.finish()
+        ok &= drv.regathers == 1
+        if rank == 0:
+            ok &= check()                                                     # the repaired frame 7
+        fake.extra_hits = 0
+        for f in range(8, 11):
+            drv.frame(None, None)
+        drv.finish()
+        ok &= drv.overflowed_frames == 1 and drv.regathers == 1
+        ok &= [drv.frame_status(f) for f in range(4, 11)] == [True, False, False, False, False, False, False]
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("halo,layers", [("recompute", 64), ("exchange", 128)])
+def test_world_8_dedicated_compositor_uneven_slabs_gloo(halo, layers):
+    """world = 8 as the first real run will have it: rank 0 composites, ranks 1-7 hold uneven Z-slabs of the 64 (512^3) / 128 (1024^3) tile
+    layers; both halo modes; a frame that overflows its gather while it is not the latest is counted and marked, one that is the latest is repaired."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, 8, port, q, halo, layers)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(1200)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(8)) == {r: True for r in range(8)}
