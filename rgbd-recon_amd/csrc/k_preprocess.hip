@@ -101,26 +101,38 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
   const float* __restrict__ src = B.fdepth + (size_t)l * P.W * P.H;
   const bool compress = P.compress[l] != 0;                      // sample() / uncompress(), pre_depth.fs:51-72
   const float sn = P.dc_scaled_near[l], scale = P.dc_scale[l], nearv = P.dc_near[l];
-  for (int i = threadIdx.x; i < 28 * 28; i += 256) {
-    const int ty = i / 28, tx = i % 28;
-    float t = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
+  const auto sample = [&](int yy, int xx) {
+    float t = src[(size_t)clamp_tap(yy, P.H) * P.W + clamp_tap(xx, P.W)];
     if (compress) t = t < sn ? 0.0f : (t * t + 0.15f * sn) * scale + nearv;
-    s_d[ty][tx] = t;
-  }
-  __syncthreads();
+    return t;
+  };
   const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, x = bx + lx, y = by + ly;
-  if (x >= P.W || y >= P.H) return;
+  const bool inside = x < P.W && y < P.H;
   const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
   const float mn = P.cv_min[l], mx = P.cv_max[l];
-  const float depth = s_d[ly + 6][lx + 6];
+  // the pixel's own part first (world position -> inside the bounding box?, Lab colour): the 13 x 13 window is staged in LDS only when some pixel of
+  // the block lies in the box -- most blocks of a frame see background, and their 784 window loads and the barrier bought nothing (round 4)
+  const float depth = inside ? sample(y, x) : 0.0f;
   const float dn = (depth - mn) / (mx - mn);
   const StreamLut& L = T.s[l];
-  const float3 wp = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, dn);
-  const bool in_box = wp.x >= P.bbox_min[0] && wp.y >= P.bbox_min[1] && wp.z >= P.bbox_min[2] && wp.x <= P.bbox_max[0] && wp.y <= P.bbox_max[1] && wp.z <= P.bbox_max[2];
-  const float2 cc = tex3d_rg(L.uv, L.uv_res, u, v, (dn <= 0.0f || dn >= 1.0f) ? 1.0f : dn);     // :136
-  const float3 lab = rgb_to_lab(color_bilinear_pre(F, l, cc.x, cc.y));
+  bool in_box = false;
   const size_t o = (size_t)l * P.W * P.H + (size_t)y * P.W + x;
-  B.lab[o] = make_float4(lab.x, lab.y, lab.z, 0.0f);
+  if (inside) {
+    const float3 wp = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, dn);
+    in_box = wp.x >= P.bbox_min[0] && wp.y >= P.bbox_min[1] && wp.z >= P.bbox_min[2] && wp.x <= P.bbox_max[0] && wp.y <= P.bbox_max[1] && wp.z <= P.bbox_max[2];
+    const float2 cc = tex3d_rg(L.uv, L.uv_res, u, v, (dn <= 0.0f || dn >= 1.0f) ? 1.0f : dn);     // :136
+    const float3 lab = rgb_to_lab(color_bilinear_pre(F, l, cc.x, cc.y));
+    B.lab[o] = make_float4(lab.x, lab.y, lab.z, 0.0f);
+  }
+  const bool taps = __syncthreads_or(in_box && P.filter_textures) != 0;   // (workgroup-uniform)
+  if (taps) {
+    for (int i = threadIdx.x; i < 28 * 28; i += 256) {
+      const int ty = i / 28, tx = i % 28;
+      s_d[ty][tx] = sample(by + ty - 6, bx + tx - 6);
+    }
+    __syncthreads();
+  }
+  if (!inside) return;
   float2 od = make_float2(0.0f, 0.0f);
   if (in_box) {
     if (!P.filter_textures) od = make_float2(dn, 1.0f);
@@ -232,18 +244,22 @@ __global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, 
   const int l = blockIdx.z, bx = blockIdx.x * 16, by = blockIdx.y * 16;
   const size_t base = (size_t)l * P.W * P.H;
   const float* __restrict__ src = B.depth_plane + base;
-  for (int i = threadIdx.x; i < 28 * 28; i += 256) {
-    const int ty = i / 28, tx = i % 28;
-    s_d[ty][tx] = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
-  }
-  __syncthreads();
   const int cell = threadIdx.x >> 6, ln = threadIdx.x & 63;
   const int lx = ((cell & 1) << 3) + (ln & 7), ly = ((cell >> 1) << 3) + (ln >> 3), x = bx + lx, y = by + ly;
   const bool inside = x < P.W && y < P.H;
   const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
-  const float depth = s_d[ly + 6][lx + 6];
+  const float depth = inside ? src[(size_t)y * P.W + x] : 0.0f;
+  const bool valid = inside && !(depth <= 0.0f || depth >= 1.0f);
+  // the window is staged only when some pixel of the block holds a depth (as in k_pre_filter)
+  if (__syncthreads_or(valid) != 0) {
+    for (int i = threadIdx.x; i < 28 * 28; i += 256) {
+      const int ty = i / 28, tx = i % 28;
+      s_d[ty][tx] = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
+    }
+    __syncthreads();
+  }
   float q = 0.0f;
-  if (inside && !(depth <= 0.0f || depth >= 1.0f)) {
+  if (valid) {
     const float dist_range_max = 0.35f * (depth / 1.0f), dist_range_max_inv = 1.0f / dist_range_max;
     // as in k_pre_filter: unrolled, branch-free; `border` and `num` count taps (integers below 2^24: exact in any order)
     float w_range = 0.0f;
