@@ -276,9 +276,9 @@ def main():
     # scene through processTextures() on the lane ahead, as `value`'s loop does with pre-processed frames
     raw_repack = args.preprocess and not args.ingest and args.frames_in_flight == 1 and not (world > 1 or alone)
 
-    def make_ctx(slab=(0, 0), recompute=False, sparse=0):
+    def make_ctx(slab=(0, 0), recompute=False, sparse=0, lane_flags=0):
         h = rr.ReconIntegrationHip(scene, res=cfg["res"], brick_size=brick, limit=LIMIT, view=VIEW, device=local, slab=slab,
-                                   recompute_halo=recompute, sparse_pool_tiles=sparse)
+                                   recompute_halo=recompute, sparse_pool_tiles=sparse, lane_flags=lane_flags)
         h.setUseBricks(cfg["use_bricks"]); h.setSpaceSkip(cfg["skip_space"]); h.setColorFilling(cfg["fill_holes"])
         if args.frames_in_flight > 1:
             h.set_stage_overlap(False)                    # several contexts already overlap whole frames: one stream each (three lanes each would fight over the hardware queues)
@@ -578,9 +578,7 @@ def main():
     # the same loop without the integrate lane (RR_DEEP=0 at creation: integrate() on the context's stream, one volume -- three lanes)
     three_lanes = None
     if nsc > 1 and repack and not slabs_mode and overlap and os.environ.get("RR_DEEP", "1") != "0":
-        os.environ["RR_DEEP"] = "0"
-        th = make_ctx(sparse=args.sparse_pool)
-        del os.environ["RR_DEEP"]
+        th = make_ctx(sparse=args.sparse_pool, lane_flags=rr.LANES_NO_INTEGRATE_LANE)
         for i in range(300):
             th.frame_dev(mv, pr, raw[i % nsc][1])
         th.sync()
@@ -591,7 +589,7 @@ def main():
         dtl = time.perf_counter() - tt0
         th.close()
         three_lanes = {"value": args.steps / dtl, "ms_per_step": dtl / args.steps * 1e3,
-                       "note": "a context created with RR_DEEP=0: lane ahead + the context's stream (integrate, march, shade) + fill lane, one volume"}
+                       "note": "a context created with tsdf_config::lane_flags = TSDF_LANES_NO_INTEGRATE_LANE: lane ahead + the context's stream (integrate, march, shade) + fill lane, one volume"}
     long_run = None
     if args.long_steps and args.frames_in_flight == 1:
         dl = timed(args.long_steps, lambda i: step(drv, i))

@@ -73,7 +73,22 @@ typedef struct tsdf_config {
    * is bound by the same image gathers as the LUT kernel and measured slower).  Tiles beyond the budget keep
    * the LUT path.  Results are bit-identical either way. */
   uint32_t proj_cache_mib;
+  /* The lanes of a context (rounds 3 / 4; the reference has ONE GL command stream, recon_integration.hpp:43-49 configures its operator through
+   * setters: these fields are their counterpart for what has no setter there).  0 = the default: four HIP streams per context -- the lane ahead
+   * (frame re-layout / processTextures, brick passes), the integrate lane, the context's stream (depth limits, march, shade), the fill lane
+   * (hole filling, issued by a helper thread) -- with everything the lanes hand over allocated twice.  MEMORY: the integrate lane keeps a SECOND
+   * VOLUME SET (volume + tile tables: 4 bytes x voxels again -- 0.5 GiB at 512^3, 4 GiB at 1024^3), allocated at the first tsdf_integrate();
+   * TSDF_LANES_NO_INTEGRATE_LANE does without it (integrate() on the context's stream, ~30 % fewer frames/s at 512^3 x 4 streams).  Results are
+   * bit-identical in every combination.  tsdf_set_stage_overlap() switches TSDF_LANES_ONE_STREAM at run time.  (The RR_* environment variables
+   * the A/B tools use -- RR_OVERLAP_FILL, RR_DEEP, RR_FILL_THREAD, RR_LANES, RR_LANE_PRIORITY -- override these fields when set.) */
+  uint32_t lane_flags;
+  /* stream priority of {lane ahead, fill lane, integrate lane, context's stream}: -1 high, 0 normal (default), 1 low */
+  int32_t lane_priority[4];
 } tsdf_config;
+#define TSDF_LANES_ONE_STREAM        1u   /* every kernel of a frame on the context's stream, one copy of everything (rounds 1 / 2) */
+#define TSDF_LANES_NO_INTEGRATE_LANE 2u   /* integrate() on the context's stream, ONE volume set */
+#define TSDF_LANES_NO_FILL_THREAD    4u   /* the fill lane's calls are issued by the calling thread */
+#define TSDF_LANES_SHARED_FILL_LANE  8u   /* the lane ahead and the fill lane share one stream */
 
 /* ---- lifetime / errors ------------------------------------------------------------------------- */
 int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out);

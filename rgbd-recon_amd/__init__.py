@@ -9,7 +9,7 @@
 The directory name carries a hyphen (project naming); import it as ``rgbd_recon_amd`` (alias module at
 the repository root) or with importlib.
 """
-from .binding import (ReconIntegrationHip, TsdfConfig, TsdfError, build_library, declared_symbols,  # noqa: F401
+from .binding import (LANES_NO_FILL_THREAD, LANES_NO_INTEGRATE_LANE, LANES_ONE_STREAM, LANES_SHARED_FILL_LANE, ReconIntegrationHip, TsdfConfig, TsdfError, build_library, declared_symbols,  # noqa: F401
                       load_library, LIB_PATH, HEADER_PATH, read_calib_volume, write_calib_volume,
                       read_stream_record, stream_num_frames, frustum_from_volume, view_matrices, inverse_volume_resolution, invert_calibration, COLOR_RGB8, COLOR_DXT1, COLOR_DXT5, DEPTH_F32, DEPTH_U8)
 from . import scene  # noqa: F401

@@ -653,7 +653,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   *out = nullptr;
   // struct_size lets the struct grow: a caller built against the layout that ended at slab_recompute_halo is still accepted
   tsdf_config grown{};
-  if (cfg->struct_size == offsetof(tsdf_config, sparse_pool_tiles) || cfg->struct_size == offsetof(tsdf_config, proj_cache_mib)) {
+  if (cfg->struct_size == offsetof(tsdf_config, sparse_pool_tiles) || cfg->struct_size == offsetof(tsdf_config, proj_cache_mib) || cfg->struct_size == offsetof(tsdf_config, lane_flags)) {
     memcpy(&grown, cfg, cfg->struct_size); grown.struct_size = sizeof(tsdf_config); cfg = &grown;
   }
   if (cfg->struct_size != sizeof(tsdf_config)) { g_create_error = "tsdf_config.struct_size mismatch"; return TSDF_ERR_INVALID_ARGUMENT; }
@@ -677,7 +677,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   // All normal by default.  The lane ahead BELOW the others ("1,0,0,0") is worth 4 % at c2 with one context (115 against 120 us per frame: its re-layout and
   // brick marking otherwise take the machine from the march) -- but a low-priority stream changes how the runtime deals its hardware queues: three contexts
   // in flight fall from 7 120 to 4 210 frames/s, and beside RCCL's kernels the lane starves (1 010 against 3 470 frames/s in the one-rank exchange rehearsal)
-  int lo = 0, hi = 0, ppre = 0, pfill = 0, pinteg = 0, pmain = 0;
+  int lo = 0, hi = 0, ppre = cfg->lane_priority[0], pfill = cfg->lane_priority[1], pinteg = cfg->lane_priority[2], pmain = cfg->lane_priority[3];
   hipDeviceGetStreamPriorityRange(&lo, &hi);                             // (least, greatest): numerically greatest <= least
   if (const char* e = getenv("RR_LANE_PRIORITY")) sscanf(e, "%d,%d,%d,%d", &ppre, &pfill, &pinteg, &pmain);
   auto prio = [&](int rel) { return rel < 0 ? hi : (rel > 0 ? lo : (lo + hi) / 2); };
@@ -710,8 +710,11 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
   c->stream = c->own_stream;
   // The three lanes of a context (stage overlap) are created together: the HIP runtime deals its hardware queues (4 by default,
   // GPU_MAX_HW_QUEUES) to streams in creation order, and two lanes that share a queue do not overlap at all
-  if (getenv("RR_OVERLAP_FILL") == nullptr || atoi(getenv("RR_OVERLAP_FILL")) != 0) {
-    const bool two_lanes = getenv("RR_LANES") && atoi(getenv("RR_LANES")) == 2;   // (A/B hook) the lane ahead and the fill lane share one stream
+  // tsdf_config::lane_flags decides; the RR_* variables of the A/B tools override it when set
+  c->overlap_fill = !(cfg->lane_flags & TSDF_LANES_ONE_STREAM); c->deep = !(cfg->lane_flags & TSDF_LANES_NO_INTEGRATE_LANE); c->fill_thread = !(cfg->lane_flags & TSDF_LANES_NO_FILL_THREAD);
+  if (const char* e = getenv("RR_OVERLAP_FILL")) c->overlap_fill = atoi(e) != 0;
+  if (c->overlap_fill) {
+    const bool two_lanes = getenv("RR_LANES") ? atoi(getenv("RR_LANES")) == 2 : (cfg->lane_flags & TSDF_LANES_SHARED_FILL_LANE) != 0;   // the lane ahead and the fill lane share one stream
     if (make_stream(&c->pre_stream, 0, ppre, true) != hipSuccess ||
         (two_lanes ? (c->fill_stream = c->pre_stream, hipSuccess) : make_stream(&c->fill_stream, 1, pfill, true)) != hipSuccess ||
         hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess ||
@@ -722,7 +725,6 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
         hipEventCreateWithFlags(&c->fill_done[1], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(TSDF_ERR_HIP); }
   }
   if (const char* e = getenv("RR_K1_RANGES")) c->use_ranges = atoi(e) != 0;
-  if (const char* e = getenv("RR_OVERLAP_FILL")) c->overlap_fill = atoi(e) != 0;
   if (const char* e = getenv("RR_FILL_THREAD")) c->fill_thread = atoi(e) != 0;
   if (const char* e = getenv("RR_PRE_ON_INTEG")) c->pre_on_integ = atoi(e) != 0;
   if (const char* e = getenv("RR_DEEP")) c->deep = atoi(e) != 0;          // A/B and test hook: integrate() on the context's stream, one volume

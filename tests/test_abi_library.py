@@ -27,7 +27,7 @@ def test_config_struct_layout_matches_header(rr):
             m = re.search(r"([a-z_0-9]+)\s*(\[\d+\])?\s*$", part.strip())
             names.append(m.group(1))
     assert names == [f[0] for f in rr.TsdfConfig._fields_]
-    assert ctypes.sizeof(rr.TsdfConfig) == 4 + 24 + 4 + 12 + 12 + 4 + 4 * 7 + 4 + 8 + 4 + 4 + 4
+    assert ctypes.sizeof(rr.TsdfConfig) == 4 + 24 + 4 + 12 + 12 + 4 + 4 * 7 + 4 + 8 + 4 + 4 + 4 + 4 + 16
 
 
 def test_create_without_a_device_fails_loudly(rr):

@@ -223,8 +223,7 @@ def test_dirty_tile_masks_reach_as_far_as_the_hole_filling_spreads(rr, overlap):
 
 def make_pair(rr, scene, deep, monkeypatch, **kw):
     """a context with the fourth lane (integrate() of frame f + 1 beside the draw of frame f, two volume sets) and one without"""
-    monkeypatch.setenv("RR_DEEP", "1" if deep else "0")
-    return rr.ReconIntegrationHip(scene, **kw)
+    return rr.ReconIntegrationHip(scene, lane_flags=0 if deep else rr.LANES_NO_INTEGRATE_LANE, **kw)   # tsdf_config::lane_flags (round 4; RR_DEEP in round 3)
 
 
 def test_two_volume_sets_alternate_without_a_trace(rr, monkeypatch):
