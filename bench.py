@@ -613,18 +613,51 @@ def main():
             ph.frame_raw_dev(mv, pr, rd[i % nsc][1])
         ph.sync()
         dtp = time.perf_counter() - tp0
-        pre_ms = None
+        pre_ms, pre_kernels = None, None
         if not args.no_timers:
+            names = ["k_pre_morph", "k_pre_filter", "k_pre_boundary", "k_pre_normal", "k_pre_quality"]
             ph.set_stage_overlap(False)
-            ph.set_timer_filter(["1preprocess"]); ph.enable_timers(True)
+            ph.set_timer_filter(["1preprocess"] + names); ph.enable_timers(True)
             for i in range(30):
                 ph.frame_raw_dev(mv, pr, rd[i % nsc][1])
             ph.sync(); ph.enable_timers(False)
             n, ms = ph.timer_stats("1preprocess")
             pre_ms = ms / n if n else None
+            # a roofline object per pass (VERDICT r03 "next" 3).  Bytes: the arrays a pass has to read and write once (N streams, P depth pixels, Pc colour
+            # pixels, L texels of a 128^3 LUT); the two bilateral passes are arithmetic, not traffic: their 13 x 13 taps are counted as vector operations
+            pp = ph.preprocessed()
+            N_, P_, Pc_, L_ = n_streams, 640 * 480, 640 * 480, LUT ** 3
+            n_box = int((pp["depth_rg"][..., 1] > 0).sum())                 # pixels the filter pass ran its taps for (inside the bounding box)
+            n_valid = int(((pp["depth_b"][..., 0] > 0) & (pp["depth_b"][..., 0] < 1)).sum())   # ... and the quality pass
+            alg = {"k_pre_morph": (4 + 4) * N_ * P_ + (3 + 4) * N_ * Pc_,    # raw depth in, dilated depth out; RGB8 in, RGBA8 out (rides along)
+                   "k_pre_filter": (4 + 8 + 16) * N_ * P_ + 4 * N_ * Pc_ + 24 * N_ * L_,
+                   "k_pre_boundary": (8 + 8 + 4 + 16) * N_ * P_,
+                   "k_pre_normal": (4 + 16) * N_ * P_ + 16 * N_ * L_,
+                   "k_pre_quality": (4 + 4 + 16) * N_ * P_ + 16 * n_valid + 16 * N_ * L_}
+            ops = {"k_pre_filter": 169 * 16 * n_box + 300 * N_ * P_, "k_pre_quality": 169 * 11 * n_valid}    # vector operations (lane-instructions): taps x instructions per tap (+ RGB -> Lab of every pixel)
+            pre_kernels = {}
+            for kname in names:
+                kn, kms = ph.timer_stats(kname)
+                if not kn:
+                    continue
+                t = kms / kn
+                o = {"avg_launch_ms": t, "algorithmic_bytes": alg[kname], "bound": "hbm", "achieved": alg[kname] / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg[kname] / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if kname in ops:                                            # 1024 SIMDs x 2.4 GHz x 32 lanes per cycle = 78.6 T lane-operations / s (half the 157.3 TFLOP/s FMA peak)
+                    o.update({"bound": "valu", "vector_ops": ops[kname], "achieved": ops[kname] / (t * 1e-3) / 1e12, "peak": 78.6, "unit": "T lane-ops/s",
+                              "frac": ops[kname] / (t * 1e-3) / 1e12 / 78.6, "hbm_frac": alg[kname] / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "13 x 13 bilateral: taps x vector instructions per tap over the pixels that run them (the scene's %d / %d); only whole waves issue, so the SIMDs' real "
+                                      "issue share is higher (valu_issue_frac from the counter pass where profiles/traffic.json holds one)" % (n_box if kname == "k_pre_filter" else n_valid, N_ * P_)})
+                    vi = measured_traffic(args.config + "_preprocess", kname, "valu_insts")
+                    if vi:
+                        o["valu_issue_frac"] = vi * 2.0 / (1024 * 2.4e9 * t * 1e-3)
+                tr = measured_traffic(args.config + "_preprocess", kname)
+                if tr:
+                    o["traffic"] = tr
+                pre_kernels[kname] = o
         ph.close()
         del ph, rd
-        with_pre = {"value": args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3, "preprocess_ms": pre_ms,
+        with_pre = {"value": args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3, "preprocess_ms": pre_ms, "kernels": pre_kernels,
                     "note": "tsdf_frame_raw_dev: every step takes the other RAW frame (depth in metres + RGB8, resident in HBM) through pre_morph / pre_depth (13 x 13 bilateral + "
                             "RGB -> Lab) / pre_boundary / pre_normal (marks the bricks) / pre_quality on the lane ahead, then the frame as in `value`; preprocess_ms: the five "
                             "passes + the range cells on one stream (HIP events)"}

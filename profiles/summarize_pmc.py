@@ -20,7 +20,9 @@ import json
 import os
 import sys
 
-GROUPS = {"k_integrate_tiles_lds": ("k_integrate_tiles_lds",), "k_march": ("k_march",), "k_march+k_shade": ("k_march", "k_shade")}   # k_march covers both passes (k_march<>, k_march_long)
+GROUPS = {"k_integrate_tiles_lds": ("k_integrate_tiles_lds",), "k_march": ("k_march",), "k_march+k_shade": ("k_march", "k_shade"),   # k_march covers both passes (k_march<>, k_march_long)
+          # round 4: the pre-processing passes (configs named *_preprocess: bench.py --preprocess)
+          "k_pre_morph": ("k_pre_morph",), "k_pre_filter": ("k_pre_filter",), "k_pre_boundary": ("k_pre_boundary",), "k_pre_normal": ("k_pre_normal",), "k_pre_quality": ("k_pre_quality",)}
 
 
 def per_kernel(path, counter=None):
@@ -50,6 +52,8 @@ def main():
     v = per_kernel(sys.argv[4], "SQ_INSTS_VALU") if len(sys.argv) > 4 else {}
     out = {}
     for name, parts in GROUPS.items():
+        if not any(any(p in k for p in parts) for k in f):
+            continue                                   # the pass did not launch these kernels
         fb = sum(v for k, v in f.items() if any(p in k for p in parts)) * 1024
         wb = sum(v for k, v in w.items() if any(p in k for p in parts)) * 1024
         out[name] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb, "hbm_bytes_if_streaming": 2 * fb + wb}

@@ -1271,8 +1271,15 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
   B.depth_rg = c->d_depth_rg; B.lab = c->d_lab; B.depth_b = c->d_depth_b; B.normal = c->d_normal;
   B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
   timer_begin_on(c, "1preprocess", lane);
-  launch_preprocess(lane, P, B, c->luts, c->frame, c->br, c->slots[c->cur_slot].ranges, c->pending_rgb, (uchar4*)c->frame.color,
-                    (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch);
+  const size_t ncol = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
+  if (c->timers_on) {                                                     // each pass between its own pair of events (bench.py: a roofline object per pass)
+    static const char* const names[5] = {"k_pre_morph", "k_pre_filter", "k_pre_boundary", "k_pre_normal", "k_pre_quality"};
+    for (int k = 1; k <= 5; ++k) {
+      timer_begin_on(c, names[k - 1], lane);
+      launch_preprocess(lane, P, B, c->luts, c->frame, c->br, c->slots[c->cur_slot].ranges, c->pending_rgb, (uchar4*)c->frame.color, ncol, nullptr, 0, k);
+      timer_end_on(c, names[k - 1], lane);
+    }
+  } else launch_preprocess(lane, P, B, c->luts, c->frame, c->br, c->slots[c->cur_slot].ranges, c->pending_rgb, (uchar4*)c->frame.color, ncol);
   c->pending_rgb = nullptr;
   timer_end_on(c, "1preprocess", lane);
   HIP_TRY(c, hipGetLastError());

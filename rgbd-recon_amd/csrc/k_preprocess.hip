@@ -310,14 +310,14 @@ __global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, 
 }
 
 void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR, float4* ranges,
-                       const uint8_t* rgb, uchar4* rgba, size_t n_color_px, uint32_t* zero, uint32_t zero_words) {
+                       const uint8_t* rgb, uchar4* rgba, size_t n_color_px, uint32_t* zero, uint32_t zero_words, int only) {
   const dim3 rows((P.W + 63) / 64, (P.H + 3) / 4, P.N), tiles((P.W + 15) / 16, (P.H + 15) / 16, P.N);
   const PreExtra E{rgb, rgba, (uint32_t)n_color_px, (uint4*)zero, zero_words >> 2};
-  hipLaunchKernelGGL(k_pre_morph, dim3(rows.x, rows.y, P.N + ((rgb || zero) ? 2 : 0)), dim3(256), 0, st, P, B, E);
-  hipLaunchKernelGGL(k_pre_filter, tiles, dim3(256), 0, st, P, B, T, F);
-  hipLaunchKernelGGL(k_pre_boundary, rows, dim3(256), 0, st, P, B);
-  hipLaunchKernelGGL(k_pre_normal, rows, dim3(256), 0, st, P, B, T, BR);
-  hipLaunchKernelGGL(k_pre_quality, tiles, dim3(256), 0, st, P, B, T, ranges, (P.W + 7) / 8, (P.H + 7) / 8);
+  if (!only || only == 1) hipLaunchKernelGGL(k_pre_morph, dim3(rows.x, rows.y, P.N + ((rgb || zero) ? 2 : 0)), dim3(256), 0, st, P, B, E);
+  if (!only || only == 2) hipLaunchKernelGGL(k_pre_filter, tiles, dim3(256), 0, st, P, B, T, F);
+  if (!only || only == 3) hipLaunchKernelGGL(k_pre_boundary, rows, dim3(256), 0, st, P, B);
+  if (!only || only == 4) hipLaunchKernelGGL(k_pre_normal, rows, dim3(256), 0, st, P, B, T, BR);
+  if (!only || only == 5) hipLaunchKernelGGL(k_pre_quality, tiles, dim3(256), 0, st, P, B, T, ranges, (P.W + 7) / 8, (P.H + 7) / 8);
 }
 
 }  // namespace rr

@@ -207,7 +207,8 @@ void launch_wire_unpack(hipStream_t st, const WireLayout& L, uchar4* rgba, float
 // ranges: the frame slot's 8x8-pixel range cells (written by the last pass), or null; rgb -> rgba (n_color_px pixels) and zero (zero_words words, a multiple of
 // 4): the frame's colour re-layout and the brick counters' clear riding along in the first launch, or null
 void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR, float4* ranges,
-                       const uint8_t* rgb = nullptr, uchar4* rgba = nullptr, size_t n_color_px = 0, uint32_t* zero = nullptr, uint32_t zero_words = 0);
+                       const uint8_t* rgb = nullptr, uchar4* rgba = nullptr, size_t n_color_px = 0, uint32_t* zero = nullptr, uint32_t zero_words = 0,
+                       int only = 0);   // only: 0 = the five passes, 1 .. 5 = that pass alone (morph, filter, boundary, normal, quality: per-kernel timers)
 
 // launchers (one per kernel family, defined in the .hip files)
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);

@@ -12,8 +12,12 @@ cp $(find_stats c1_serial) $R/profiles/${NAME}_c1_kernel_stats.csv
 cp $G/bench_stats_c2_serial.json $R/profiles/${NAME}_bench_c2_under_rocprof.json
 cp $G/bench_stats_c2_lanes.json $R/profiles/${NAME}_bench_c2_all_lanes_under_rocprof.json
 cp $G/bench_stats_c1_serial.json $R/profiles/${NAME}_bench_c1_under_rocprof.json
-for c in c2 c1; do
+cp $(find_stats c3_serial) $R/profiles/${NAME}_c3_kernel_stats.csv
+cp $(find_stats c4_serial) $R/profiles/${NAME}_c4_kernel_stats.csv
+cp $(find_stats c2_preprocess) $R/profiles/${NAME}_c2_preprocess_kernel_stats.csv
+for c in c2 c4; do for p in TA_BUSY_avr SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES; do [ -f $G/pmc_${p}_$c.csv ] && cp $G/pmc_${p}_$c.csv $R/profiles/${NAME}_pmc_${p}_$c.csv || true; done; done
+for c in c2 c1 c3 c4 c2_preprocess; do
   for p in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do cp $G/pmc_${p}_$c.csv $R/profiles/${NAME}_pmc_${p}_$c.csv; done
   python3 $R/profiles/summarize_pmc.py $c $R/profiles/${NAME}_pmc_FETCH_SIZE_$c.csv $R/profiles/${NAME}_pmc_WRITE_SIZE_$c.csv $R/profiles/${NAME}_pmc_SQ_INSTS_VALU_$c.csv
 done
-for c in c1 c2 c3 c4 c2_exchange_alone c2_exchange_alone_native c2_one_stream c2_3_frames_in_flight; do cp $G/bench_$c.json $R/profiles/${NAME}_bench_$c.json; done
+for c in c1 c2 c3 c4 c2_preprocess c2_exchange_alone c2_exchange_alone_native c2_one_stream c2_3_frames_in_flight; do cp $G/bench_$c.json $R/profiles/${NAME}_bench_$c.json; done

@@ -9,10 +9,12 @@ TAG=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
-for c in c2 c1; do
+# round 4: the counter passes also for configs[3] / configs[4] (their roofline.traffic was null), one pass of the texture-address /
+# vector-memory counters for c2 and c4, and the kernel stats of the pre-processing passes (bench.py --preprocess)
+for c in c2 c1 c3 c4; do
   for mode in lanes serial; do
     [ $mode = serial ] && export RR_OVERLAP_FILL=0 || unset RR_OVERLAP_FILL
-    [ $c = c1 ] && [ $mode = lanes ] && continue
+    [ $c != c2 ] && [ $mode = lanes ] && continue
     rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/${c}_$mode -o stats -- python3 $R/bench.py --config $c --no-cpu-baseline --no-c1 --long-steps 0 --steps 100 > $R/gpurun_out/$TAG/bench_stats_${c}_$mode.json 2> $R/gpurun_out/$TAG/stats_${c}_$mode.err
     find $R/gpurun_out/$TAG/${c}_$mode -name '*kernel_trace.csv' -delete
     echo "stats $c $mode done"
@@ -24,8 +26,26 @@ for c in c2 c1; do
     python3 $R/tools/pmc_aggregate.py $f $R/gpurun_out/$TAG/pmc_${pmc}_$c.csv
     echo "$pmc $c done"
   done
+  if [ $c = c2 ] || [ $c = c4 ]; then
+    for pmc in TA_BUSY_avr SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES; do
+      rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc2_$c -o $pmc -- python3 $R/bench.py --config $c --no-cpu-baseline --no-timers --no-c1 --long-steps 0 --steps 20 --warmup 3 > /dev/null 2> $R/gpurun_out/$TAG/${pmc}_$c.err || true
+      f=$(find /tmp/pmc2_$c -name "${pmc}_counter_collection.csv" | head -n 1)
+      [ -n "$f" ] && python3 $R/tools/pmc_aggregate.py $f $R/gpurun_out/$TAG/pmc_${pmc}_$c.csv || true
+      echo "$pmc $c done"
+    done
+  fi
   unset RR_OVERLAP_FILL
 done
+RR_OVERLAP_FILL=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/c2_preprocess -o stats -- python3 $R/bench.py --preprocess --no-cpu-baseline --no-c1 --long-steps 0 --steps 100 > $R/gpurun_out/$TAG/bench_stats_c2_preprocess.json 2> $R/gpurun_out/$TAG/stats_c2_preprocess.err
+find $R/gpurun_out/$TAG/c2_preprocess -name '*kernel_trace.csv' -delete
+export RR_OVERLAP_FILL=0
+for pmc in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+  rocprofv3 --pmc $pmc --output-format csv -d /tmp/pmc_pre -o $pmc -- python3 $R/bench.py --preprocess --no-cpu-baseline --no-timers --no-c1 --long-steps 0 --steps 20 --warmup 3 > /dev/null 2> $R/gpurun_out/$TAG/${pmc}_c2_preprocess.err
+  f=$(find /tmp/pmc_pre -name "${pmc}_counter_collection.csv" | head -n 1)
+  python3 $R/tools/pmc_aggregate.py $f $R/gpurun_out/$TAG/pmc_${pmc}_c2_preprocess.csv
+done
+unset RR_OVERLAP_FILL
+echo "stats preprocess done"
 cd $R
 python3 bench.py > gpurun_out/$TAG/bench_c2.json 2> gpurun_out/$TAG/bench_c2.err
 echo "bench c2 done"
@@ -35,6 +55,7 @@ python3 bench.py --config c4 --no-cpu-baseline --no-c1 > gpurun_out/$TAG/bench_c
 echo "bench c1 c3 c4 done"
 RR_BENCH_EXCHANGE_ALONE=1 python3 bench.py --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_exchange_alone.json 2> gpurun_out/$TAG/bench_c2_exchange_alone.err
 RR_BENCH_EXCHANGE_ALONE=1 python3 bench.py --no-cpu-baseline --no-c1 --long-steps 0 --exchange native > gpurun_out/$TAG/bench_c2_exchange_alone_native.json 2> gpurun_out/$TAG/bench_c2_exchange_alone_native.err
+python3 bench.py --preprocess --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_preprocess.json 2> gpurun_out/$TAG/bench_c2_preprocess.err
 RR_OVERLAP_FILL=0 python3 bench.py --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_one_stream.json 2> gpurun_out/$TAG/bench_c2_one_stream.err
 python3 bench.py --frames-in-flight 3 --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_3_frames_in_flight.json 2> gpurun_out/$TAG/bench_c2_3fif.err
 echo "all done"
