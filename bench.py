@@ -629,11 +629,14 @@ def main():
             N_, P_, Pc_, L_ = n_streams, 640 * 480, 640 * 480, LUT ** 3
             n_box = int((pp["depth_rg"][..., 1] > 0).sum())                 # pixels the filter pass ran its taps for (inside the bounding box)
             n_valid = int(((pp["depth_b"][..., 0] > 0) & (pp["depth_b"][..., 0] < 1)).sum())   # ... and the quality pass
+            # LUT bytes: the distinct texels the passes can touch -- background pixels tap the two depth slices at the clamped end of the LUT, a pixel with
+            # a depth its own 2 x 2 x 2 neighbourhood (an upper figure: neighbours share texels) --, never more than the whole LUT
+            lut = lambda texel_bytes, px: min(N_ * texel_bytes * L_, texel_bytes * (N_ * 2 * LUT * LUT + 8 * px))
             alg = {"k_pre_morph": (4 + 4) * N_ * P_ + (3 + 4) * N_ * Pc_,    # raw depth in, dilated depth out; RGB8 in, RGBA8 out (rides along)
-                   "k_pre_filter": (4 + 8 + 16) * N_ * P_ + 4 * N_ * Pc_ + 24 * N_ * L_,
+                   "k_pre_filter": (4 + 8 + 16) * N_ * P_ + 4 * N_ * Pc_ + lut(16 + 8, n_box),
                    "k_pre_boundary": (8 + 8 + 4 + 16) * N_ * P_,
-                   "k_pre_normal": (4 + 16) * N_ * P_ + 16 * N_ * L_,
-                   "k_pre_quality": (4 + 4 + 16) * N_ * P_ + 16 * n_valid + 16 * N_ * L_}
+                   "k_pre_normal": (4 + 16) * N_ * P_ + lut(16, 5 * n_valid),
+                   "k_pre_quality": (4 + 4 + 16) * N_ * P_ + 16 * n_valid + lut(16, n_valid)}
             ops = {"k_pre_filter": 169 * 16 * n_box + 300 * N_ * P_, "k_pre_quality": 169 * 11 * n_valid}    # vector operations (lane-instructions): taps x instructions per tap (+ RGB -> Lab of every pixel)
             pre_kernels = {}
             for kname in names:
