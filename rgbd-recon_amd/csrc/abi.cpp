@@ -1272,7 +1272,7 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
   B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
   timer_begin_on(c, "1preprocess", lane);
   const size_t ncol = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
-  if (c->timers_on) {                                                     // each pass between its own pair of events (bench.py: a roofline object per pass)
+  if (c->timers_on && c->timer_filter.find(",k_pre_") != std::string::npos) {   // each pass between its own pair of events, when the timer filter NAMES them (a pair costs the lane ~7 us)
     static const char* const names[5] = {"k_pre_morph", "k_pre_filter", "k_pre_boundary", "k_pre_normal", "k_pre_quality"};
     for (int k = 1; k <= 5; ++k) {
       timer_begin_on(c, names[k - 1], lane);
