@@ -171,12 +171,12 @@ def test_frame_sequence_resets_tiles_that_empty_out(rr):
 
 
 def test_older_config_struct_is_still_accepted(rr, small_scene):
-    """tsdf_config grew twice (sparse_pool_tiles, proj_cache_mib): a caller built against either earlier layout still works."""
+    """tsdf_config grew three times (sparse_pool_tiles, proj_cache_mib, the lane fields): a caller built against any earlier layout still works."""
     import ctypes as C
     L = rr.load_library()
     hip = rr.ReconIntegrationHip(small_scene, **KW)                  # reference context for the geometry
     cfg = rr.TsdfConfig()
-    cfg.struct_size = C.sizeof(rr.TsdfConfig) - 8                    # the layout that ended at slab_recompute_halo
+    cfg.struct_size = rr.TsdfConfig.sparse_pool_tiles.offset         # the layout that ended at slab_recompute_halo
     cfg.bbox_min[:] = [float(x) for x in small_scene["bbox_min"]]
     cfg.bbox_max[:] = [float(x) for x in small_scene["bbox_max"]]
     cfg.voxel_size = 0.05
@@ -193,9 +193,14 @@ def test_older_config_struct_is_still_accepted(rr, small_scene):
     need, cap = C.c_uint32(), C.c_uint32()
     assert L.tsdf_sparse_pool_stats(ctx, C.byref(need), C.byref(cap)) != 0       # a dense context
     assert L.tsdf_destroy(ctx) == 0
-    cfg.struct_size = C.sizeof(rr.TsdfConfig) - 4                    # the layout that ended at sparse_pool_tiles: the field counts now
+    cfg.struct_size = rr.TsdfConfig.proj_cache_mib.offset            # the layout that ended at sparse_pool_tiles: the field counts now
     cfg.sparse_pool_tiles = 0
     cfg.proj_cache_mib = 0xfffffff                                   # lies beyond struct_size: must be ignored
+    assert L.tsdf_create(C.byref(cfg), C.byref(ctx)) == 0
+    assert L.tsdf_destroy(ctx) == 0
+    cfg.struct_size = rr.TsdfConfig.lane_flags.offset                # round 3's layout (ended at proj_cache_mib)
+    cfg.proj_cache_mib = 0
+    cfg.lane_flags = 0xffffffff                                      # lies beyond struct_size: must be ignored (all four lanes)
     assert L.tsdf_create(C.byref(cfg), C.byref(ctx)) == 0
     assert L.tsdf_destroy(ctx) == 0
     cfg.struct_size = 8
