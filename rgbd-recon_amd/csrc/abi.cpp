@@ -1437,7 +1437,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   timer_begin_on(c, "2integrate", lane);
   int lds = 2;
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) lds = std::min(lds, c->lds_ok[i]);
-  const bool want_cache = lds == 2 && c->k1_form_cap >= 3 && c->proj_budget > 0 && !c->vol.slot && !c->proj_failed;
+  const bool want_cache = lds >= 2 && c->k1_form_cap >= 3 && c->proj_budget > 0 && !c->vol.slot && !c->proj_failed;
   lds = std::min(lds, c->k1_form_cap);
   if (c->use_bricks) {
     // this frame's list / count, the previous integrate()'s (trusted unless something else may have written the volume)

@@ -459,6 +459,16 @@ __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F
   }
 }
 
+#ifdef RR_K1_TRACE          // instrumented build (tools/k1_phase_trace.py): s_memtime stamps of the first tile of every workgroup of the culled LDS launch
+__device__ unsigned long long g_k1_trace[4096 * 16];
+extern "C" int32_t tsdf_debug_k1_trace(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k1_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#define RR_STAMP(slot) do { if (kList && kRanges && !kCache) { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
+  __builtin_amdgcn_sched_barrier(0); if (tid == 0 && blockIdx.x < 4096 && (slot) < 16) g_k1_trace[blockIdx.x * 16 + (slot)] = _t; } } while (0)
+#else
+#define RR_STAMP(slot) do { } while (0)
+#endif
 #ifndef RR_K1_BOXCAP
 #define RR_K1_BOXCAP 384
 #endif
@@ -488,12 +498,30 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
   // INVARIANT of the tile loop: every exit from an iteration after phase A has touched s_* passes through store_tile_class(), whose
   // workgroup barrier is what lets the next iteration overwrite s_* (there is no barrier at the head of the loop).  The `continue`s
   // below are workgroup-uniform and sit in front of phase A.
+  // Round 4 (in-kernel stamps, profiles/r04_k1_phase_trace_*.txt): 29 % of a tile's 24 k cycles went by BEFORE its first stream -- the list entry (a
+  // dependent scalar load), then phase A's per-lane loads of the LUT resolutions out of the kernel arguments (a vector-memory round trip per tile for
+  // values that never change).  Now: a thread's phase-A assignment (stream, axis, coordinate) is fixed by its index, so its LUT resolution is loaded
+  // once per workgroup (into LDS); the next tile's list entry and pair classes are requested at the head of the current tile.
+  __shared__ int s_invres[TSDF_MAX_STREAMS][3], s_vres[3];                         // LUT / volume resolutions: phase A reads them per (stream, axis) -- from LDS, once per workgroup
+  __shared__ float s_step[3];
+  if (tid < T.n * 3) s_invres[tid / 3][tid % 3] = T.s[tid / 3].inv_res[tid % 3];
+  if (tid < 3) { s_vres[tid] = tid == 0 ? V.res[0] : (tid == 1 ? V.res[1] : V.res[2]); s_step[tid] = tid == 0 ? step[0] : (tid == 1 ? step[1] : step[2]); }
+  __syncthreads();
+  int tile_next = blockIdx.x < n_work ? work_tile<kList>(S, blockIdx.x) : 0;
+  uint32_t pairs_next = kRanges && blockIdx.x < n_work ? pair_masks[blockIdx.x] : 0u;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    RR_STAMP(0);                                                                     // tile head
+    [[maybe_unused]] int _stream_slot = 3;
     uint32_t item = kItemNone;
     if (kCache) { item = PC.items[w]; if (item < kItemFresh) continue; }           // cached: k_integrate_cached's
     const bool fill = kCache && item != kItemNone;                                   // workgroup-uniform
     float* __restrict__ const fill_base = fill ? PC.data + (size_t)(item & ~kItemFresh) * PC.slot_floats : nullptr;
-    const int tile = work_tile<kList>(S, w);
+    const int tile = kCache ? work_tile<kList>(S, w) : tile_next;
+    uint32_t pairs = kRanges ? (kCache ? pair_masks[w] : pairs_next) : 0u;         // (kRanges) from k_pair_masks: 2 bits per stream -- which streams treat every voxel of this tile alike --, bit 31: every brick reaching into the tile is occupied
+    {                                                                                // the next tile's, in flight across this one (scalar loads: the indices are workgroup-uniform)
+      const int wn = w + (int)gridDim.x;
+      if (!kCache && wn < n_work) { tile_next = work_tile<kList>(S, wn); if (kRanges) pairs_next = pair_masks[wn]; }
+    }
     int t3[3];
     tile_coords(V, tile, t3[0], t3[1], t3[2]);
     if (V.slot && (uint32_t)w >= V.pool_tiles) continue;              // sparse pool exhausted: the tile stays unallocated (reads -limit)
@@ -503,7 +531,6 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
     const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
     bool drawn[kVox];
     float tsd[kVox], wsum[kVox];
-    uint32_t pairs = kRanges ? pair_masks[w] : 0u;                      // (kRanges) from k_pair_masks: 2 bits per stream -- which streams treat every voxel of this tile alike --, bit 31: every brick reaching into the tile is occupied
     if (fill) pairs &= T.n <= 15 ? 0x80000000u : 0u;                    // a slot is filled for all streams: no shortcut this once
     const bool check_voxels = per_voxel_check && !(kRanges && T.n <= 15 && (pairs >> 31));
 #pragma unroll
@@ -517,11 +544,14 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
     // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)                // (kRanges) 2 bits per stream, from k_pair_masks: which streams treat every voxel of this tile alike
     for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
       const int i = t / 24, a = (t % 24) >> 3, k = t & 7;
-      const int coord = min(t3[a] * 8 + k, V.res[a] - 1);               // padding voxels reuse the last real coordinate
-      const Axis ax = axis_linear(((float)coord + 0.5f) * step[a], T.s[i].inv_res[a]);
+      const int ta = a == 0 ? t3[0] : (a == 1 ? t3[1] : t3[2]);
+      const int coord = min(ta * 8 + k, s_vres[a] - 1);                 // padding voxels reuse the last real coordinate
+      const Axis ax = axis_linear(((float)coord + 0.5f) * s_step[a], s_invres[i][a]);
       s_i0a[i][a][k] = ax.i0; s_i1a[i][a][k] = ax.i1; s_wa[i][a][k] = ax.a;
     }
+    RR_STAMP(1);                                                                     // own part of phase A done (incl. the voxel checks)
     __syncthreads();
+    RR_STAMP(2);                                                                     // phase A barrier passed
     for (int i = 0; i < T.n; ++i) {
       if (kRanges) {
         const int pair = (int)((pairs >> (2 * i)) & 3u);                // workgroup-uniform
@@ -557,7 +587,9 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
           s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
         }
       }
+      RR_STAMP(_stream_slot);                                                        // own box texels stored
       __syncthreads();
+      RR_STAMP(_stream_slot + 1);                                                    // phase B barrier passed
       if (kSep) {                                                       // passes X and Y
         const int n1 = min(__mul24(__mul24(dy, dz), 8), kRowCap);
         for (int e = tid; e < n1; e += 256) {
@@ -578,6 +610,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
         }
         __syncthreads();
       }
+      RR_STAMP(_stream_slot + 2);                                                    // passes X and Y done
       bool any_drawn = false;
 #pragma unroll
       for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
@@ -623,10 +656,15 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
           }
         }
       }
+      RR_STAMP(_stream_slot + 3);                                                    // phase Z done (gathers + fusion)
+      _stream_slot += 4;
     }
+    RR_STAMP(13);
 #pragma unroll
     for (int h = 0; h < kVox; ++h) { tsd[h] = drawn[h] ? tsd[h] : -limit; out[tid + 256 * h] = tsd[h]; }   // clearImage(-limit), :249-250
+    RR_STAMP(14);
     store_tile_class(S, tile, tsd[0] == -limit && tsd[1] == -limit);
+    RR_STAMP(15);
   }
 }
 
@@ -852,7 +890,7 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
       hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
     }
     else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
-    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
+    else if (lds_ok >= 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
     else hipLaunchKernelGGL(k_integrate_tiles<true>, grid, dim3(256), 0, st, T, F, V, B, S, pvc);
   } else {
@@ -864,9 +902,10 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
       // at most 16 384 workgroups striding over the tiles instead of one per tile: the launch alone is as fast (119 us at c1), the frame beside the other
       // lanes 2.5 % faster (4 349 against 4 242 frames/s; 8 192: 4 380 but the launch alone 125 us, 2 048: 3 796); RR_K1_DENSE_GRID: A/B hook
       static const int dcap = [] { const char* e = getenv("RR_K1_DENSE_GRID"); return e ? atoi(e) : 16384; }();
-      hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dim3(dcap > 0 && dcap < S.n ? dcap : S.n), dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);
+      const dim3 dgrid(dcap > 0 && dcap < S.n ? dcap : S.n);
+      hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dgrid, dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);
     }
-    else if (lds_ok == 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr, PC);
+    else if (lds_ok >= 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr, PC);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr, PC);
     else hipLaunchKernelGGL(k_integrate_tiles<false>, dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0);
   }
