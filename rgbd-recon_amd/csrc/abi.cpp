@@ -555,7 +555,7 @@ RayTarget ray_target(tsdf_ctx* c) {
 void release_volume(tsdf_ctx* c) {
   hipFree(c->vol.data); hipFree(c->vol.slot);                          // (both callers have synchronised the stream)
   hipFree(c->tiles.stamp); hipFree(c->d_cls_all);
-  hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts); hipFree(c->d_linear); hipFree(c->d_tile_bounds); hipFree(c->d_pair_masks); c->d_pair_masks = nullptr;
+  hipFree(c->d_tile_list[0]); hipFree(c->d_tile_list[1]); hipFree(c->d_tile_counts); hipFree(c->d_linear); hipFree(c->d_tile_bounds); hipFree(c->d_pair_masks); c->d_pair_masks = nullptr; hipFree(c->d_work_recs); c->d_work_recs = nullptr;
   hipFree(c->proj.data); hipFree(c->proj.slot); hipFree(c->proj.items); hipFree(c->d_proj_words); hipFree(c->d_item_stats);
   c->proj = ProjCache{}; c->d_proj_words = nullptr; c->d_item_stats = nullptr; c->proj_failed = false; c->last_integrate_cached = false;
   hipFree(c->alt.data); hipFree(c->alt.cls_all); hipFree(c->alt.stamp); hipFree(c->alt.list[0]); hipFree(c->alt.list[1]); hipFree(c->alt.counts);
@@ -734,6 +734,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
     c->proj_budget = (size_t)(mib << 20);
   }
   if (const char* e = getenv("RR_K1_CULLED_RANGES")) c->culled_ranges = atoi(e) != 0;
+  if (const char* e = getenv("RR_K1_REC")) c->use_recs = atoi(e) != 0;    // A/B hook: 0 = the LDS form's own tile head
   // setVoxelSize(), :340-347
   for (int a = 0; a < 3; ++a) {
     const float ext = cfg->bbox_max[a] - cfg->bbox_min[a];
@@ -1468,6 +1469,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   if ((!c->use_bricks || culled_ranges) && lds >= 2 && c->frame.ranges) {
     if (!c->d_tile_bounds) HIP_TRY(c, hipMalloc((void**)&c->d_tile_bounds, (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 2 * sizeof(float4)));
     if (!c->d_pair_masks) HIP_TRY(c, hipMalloc((void**)&c->d_pair_masks, (size_t)c->tiles.n * sizeof(uint32_t)));
+    if (c->use_recs && !c->d_work_recs) HIP_TRY(c, hipMalloc((void**)&c->d_work_recs, (size_t)c->tiles.n * sizeof(uint4)));
     if (!c->tile_bounds_valid) { launch_tile_bounds(lane, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
     bounds = c->d_tile_bounds;
   }
@@ -1506,11 +1508,11 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   c->last_integrate_cached = proj != nullptr;
   if (bounds) {                                                        // this frame's (tile, stream) pair classes (+ which work items are cached)
     timer_begin_on(c, "k_pair_masks", lane);
-    launch_integrate(lane, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 3, nullptr, bounds, c->d_pair_masks, proj);
+    launch_integrate(lane, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 3, nullptr, bounds, c->d_pair_masks, proj, c->use_recs ? c->d_work_recs : nullptr);
     timer_end_on(c, "k_pair_masks", lane);
   }
   timer_begin_on(c, "k_integrate_tiles", lane);                                // the kernel(s) alone (bench.py's roofline)
-  launch_integrate(lane, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 4, nullptr, bounds, bounds ? c->d_pair_masks : nullptr, proj);
+  launch_integrate(lane, c->luts, c->frame, c->vol, c->br, c->tiles, c->use_bricks ? 1 : 0, lds, 0, c->frame_stamp, 4, nullptr, bounds, bounds ? c->d_pair_masks : nullptr, proj, bounds && c->use_recs ? c->d_work_recs : nullptr);
   timer_end_on(c, "k_integrate_tiles", lane);
   if (c->use_bricks) { c->tile_parity ^= 1; c->full_classify = false; }
   else c->full_classify = true;                                       // a dense pass wrote every tile: the next culled frame must look at all of them

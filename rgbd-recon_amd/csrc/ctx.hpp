@@ -111,6 +111,7 @@ struct tsdf_ctx {
   bool use_tile_history = true;   // RR_IMAGE_TILES=0 turns it off (A/B)
   bool peels_cleared = false;     // integrate() already reset the peel tiles the coming draw would reset (part C of k_classify_lists)
   uint32_t* d_pair_masks = nullptr;   // per work item of the integrate launch: this frame's (tile, stream) pair classes (k_pair_masks)
+  uint4* d_work_recs = nullptr; bool use_recs = true;   // per work item of the integrate launch: the 16-byte record k_pair_masks leaves for k_integrate_tiles_rec (RR_K1_REC=0: off, A/B)
   float4* d_tile_bounds = nullptr; bool tile_bounds_valid = false;   // static per (stored tile, stream) LUT-box bounds, built on the first dense integrate after a calibration
   bool culled_ranges = true;      // RR_K1_CULLED_RANGES=0: no uniform-pair shortcut in culled launches (A/B hook; dense storage with a bounds table of at most 512 MiB only)
   bool use_ranges = true;         // RR_K1_RANGES=0: the dense integrate evaluates every voxel of every stream (A/B and test hook, read at creation)

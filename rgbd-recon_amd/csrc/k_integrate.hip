@@ -382,7 +382,7 @@ extern "C" int32_t tsdf_debug_pair_stats(unsigned long long out[4], int reset) {
 #endif
 template <bool kList>
 __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
-                                                    const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks, ProjCache PC) {
+                                                    const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks, uint4* __restrict__ recs, ProjCache PC) {
   const int ln = threadIdx.x & 63;
   const int n_work = kList ? (int)*S.count : S.n;
   const int n_waves = gridDim.x * 4;
@@ -433,6 +433,12 @@ __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F
       if (all && T.n <= 15) pairs |= 0x80000000u;                       // (16 streams use all 32 bits for their classes)
     }
     if (ln == 0) masks[w] = pairs;
+    if (recs && ln == 0) {                                              // the work item's record (k_integrate_tiles_rec): everything its tile head needs in one 16-byte load
+      int c3[3];
+      tile_coords(V, tile, c3[0], c3[1], c3[2]);
+      const uint32_t interior = (c3[0] * 8 + 7 < V.res[0] && c3[1] * 8 + 7 < V.res[1] && c3[2] * 8 + 7 < V.res[2]) ? 1u : 0u;
+      recs[w] = make_uint4(pairs, (uint32_t)tile, (uint32_t)c3[0] | ((uint32_t)c3[1] << 10) | ((uint32_t)c3[2] << 20) | (interior << 30), st);
+    }
     // projection cache: is the tile's (u, v, z) table in the pool?  No: deal it a slot (the LDS kernel fills it while it integrates the
     // tile, this frame) -- or, pool exhausted, leave the tile to the LDS kernel for good
     if (PC.items && ln == 0) {
@@ -607,6 +613,188 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
             float* __restrict__ const o = fill_base + (uint32_t)(__mul24(__mul24(i, (int)PC.dz_max), 64) + e) * 3u;
             o[0] = r.x; o[1] = r.y; o[2] = r.z;
           }
+        }
+        __syncthreads();
+      }
+      RR_STAMP(_stream_slot + 2);                                                    // passes X and Y done
+      bool any_drawn = false;
+#pragma unroll
+      for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
+      if (__ballot(any_drawn) != 0ull) {                                // phase Z
+        const int x0 = s_i0[0][lx] - mx, x1 = s_i1[0][lx] - mx;
+        const int y0 = __mul24(s_i0[1][ly] - my, dx), y1 = __mul24(s_i1[1][ly] - my, dx);
+        const int pl = __mul24(dx, dy);
+        const float wx = s_w[0][lx], wy = s_w[1][ly];
+#pragma unroll
+        for (int h = 0; h < kVox; ++h) {
+          const int kz = lz + 4 * h;
+          const int z0 = __mul24(s_i0[2][kz] - mz, pl), z1 = __mul24(s_i1[2][kz] - mz, pl);
+          float3 pc;                                                    // texture(cv_xyz_inv[i], position).xyz, :31
+          if (kSep) {
+            pc = lerp3(s_box[(((s_i0[2][kz] - mz) << 3) + ly) * 8 + lx], s_box[(((s_i1[2][kz] - mz) << 3) + ly) * 8 + lx], s_w[2][kz]);
+          } else {
+            const float3 c00 = lerp3(s_box[z0 + y0 + x0], s_box[z0 + y0 + x1], wx), c10 = lerp3(s_box[z0 + y1 + x0], s_box[z0 + y1 + x1], wx);
+            const float3 c01 = lerp3(s_box[z1 + y0 + x0], s_box[z1 + y0 + x1], wx), c11 = lerp3(s_box[z1 + y1 + x0], s_box[z1 + y1 + x1], wx);
+            pc = lerp3(lerp3(c00, c10, wy), lerp3(c01, c11, wy), s_w[2][kz]);
+          }
+          // the gather and the fusion rule are two branches on purpose: in one branch the compiler keeps voxel 1's loads behind
+          // voxel 0's arithmetic; apart, the unrolled loop has both voxels' gathers in flight together
+          Dqs q;
+          if (drawn[h]) q = dqs_fetch(F, i, pc.x, pc.y);
+          if (drawn[h]) {
+            float weighted_tsd = tsd[h], total_weight = wsum[h];        // tsdf_integration.vs:30-55, in stream order
+            bool skip = false;
+            if (dqs_silhouette(q) < 1.0f) {
+              if (weighted_tsd >= limit) { weighted_tsd = -limit; skip = true; }
+            }
+            if (!skip) {
+              const float sdist = pc.z - dqs_depth(q);
+              if (sdist <= -limit) {
+                weighted_tsd = -limit;
+              } else if (sdist >= limit) {
+              } else {
+                const float weight = dqs_quality(q);
+                weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
+                total_weight += weight;
+              }
+            }
+            tsd[h] = weighted_tsd; wsum[h] = total_weight;
+          }
+        }
+      }
+      RR_STAMP(_stream_slot + 3);                                                    // phase Z done (gathers + fusion)
+      _stream_slot += 4;
+    }
+    RR_STAMP(13);
+#pragma unroll
+    for (int h = 0; h < kVox; ++h) { tsd[h] = drawn[h] ? tsd[h] : -limit; out[tid + 256 * h] = tsd[h]; }   // clearImage(-limit), :249-250
+    RR_STAMP(14);
+    store_tile_class(S, tile, tsd[0] == -limit && tsd[1] == -limit);
+    RR_STAMP(15);
+  }
+}
+
+
+// Record form (round 4): the LDS form for launches with pair classes, dense storage and no projection cache -- every BASELINE configuration --, with the
+// tile head the in-kernel stamps asked for (profiles/r04_k1_phase_trace_*.txt: a quarter of a tile's cycles went by before its first stream, in a chain of
+// scalar loads -- list entry, pair classes, a dozen kernel-argument reloads forced by SGPR pressure -- each waited for at once).  k_pair_masks leaves a
+// 16-byte record per work item and the head is one load, requested a tile ahead; the per-voxel "is it drawn" test is a template parameter (off where
+// bricks and tiles coincide: no brick tables in the hot variant).
+template <bool kList, bool kCheck>
+__global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, const uint4* __restrict__ recs) {
+  [[maybe_unused]] constexpr bool kSep = true, kRanges = true, kCache = false;
+  __shared__ float4 s_box[kBoxCap];             // the stream's texel box, x fastest: ((z - mz) * dy + (y - my)) * dx + (x - mx)
+  __shared__ float4 s_row[kSep ? kRowCap : 1];  // (separable form) x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
+  __shared__ int s_i0a[TSDF_MAX_STREAMS][3][8], s_i1a[TSDF_MAX_STREAMS][3][8];   // per stream, axis and voxel coordinate of the tile: the two texel indices ...
+  __shared__ float s_wa[TSDF_MAX_STREAMS][3][8];                                 // ... and the weight of the GL LINEAR filter
+  const float step[3] = {1.0f / (float)V.res[0], 1.0f / (float)V.res[1], 1.0f / (float)V.res[2]};       // volume_sampler.cpp:36-38
+  const float limit = V.limit;
+  const int n_work = kList ? (int)*S.count : S.n;
+  const int tid = threadIdx.x;
+  if (kList && blockIdx.x == 0 && tid == 0) *S.next_count = 0u;                    // the previous list was consumed by the classify launch
+  // INVARIANT of the tile loop: every exit from an iteration after phase A has touched s_* passes through store_tile_class(), whose
+  // workgroup barrier is what lets the next iteration overwrite s_* (there is no barrier at the head of the loop).  The `continue`s
+  // below are workgroup-uniform and sit in front of phase A.
+  // Round 4 (in-kernel stamps, profiles/r04_k1_phase_trace_*.txt): 29 % of a tile's 24 k cycles went by BEFORE its first stream -- the list entry (a
+  // dependent scalar load), then phase A's per-lane loads of the LUT resolutions out of the kernel arguments (a vector-memory round trip per tile for
+  // values that never change).  Now: a thread's phase-A assignment (stream, axis, coordinate) is fixed by its index, so its LUT resolution is loaded
+  // once per workgroup (into LDS); the next tile's list entry and pair classes are requested at the head of the current tile.
+  __shared__ int s_invres[TSDF_MAX_STREAMS][3], s_vres[3];                         // LUT / volume resolutions: phase A reads them per (stream, axis) -- from LDS, once per workgroup
+  __shared__ float s_step[3];
+  if (tid < T.n * 3) s_invres[tid / 3][tid % 3] = T.s[tid / 3].inv_res[tid % 3];
+  if (tid < 3) { s_vres[tid] = tid == 0 ? V.res[0] : (tid == 1 ? V.res[1] : V.res[2]); s_step[tid] = tid == 0 ? step[0] : (tid == 1 ? step[1] : step[2]); }
+  __syncthreads();
+  // The work item's record (k_pair_masks): {pair classes, tile id, tile coordinates + "every voxel lies inside the volume", stored tile index}.  The next
+  // item's record is requested at the head of the current one -- as a VECTOR load (mbcnt keeps the compiler from proving the address uniform): scalar loads
+  // share their counter with the LDS operations, whose waits would expose it at once, while a vector load's counter is in order and waited for by number.
+  const int lane0 = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);                          // 0 in every lane
+  uint4 rec_next = recs[(blockIdx.x < n_work ? blockIdx.x : 0) + lane0];
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    RR_STAMP(0);                                                                     // tile head
+    [[maybe_unused]] int _stream_slot = 3;
+    const uint32_t pairs = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_next.x), packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_next.z);
+    const int tile = __builtin_amdgcn_readfirstlane((int)rec_next.y);
+    const uint32_t stored = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_next.w);
+    { const int wn = w + (int)gridDim.x; rec_next = recs[(wn < n_work ? wn : w) + lane0]; }
+    const int t3[3] = {(int)(packed & 1023u), (int)((packed >> 10) & 1023u), (int)((packed >> 20) & 1023u)};
+    const bool interior = (packed >> 30) & 1u;                          // all 512 voxels of the tile lie inside the volume
+    float* __restrict__ out = V.data + ((size_t)stored << 9);
+    constexpr int kVox = 2;                                             // voxels per thread: local z = lz and lz + 4, same x and y
+    const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
+    const int x = t3[0] * 8 + lx, y = t3[1] * 8 + ly;
+    bool drawn[kVox];
+    float tsd[kVox], wsum[kVox];
+    const bool check_voxels = kCheck && !(T.n <= 15 && (pairs >> 31));
+#pragma unroll
+    for (int h = 0; h < kVox; ++h) {
+      const int z = t3[2] * 8 + lz + 4 * h;
+      drawn[h] = interior || ((x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]));
+      if (kCheck && drawn[h] && check_voxels) drawn[h] = voxel_drawn(B, x, y, z);
+      tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
+      wsum[h] = 0.0f;
+    }
+    // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)                // (kRanges) 2 bits per stream, from k_pair_masks: which streams treat every voxel of this tile alike
+    for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
+      const int i = t / 24, a = (t % 24) >> 3, k = t & 7;
+      const int ta = a == 0 ? t3[0] : (a == 1 ? t3[1] : t3[2]);
+      const int coord = min(ta * 8 + k, s_vres[a] - 1);                 // padding voxels reuse the last real coordinate
+      const Axis ax = axis_linear(((float)coord + 0.5f) * s_step[a], s_invres[i][a]);
+      s_i0a[i][a][k] = ax.i0; s_i1a[i][a][k] = ax.i1; s_wa[i][a][k] = ax.a;
+    }
+    RR_STAMP(1);                                                                     // own part of phase A done (incl. the voxel checks)
+    __syncthreads();
+    RR_STAMP(2);                                                                     // phase A barrier passed
+    for (int i = 0; i < T.n; ++i) {
+      if (kRanges) {
+        const int pair = (int)((pairs >> (2 * i)) & 3u);                // workgroup-uniform
+        if (pair != kPairFull) {                                        // no box, no passes, no gathers: the branch is the same for every voxel
+#pragma unroll
+          for (int h = 0; h < kVox; ++h)
+            if (drawn[h]) {
+              if (pair == kPairNeg) tsd[h] = -limit;
+              else if (pair == kPairCarve && tsd[h] >= limit) tsd[h] = -limit;
+            }
+          continue;
+        }
+      }
+      const StreamLut& L = T.s[i];
+      const int (*s_i0)[8] = s_i0a[i];
+      const int (*s_i1)[8] = s_i1a[i];
+      const float (*s_w)[8] = s_wa[i];
+      if (i) __syncthreads();                                           // the previous stream's readers of s_box are done
+      const int mx = s_i0[0][0], my = s_i0[1][0], mz = s_i0[2][0];
+      const int dx = s_i1[0][7] - mx + 1, dy = s_i1[1][7] - my + 1, dz = s_i1[2][7] - mz + 1;
+      {                                                                 // phase B
+        const int n = min(__mul24(__mul24(dx, dy), dz), kBoxCap);
+        // e -> (bx, by, bz) without integer division (three of them are ~45 VALU instructions, and VALU issue is this launch's largest cost):
+        // floor((e + .5) * (1 / d)) in fp32 equals e / d for all 0 <= e < 1024, 1 <= d <= 1024 (checked exhaustively; the quotient is at
+        // least 0.5 / d away from the next integer, four orders of magnitude more than the 1 ulp of the hardware reciprocal)
+        const float rdx = __builtin_amdgcn_rcpf((float)dx), rdy = __builtin_amdgcn_rcpf((float)dy);
+        for (int e = tid; e < n; e += 256) {
+          const int row = (int)(((float)e + 0.5f) * rdx);               // e / dx
+          const int bz = (int)(((float)row + 0.5f) * rdy);              // row / dy
+          const int bx = e - __mul24(row, dx), by = row - __mul24(bz, dy);
+          // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): operands are LUT
+          // coordinates / resolutions <= 2048, the texel index fits 32 bits (tsdf_set_calibration rejects larger LUTs)
+          s_box[e] = L.inv[(uint32_t)__mul24(__mul24(mz + bz, L.inv_res[1]) + (my + by), L.inv_res[0]) + (uint32_t)(mx + bx)];
+        }
+      }
+      RR_STAMP(_stream_slot);                                                        // own box texels stored
+      __syncthreads();
+      RR_STAMP(_stream_slot + 1);                                                    // phase B barrier passed
+      if (kSep) {                                                       // passes X and Y
+        const int n1 = min(__mul24(__mul24(dy, dz), 8), kRowCap);
+        for (int e = tid; e < n1; e += 256) {
+          const int k = e & 7, rb = __mul24(e >> 3, dx);
+          const float3 r = lerp3(s_box[rb + (s_i0[0][k] - mx)], s_box[rb + (s_i1[0][k] - mx)], s_w[0][k]);
+          s_row[e] = make_float4(r.x, r.y, r.z, 0.0f);
+        }
+        __syncthreads();
+        const int n2 = min(dz << 6, kBoxCap);
+        for (int e = tid; e < n2; e += 256) {                           // the y-lerped planes overwrite the box
+          const int k = e & 7, j = (e >> 3) & 7, zb = __mul24(e >> 6, dy);
+          const float3 r = lerp3(s_row[((zb + (s_i0[1][j] - my)) << 3) + k], s_row[((zb + (s_i1[1][j] - my)) << 3) + k], s_w[1][j]);
+          s_box[e] = make_float4(r.x, r.y, r.z, 0.0f);
         }
         __syncthreads();
       }
@@ -855,12 +1043,14 @@ void launch_item_stats(hipStream_t st, const StreamTable& T, const TileState& S,
 }
 
 void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F, const Volume& V, const Bricks& B, const TileState& S, int use_bricks, int lds_ok,
-                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, const float4* tile_bounds, uint32_t* pair_masks, const ProjCache* proj) {
+                      int full_classify, uint32_t frame_stamp, int phase, const PeelClear* pc, const float4* tile_bounds, uint32_t* pair_masks, const ProjCache* proj,
+                      uint4* work_recs) {
   // phase 1: tile classification + stale-tile clear; 2: pair-mask pass + integrate kernel(s); 3: the pair-mask pass alone; 4: the integrate
   // kernel(s) alone; 0: everything (the split lets the caller time the kernels separately)
   const ProjCache none_pc{};
   const bool ranges = F.ranges && tile_bounds && pair_masks && lds_ok >= 2;
   const bool cached = ranges && proj && proj->data;
+  const bool rec = ranges && !cached && !V.slot && work_recs;           // k_integrate_tiles_rec
   const ProjCache& PC = cached ? *proj : none_pc;
   const int pvc = use_bricks ? (S.uniform ? 0 : 1) : 0;
   if (use_bricks && phase < 2) {
@@ -874,8 +1064,8 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
   }
   if (phase == 1) return;
   if (ranges && phase != 4) {
-    if (use_bricks) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, B, S, pvc, tile_bounds, pair_masks, PC);
-    else hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds, pair_masks, PC);
+    if (use_bricks) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, B, S, pvc, tile_bounds, pair_masks, rec ? work_recs : nullptr, PC);
+    else hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds, pair_masks, rec ? work_recs : nullptr, PC);
   }
   if (phase == 3) return;
   if (use_bricks) {
@@ -889,6 +1079,8 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
       hipLaunchKernelGGL((k_integrate_cached<true, RR_K1C_CHUNK>), dim3(RR_K1C_GRID), dim3(64), 0, st, T.n, F, V, B, S, pvc, S.count, S.list, pair_masks, PC.items, PC);
       hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
     }
+    else if (rec && pvc) hipLaunchKernelGGL((k_integrate_tiles_rec<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, work_recs);
+    else if (rec) hipLaunchKernelGGL((k_integrate_tiles_rec<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, work_recs);
     else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
     else if (lds_ok >= 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
@@ -903,7 +1095,8 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
       // lanes 2.5 % faster (4 349 against 4 242 frames/s; 8 192: 4 380 but the launch alone 125 us, 2 048: 3 796); RR_K1_DENSE_GRID: A/B hook
       static const int dcap = [] { const char* e = getenv("RR_K1_DENSE_GRID"); return e ? atoi(e) : 16384; }();
       const dim3 dgrid(dcap > 0 && dcap < S.n ? dcap : S.n);
-      hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dgrid, dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);
+      if (rec) hipLaunchKernelGGL((k_integrate_tiles_rec<false, false>), dgrid, dim3(256), 0, st, T, F, V, B, S, work_recs);
+      else hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dgrid, dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);
     }
     else if (lds_ok >= 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr, PC);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<false, false>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr, PC);

@@ -230,7 +230,8 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
                       int full_classify, uint32_t frame_stamp, int phase = 0, const PeelClear* pc = nullptr,
                       const float4* tile_bounds = nullptr,   // per (stored tile, stream) 2 x float4 LUT-box bounds (launch_tile_bounds), or null
                       uint32_t* pair_masks = nullptr,         // per work item: the frame's pair classes (written by the launch itself), or null
-                      const ProjCache* proj = nullptr);       // projection cache (needs tile_bounds / pair_masks: its work items are classified by the pair-mask pass), or null
+                      const ProjCache* proj = nullptr,        // projection cache (needs tile_bounds / pair_masks: its work items are classified by the pair-mask pass), or null
+                      uint4* work_recs = nullptr);            // per work item: the 16-byte record of k_integrate_tiles_rec (written by the pair-mask pass), or null
 // [work items, cached items, (tile, stream) pairs of cached items evaluated per voxel, items taken by the LDS kernel] of the last launch -> out[4] (device)
 void launch_item_stats(hipStream_t st, const StreamTable& T, const TileState& S, int use_bricks, const uint32_t* pair_masks, const ProjCache& PC, uint32_t* out);
 void launch_tile_bounds(hipStream_t st, const StreamTable& T, const Volume& V, float4* bounds);
