@@ -203,8 +203,13 @@ __global__ __launch_bounds__(256) void k_classify_lists(Volume V, Bricks B, Tile
 // The dense march leaps over whole runs of kTileMinus tiles (k_march_box, k_raymarch.hip); for the culled path an exact class only
 // means that such a tile needs no reset when it stops being active.  One __syncthreads_and per tile.
 __device__ __forceinline__ void store_tile_class(const TileState& S, int tile, bool mine_all_clear) {
-  const int all = __syncthreads_and(mine_all_clear ? 1 : 0);
-  if (threadIdx.x == 0) S.cls[tile] = all ? kTileMinus : kTileMixed;
+  // one ballot per wave, one LDS flag per wave, ONE barrier (round 4; __syncthreads_and is a DPP reduction, an LDS atomic and three barriers).  The flags are
+  // read by thread 0 right behind the barrier and written again one whole tile later, behind that tile's own barriers.
+  __shared__ int s_wave_clear[4];
+  const bool wave_clear = __ballot(!mine_all_clear) == 0ull;
+  if ((threadIdx.x & 63) == 0) s_wave_clear[threadIdx.x >> 6] = wave_clear ? 1 : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) S.cls[tile] = (s_wave_clear[0] & s_wave_clear[1] & s_wave_clear[2] & s_wave_clear[3]) ? kTileMinus : kTileMixed;
 }
 
 // Shared tile loop: which tile does work item w map to
