@@ -768,7 +768,7 @@ def main():
         kn = "k_integrate_tiles_lds" if kname == "k_integrate_tiles" else "k_march"
         traffic = measured_traffic(cfgname, kn)
         valu = measured_traffic(cfgname, kn, "valu_insts")
-        return {"bound": "hbm", "kernel": kn, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        return {"bound": "hbm", "kernel": "k_integrate_tiles_rec (the LDS form, record head)" if kn == "k_integrate_tiles_lds" else kn, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes": alg, "avg_launch_ms": ms,
                 "traffic_frac": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 # share of the SIMDs' vector issue capacity: a SIMD-32 issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md,

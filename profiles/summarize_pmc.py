@@ -20,7 +20,8 @@ import json
 import os
 import sys
 
-GROUPS = {"k_integrate_tiles_lds": ("k_integrate_tiles_lds",), "k_march": ("k_march",), "k_march+k_shade": ("k_march", "k_shade"),   # k_march covers both passes (k_march<>, k_march_long)
+GROUPS = {"k_integrate_tiles_lds": ("k_integrate_tiles_lds", "k_integrate_tiles_rec"),   # (round 4: k_integrate_tiles_rec is the LDS form with the record head; one of the two runs per launch)
+          "k_march": ("k_march",), "k_march+k_shade": ("k_march", "k_shade"),                  # k_march covers both passes (k_march<>, k_march_long)
           # round 4: the pre-processing passes (configs named *_preprocess: bench.py --preprocess)
           "k_pre_morph": ("k_pre_morph",), "k_pre_filter": ("k_pre_filter",), "k_pre_boundary": ("k_pre_boundary",), "k_pre_normal": ("k_pre_normal",), "k_pre_quality": ("k_pre_quality",)}
 

@@ -35,3 +35,7 @@ for k in range(1, 16):
     if d.size:
         print(f"{names[k]:16s} n={d.size:5d} mean {d.mean():8.1f} median {np.median(d):8.1f} p90 {np.percentile(d, 90):8.1f}")
     prev = np.where(valid, cur, prev)
+
+h = (t[:, 11] >= t[:, 0]) & (t[:, 12] >= t[:, 11]) & (t[:, 12] <= t[:, 1])
+if h.any():
+    print(f"three back-to-back stamps at the loop top (n={int(h.sum())}): 0 -> 11: mean {np.mean(t[h, 11] - t[h, 0]):.0f} median {np.median(t[h, 11] - t[h, 0]):.0f}; 11 -> 12: mean {np.mean(t[h, 12] - t[h, 11]):.0f} median {np.median(t[h, 12] - t[h, 11]):.0f}; 12 -> phase A own part done: mean {np.mean(t[h, 1] - t[h, 12]):.0f}")
