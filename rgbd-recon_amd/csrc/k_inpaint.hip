@@ -144,12 +144,22 @@ __global__ __launch_bounds__(256) void k_inpaint_level(Atlas A, int w, int lod, 
 // The small tail of the pyramid (levels first_lod + 1 .. num_lods - 1, a few thousand pixels in all) in ONE
 // workgroup: each level is a loop over its pixels, a workgroup barrier orders a level's global stores before
 // the next level's loads (same CU, workgroup-scope fence), and the launch boundaries between them disappear.
+#ifdef RR_TAIL_TRACE     // tools/build_k1_variant.sh tailtrace "-DRR_TAIL_TRACE" k_inpaint: s_memtime stamps of thread 0 at the level boundaries of the last launch (tools/tail_trace.py)
+__device__ unsigned long long g_tail_trace[32];
+#define RR_TAIL_STAMP(k) do { if (threadIdx.x == 0) g_tail_trace[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RR_TAIL_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void k_inpaint_tail(Atlas A, int w, int first_lod) {
+  RR_TAIL_STAMP(0);
+  RR_TAIL_STAMP(1);
   for (int lod = first_lod; lod + 1 < A.num_lods; ++lod) {
     const int rx = A.res[lod + 1][0], n = rx * A.res[lod + 1][1];
     for (int i = threadIdx.x; i < n; i += blockDim.x) inpaint_pixel(A, w, lod, i % rx, i / rx);
+    RR_TAIL_STAMP(2 + 2 * (lod - first_lod));
     __threadfence_block();
     __syncthreads();
+    RR_TAIL_STAMP(3 + 2 * (lod - first_lod));
   }
 }
 constexpr int kTailPixels = 1024;   // levels with at most this many pixels go to the fused tail (one pass of 1024 threads each)
@@ -291,3 +301,8 @@ void launch_clear_image(hipStream_t st, float4* color, float* depth, size_t n, f
 }
 
 }  // namespace rr
+#ifdef RR_TAIL_TRACE
+extern "C" __attribute__((visibility("default"))) int tsdf_debug_tail_trace(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rr::g_tail_trace), sizeof(unsigned long long) * (size_t)(n < 32 ? n : 32));
+}
+#endif

@@ -685,6 +685,16 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
 // scalar loads -- list entry, pair classes, a dozen kernel-argument reloads forced by SGPR pressure -- each waited for at once).  k_pair_masks leaves a
 // 16-byte record per work item and the head is one load, requested a tile ahead; the per-voxel "is it drawn" test is a template parameter (off where
 // bricks and tiles coincide: no brick tables in the hot variant).
+// Wave priority by phase (A/B hook, tools/build_k1_variant.sh prioN "-DRR_K1_PRIO=N"): does a tile's head starve behind the other waves' long VALU runs?
+#ifdef RR_K1_PRIO
+#define RR_PRIO(site) do { constexpr int _v = RR_K1_PRIO, _s = (site); \
+  if (_v == 1) { if (_s == 0 || _s == 7) __builtin_amdgcn_s_setprio(3); else if (_s == 3) __builtin_amdgcn_s_setprio(0); } \
+  else if (_v == 2) { if (_s == 0) __builtin_amdgcn_s_setprio(3); else if (_s == 1) __builtin_amdgcn_s_setprio(0); } \
+  else if (_v == 3) { if (_s == 4) __builtin_amdgcn_s_setprio(0); else if (_s == 6 || _s == 0) __builtin_amdgcn_s_setprio(3); } \
+  else if (_v == 4) { if (_s == 4) __builtin_amdgcn_s_setprio(3); else if (_s == 6 || _s == 0) __builtin_amdgcn_s_setprio(0); } } while (0)
+#else
+#define RR_PRIO(site) do { } while (0)
+#endif
 template <bool kList, bool kCheck>
 __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, const uint4* __restrict__ recs) {
   [[maybe_unused]] constexpr bool kSep = true, kRanges = true, kCache = false;
@@ -716,6 +726,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
   uint4 rec_next = recs[(blockIdx.x < n_work ? blockIdx.x : 0) + lane0];
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     RR_STAMP(0);                                                                     // tile head
+    RR_PRIO(0);
     [[maybe_unused]] int _stream_slot = 3;
     const uint32_t pairs = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_next.x), packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_next.z);
     const int tile = __builtin_amdgcn_readfirstlane((int)rec_next.y);
@@ -749,6 +760,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
     RR_STAMP(1);                                                                     // own part of phase A done (incl. the voxel checks)
     __syncthreads();
     RR_STAMP(2);                                                                     // phase A barrier passed
+    RR_PRIO(1);
     for (int i = 0; i < T.n; ++i) {
       if (kRanges) {
         const int pair = (int)((pairs >> (2 * i)) & 3u);                // workgroup-uniform
@@ -785,6 +797,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
         }
       }
       RR_STAMP(_stream_slot);                                                        // own box texels stored
+      RR_PRIO(3);
       __syncthreads();
       RR_STAMP(_stream_slot + 1);                                                    // phase B barrier passed
       if (kSep) {                                                       // passes X and Y
@@ -804,6 +817,7 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
         __syncthreads();
       }
       RR_STAMP(_stream_slot + 2);                                                    // passes X and Y done
+      RR_PRIO(4);
       bool any_drawn = false;
 #pragma unroll
       for (int h = 0; h < kVox; ++h) any_drawn |= drawn[h];
@@ -850,9 +864,11 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
         }
       }
       RR_STAMP(_stream_slot + 3);                                                    // phase Z done (gathers + fusion)
+      RR_PRIO(6);
       _stream_slot += 4;
     }
     RR_STAMP(13);
+    RR_PRIO(7);
 #pragma unroll
     for (int h = 0; h < kVox; ++h) { tsd[h] = drawn[h] ? tsd[h] : -limit; out[tid + 256 * h] = tsd[h]; }   // clearImage(-limit), :249-250
     RR_STAMP(14);
