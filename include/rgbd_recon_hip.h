@@ -244,7 +244,10 @@ int32_t tsdf_set_camera_position(tsdf_ctx* ctx, uint32_t stream, const float xyz
 /* filterTextures / useProcessedDepths / refineBoundary, NetKinectArray.cpp:466-480 (all default true, :63-69) */
 int32_t tsdf_set_preprocess(tsdf_ctx* ctx, int32_t filter_textures, int32_t processed_depth, int32_t refine_boundary);
 int32_t tsdf_process_textures(tsdf_ctx* ctx);
-/* products, any pointer may be NULL: depth2 [N][H][W], depth_rg [..][2], lab [..][3], depth_b [..][2], silhouette, normals [..][3], quality */
+/* products, any pointer may be NULL: depth2 [N][H][W], depth_rg [..][2], lab [..][3], depth_b [..][2], silhouette, normals [..][3], quality.
+ * lab (the Lab colour image pre_depth.fs writes, read only by pre_boundary.fs) is evaluated by the passes only around the boundary pass's candidate
+ * pixels; the whole image is produced by THIS call, from the inputs of the frame that was processed: TSDF_ERR_STATE when a newer raw frame has been
+ * uploaded since tsdf_process_textures (ask before the next upload, or pass lab = NULL). */
 int32_t tsdf_download_preprocessed(tsdf_ctx* ctx, float* depth2, float* depth_rg, float* lab, float* depth_b, float* silhouette, float* normals, float* quality);
 
 /* ---- brick occupancy: clearOccupiedBricks / mark_brick / updateOccupiedBricks -------------------- */

@@ -346,12 +346,16 @@ class ReconIntegrationHip:
 
     def processTextures(self): self._ck(self._L.tsdf_process_textures(self._c))
 
-    def preprocessed(self):
+    def preprocessed(self, lab=True):
+        """the products of processTextures(); lab=False leaves out the Lab image, which the library produces on request from the processed frame's inputs
+        (an error once a newer raw frame has been uploaded)"""
         n, h, w = self._pp_shape
         out = dict(depth2=np.zeros((n, h, w), np.float32), depth_rg=np.zeros((n, h, w, 2), np.float32), lab=np.zeros((n, h, w, 3), np.float32),
                    depth_b=np.zeros((n, h, w, 2), np.float32), silhouette=np.zeros((n, h, w), np.float32),
                    normals=np.zeros((n, h, w, 3), np.float32), quality=np.zeros((n, h, w), np.float32))
-        self._ck(self._L.tsdf_download_preprocessed(self._c, _fp(out["depth2"]), _fp(out["depth_rg"]), _fp(out["lab"]), _fp(out["depth_b"]),
+        if not lab:
+            del out["lab"]
+        self._ck(self._L.tsdf_download_preprocessed(self._c, _fp(out["depth2"]), _fp(out["depth_rg"]), _fp(out["lab"]) if lab else None, _fp(out["depth_b"]),
                                                     _fp(out["silhouette"]), _fp(out["normals"]), _fp(out["quality"])))
         return out
 

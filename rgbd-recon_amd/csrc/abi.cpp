@@ -1109,7 +1109,7 @@ int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t
   HIP_TRY(c, hipMemcpyAsync(c->d_raw, depth_raw, np * sizeof(float), hipMemcpyHostToDevice, lane));
   HIP_TRY(c, hipMemcpyAsync(c->d_stage_col, colour, nc * 3, hipMemcpyHostToDevice, lane));
   c->pending_rgb = c->d_stage_col;                                       // its RGBA8 re-layout rides along in tsdf_process_textures' first launch
-  c->raw_src = c->d_raw; c->have_raw = true;
+  c->raw_src = c->d_raw; c->have_raw = true; ++c->raw_generation;
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
@@ -1129,7 +1129,7 @@ int32_t tsdf_upload_raw_frame_dev(tsdf_ctx* c, const float* depth_raw, const uin
   }
   if (int32_t rc = begin_slot_write(c, lane, false)) return rc;
   c->pending_rgb = colour;                                               // its RGBA8 re-layout rides along in tsdf_process_textures' first launch
-  c->raw_src = depth_raw; c->have_raw = true;
+  c->raw_src = depth_raw; c->have_raw = true; ++c->raw_generation;
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
@@ -1218,7 +1218,7 @@ int32_t tsdf_upload_wire_frame(tsdf_ctx* c, const void* message, uint64_t bytes,
   launch_wire_unpack(lane, L, (uchar4*)c->frame.color, c->d_raw);
   timer_end_on(c, "0ingest", lane);
   HIP_TRY(c, hipGetLastError());
-  c->raw_src = c->d_raw; c->have_raw = true;
+  c->raw_src = c->d_raw; c->have_raw = true; ++c->raw_generation;
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
@@ -1248,6 +1248,13 @@ int32_t tsdf_set_preprocess(tsdf_ctx* c, int32_t filter_textures, int32_t proces
   c->pre.filter_textures = filter_textures != 0; c->use_processed_depth = processed_depth != 0; c->pre.refine = refine != 0;
   return TSDF_OK;
 }
+static PreBuffers pre_buffers(tsdf_ctx* c) {
+  PreBuffers B{};
+  B.raw = c->raw_src; B.depth2 = c->d_depth2; B.fdepth = c->use_processed_depth ? c->d_depth2 : c->raw_src;
+  B.depth_rg = c->d_depth_rg; B.lab = c->d_lab; B.depth_b = c->d_depth_b; B.normal = c->d_normal;
+  B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
+  return B;
+}
 int32_t tsdf_process_textures(tsdf_ctx* c) {
   CHECK_CTX(c);
   if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "no raw frame uploaded (tsdf_upload_raw_frame)");
@@ -1267,10 +1274,8 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
   PreParams& P = c->pre;
   P.W = c->frame.w; P.H = c->frame.h; P.N = (int)c->cfg.num_streams;
   for (int a = 0; a < 3; ++a) { P.bbox_min[a] = c->cfg.bbox_min[a]; P.bbox_max[a] = c->cfg.bbox_max[a]; }
-  PreBuffers B{};
-  B.raw = c->raw_src; B.depth2 = c->d_depth2; B.fdepth = c->use_processed_depth ? c->d_depth2 : c->raw_src;
-  B.depth_rg = c->d_depth_rg; B.lab = c->d_lab; B.depth_b = c->d_depth_b; B.normal = c->d_normal;
-  B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
+  const PreBuffers B = pre_buffers(c);
+  c->pre_generation = c->raw_generation; c->pre_processed_depth = c->use_processed_depth;
   timer_begin_on(c, "1preprocess", lane);
   const size_t ncol = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
   if (c->timers_on && c->timer_filter.find(",k_pre_") != std::string::npos) {   // each pass between its own pair of events, when the timer filter NAMES them (a pair costs the lane ~7 us)
@@ -1300,6 +1305,15 @@ int32_t tsdf_download_preprocessed(tsdf_ctx* c, float* depth2, float* depth_rg, 
   std::vector<float4> tmp;
   auto fetch4 = [&](const void* src) -> int32_t { tmp.resize(np); HIP_TRY(c, hipMemcpy(tmp.data(), src, np * 16, hipMemcpyDeviceToHost)); return TSDF_OK; };
   int32_t rc;
+  if (lab) {
+    // the Lab image of the filter pass: the passes evaluate it only where the boundary pass reads it (k_pre_boundary); the whole image is produced here, from the
+    // inputs of the frame that was processed -- which must still be the resident ones
+    if (c->pre_generation != c->raw_generation || c->pre_processed_depth != c->use_processed_depth)
+      FAIL(c, TSDF_ERR_STATE, "the Lab image is produced on request from the processed frame's inputs, and a newer raw frame has replaced them (download before the next upload)");
+    launch_pre_lab(c->stream, c->pre, pre_buffers(c), c->luts, c->frame);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   if (lab) { if ((rc = fetch4(c->d_lab))) return rc; for (size_t i = 0; i < np; ++i) { lab[3 * i] = tmp[i].x; lab[3 * i + 1] = tmp[i].y; lab[3 * i + 2] = tmp[i].z; } }
   if (normals) { if ((rc = fetch4(c->d_normal))) return rc; for (size_t i = 0; i < np; ++i) { normals[3 * i] = tmp[i].x; normals[3 * i + 1] = tmp[i].y; normals[3 * i + 2] = tmp[i].z; } }
   if (sil || quality) { if ((rc = fetch4(c->frame.dqs))) return rc; for (size_t i = 0; i < np; ++i) { if (quality) quality[i] = tmp[i].y; if (sil) sil[i] = tmp[i].z; } }

@@ -80,6 +80,7 @@ struct tsdf_ctx {
   float* d_raw = nullptr; float* d_depth2 = nullptr; float2* d_depth_rg = nullptr; float4* d_lab = nullptr; float2* d_depth_b = nullptr; float4* d_normal = nullptr;
   bool have_raw = false, use_processed_depth = true;
   const uint8_t* pending_rgb = nullptr;   // RGB8 colour of the raw frame uploaded last, still to be re-laid out into the frame slot (rides along in processTextures' first launch)
+  uint64_t raw_generation = 0, pre_generation = 0; bool pre_processed_depth = true;   // which raw upload the products of processTextures() belong to (the Lab image is produced on request from its inputs)
   const float* raw_src = nullptr;   // the raw depth the passes read: d_raw (host upload, wire unpack) or the caller's device array (tsdf_upload_raw_frame_dev)
   hipEvent_t normals_read = nullptr; bool normals_read_pending = false;   // recorded behind a point / triangle-grid draw: the lane ahead rewrites d_normal
   bool have_limits[TSDF_MAX_STREAMS]{}, have_cam[TSDF_MAX_STREAMS]{};

@@ -93,24 +93,43 @@ __device__ __forceinline__ float3 color_bilinear_pre(const FrameImages& F, int l
                      lerpf(lerpf(t00.z / 255.0f, t10.z / 255.0f, X.a), lerpf(t01.z / 255.0f, t11.z / 255.0f, X.a), Y.a));
 }
 
+// sample() / uncompress(), pre_depth.fs:51-72: the filter pass's input depth at a clamped tap
+__device__ __forceinline__ float pre_sample(const PreParams& P, const float* __restrict__ src, int l, int yy, int xx) {
+  float t = src[(size_t)clamp_tap(yy, P.H) * P.W + clamp_tap(xx, P.W)];
+  if (P.compress[l] != 0) { const float sn = P.dc_scaled_near[l]; t = t < sn ? 0.0f : (t * t + 0.15f * sn) * P.dc_scale[l] + P.dc_near[l]; }
+  return t;
+}
+// pre_depth.fs :131-143: the Lab colour the filter pass writes beside its depth -- the colour image looked up through cv_uv at the pixel's normalised
+// input depth.  Round 4: only pre_boundary.fs reads that image, and only around its candidate pixels (1.3 % of the c2 frame, in 6 % of its 16 x 16
+// blocks), while its six powf and eighteen IEEE divisions per pixel were two thirds of the filter pass's vector instructions: the boundary pass now
+// evaluates it for the blocks that need it (k_pre_boundary), and the full image is produced when somebody asks for it (k_pre_lab, tsdf_download_preprocessed).
+__device__ __forceinline__ float4 lab_of_pixel(const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, int l, int x, int y) {
+  const float depth = pre_sample(P, B.fdepth + (size_t)l * P.W * P.H, l, y, x);
+  const float mn = P.cv_min[l], mx = P.cv_max[l];
+  const float dn = (depth - mn) / (mx - mn);
+  const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
+  const StreamLut& L = T.s[l];
+  const float2 cc = tex3d_rg(L.uv, L.uv_res, u, v, (dn <= 0.0f || dn >= 1.0f) ? 1.0f : dn);     // :136
+  const float3 lab = rgb_to_lab(color_bilinear_pre(F, l, cc.x, cc.y));
+  return make_float4(lab.x, lab.y, lab.z, 0.0f);
+}
+__global__ __launch_bounds__(256) void k_pre_lab(PreParams P, PreBuffers B, StreamTable T, FrameImages F) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), l = blockIdx.z;
+  if (x < P.W && y < P.H) B.lab[(size_t)l * P.W * P.H + (size_t)y * P.W + x] = lab_of_pixel(P, B, T, F, l, x, y);
+}
+
 // ---- pre_depth.fs main() :129-154 with bilateral_filter :85-127.  The 13x13 window of a 16x16 pixel block is staged in
 // LDS (28x28 depths, clamped taps), so the 169 taps per pixel are LDS reads.
-__global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, StreamTable T, FrameImages F) {
+__global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, StreamTable T) {
   __shared__ float s_d[28][29];
   const int l = blockIdx.z, bx = blockIdx.x * 16, by = blockIdx.y * 16;
   const float* __restrict__ src = B.fdepth + (size_t)l * P.W * P.H;
-  const bool compress = P.compress[l] != 0;                      // sample() / uncompress(), pre_depth.fs:51-72
-  const float sn = P.dc_scaled_near[l], scale = P.dc_scale[l], nearv = P.dc_near[l];
-  const auto sample = [&](int yy, int xx) {
-    float t = src[(size_t)clamp_tap(yy, P.H) * P.W + clamp_tap(xx, P.W)];
-    if (compress) t = t < sn ? 0.0f : (t * t + 0.15f * sn) * scale + nearv;
-    return t;
-  };
+  const auto sample = [&](int yy, int xx) { return pre_sample(P, src, l, yy, xx); };
   const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, x = bx + lx, y = by + ly;
   const bool inside = x < P.W && y < P.H;
   const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
   const float mn = P.cv_min[l], mx = P.cv_max[l];
-  // the pixel's own part first (world position -> inside the bounding box?, Lab colour): the 13 x 13 window is staged in LDS only when some pixel of
+  // the pixel's own part first (world position -> inside the bounding box?): the 13 x 13 window is staged in LDS only when some pixel of
   // the block lies in the box -- most blocks of a frame see background, and their 784 window loads and the barrier bought nothing (round 4)
   const float depth = inside ? sample(y, x) : 0.0f;
   const float dn = (depth - mn) / (mx - mn);
@@ -120,9 +139,6 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
   if (inside) {
     const float3 wp = tex3d_rgba_xyz(L.xyz, L.xyz_res, u, v, dn);
     in_box = wp.x >= P.bbox_min[0] && wp.y >= P.bbox_min[1] && wp.z >= P.bbox_min[2] && wp.x <= P.bbox_max[0] && wp.y <= P.bbox_max[1] && wp.z <= P.bbox_max[2];
-    const float2 cc = tex3d_rg(L.uv, L.uv_res, u, v, (dn <= 0.0f || dn >= 1.0f) ? 1.0f : dn);     // :136
-    const float3 lab = rgb_to_lab(color_bilinear_pre(F, l, cc.x, cc.y));
-    B.lab[o] = make_float4(lab.x, lab.y, lab.z, 0.0f);
   }
   const bool taps = __syncthreads_or(in_box && P.filter_textures) != 0;   // (workgroup-uniform)
   if (taps) {
@@ -163,51 +179,81 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
   B.depth_rg[o] = od;
 }
 
-__device__ __forceinline__ float3 lab_bilinear(const float4* __restrict__ lab, int W, int H, float u, float v) {   // RGB32F LINEAR
-  const Axis X = axis_linear(u, W), Y = axis_linear(v, H);
-  const float4 t00 = lab[(size_t)Y.i0 * W + X.i0], t10 = lab[(size_t)Y.i0 * W + X.i1], t01 = lab[(size_t)Y.i1 * W + X.i0], t11 = lab[(size_t)Y.i1 * W + X.i1];
-  return make_float3(lerpf(lerpf(t00.x, t10.x, X.a), lerpf(t01.x, t11.x, X.a), Y.a), lerpf(lerpf(t00.y, t10.y, X.a), lerpf(t01.y, t11.y, X.a), Y.a),
-                     lerpf(lerpf(t00.z, t10.z, X.a), lerpf(t01.z, t11.z, X.a), Y.a));
-}
-
 // ---- pre_boundary.fs main() :86-117, get_color_diff :37-55
-__global__ __launch_bounds__(256) void k_pre_boundary(PreParams P, PreBuffers B) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), l = blockIdx.z;
-  if (x >= P.W || y >= P.H) return;
+// Round 4: 16 x 16-pixel blocks (the candidates -- pixels with a depth whose range quality is not above 0.65 -- run along silhouettes: 1.3 % of the pixels
+// of a c2 frame, in 6 % of its blocks).  A block with a candidate first
+// evaluates the Lab colour (lab_of_pixel) of its 22 x 22 neighbourhood into LDS -- the 5 x 5 taps of a bilinear fetch reach three pixels out --, the
+// candidates' 26 bilinear fetches read that tile.  (A fetch at pass_TexCoord + (kx, ky) * texSizeInv, |k| <= 2, lies within W * 3e-7 texels of the centre of
+// pixel (x + kx, y + ky) -- clamp_tap's argument above --, so its two texels per axis are among x + kx - 1 .. x + kx + 1: inside the tile.  The tile index is
+// clamped all the same, for the memory's sake, not the value's.)
+constexpr int kLabTile = 22, kLabHalo = 3;
+__global__ __launch_bounds__(256) void k_pre_boundary(PreParams P, PreBuffers B, StreamTable T, FrameImages F) {
+  __shared__ float4 s_lab[kLabTile][kLabTile];
+  __shared__ float2 s_drg[20][20];
+  const int l = blockIdx.z, bx = blockIdx.x * 16, by = blockIdx.y * 16;
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, x = bx + lx, y = by + ly;                     // a wave is 16 x 4 pixels: its stores are whole 128-byte / 64-byte row segments
+  const bool inside = x < P.W && y < P.H;
   const size_t base = (size_t)l * P.W * P.H, o = base + (size_t)y * P.W + x;
   const float2* __restrict__ drg = B.depth_rg + base;
-  const float4* __restrict__ lab = B.lab + base;
+  float2 d = inside ? drg[(size_t)y * P.W + x] : make_float2(0.0f, 0.0f);
+  const bool cand = inside && !(d.x <= 0.0f) && !(d.y > 0.65f);                         // valid_range, :27-30
+  if (__syncthreads_or(cand) != 0) {
+    // the candidates' 5 x 5 {depth, range quality} taps: staged too (with a load, a wait and a branch per tap the candidates' waves -- whose chain is
+    // the launch's length -- paid 25 L2 round trips in a row)
+    for (int i = threadIdx.x; i < 20 * 20; i += 256) {
+      const int ty = i / 20, tx = i - ty * 20;
+      s_drg[ty][tx] = drg[(size_t)clamp_tap(by - 2 + ty, P.H) * P.W + clamp_tap(bx - 2 + tx, P.W)];
+    }
+    for (int i = threadIdx.x; i < kLabTile * kLabTile; i += 256) {
+      const int ty = i / kLabTile, tx = i - ty * kLabTile, px = bx - kLabHalo + tx, py = by - kLabHalo + ty;
+      if (px >= 0 && py >= 0 && px < P.W && py < P.H) s_lab[ty][tx] = lab_of_pixel(P, B, T, F, l, px, py);
+    }
+    __syncthreads();
+  }
+  if (!inside) return;
+  const auto lab_at = [&](int ix, int iy) {                                               // texel (ix, iy) of the Lab image (indices already clamped to it)
+    const int tx = min(max(ix - (bx - kLabHalo), 0), kLabTile - 1), ty = min(max(iy - (by - kLabHalo), 0), kLabTile - 1);
+    return s_lab[ty][tx];
+  };
+  const auto lab_bilinear = [&](float uu, float vv) {                                     // RGB32F LINEAR
+    const Axis X = axis_linear(uu, P.W), Y = axis_linear(vv, P.H);
+    const float4 t00 = lab_at(X.i0, Y.i0), t10 = lab_at(X.i1, Y.i0), t01 = lab_at(X.i0, Y.i1), t11 = lab_at(X.i1, Y.i1);
+    return make_float3(lerpf(lerpf(t00.x, t10.x, X.a), lerpf(t01.x, t11.x, X.a), Y.a), lerpf(lerpf(t00.y, t10.y, X.a), lerpf(t01.y, t11.y, X.a), Y.a),
+                       lerpf(lerpf(t00.z, t10.z, X.a), lerpf(t01.z, t11.z, X.a), Y.a));
+  };
   const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
   const float tsx = 1.0f / (float)P.W, tsy = 1.0f / (float)P.H;
-  float2 d = drg[(size_t)tap_y(y, 0, P.H) * P.W + tap_x(x, 0, P.W)];
-  float sil = 1.0f;
-  if (d.x <= 0.0f) { d.y = 0.0f; sil = 0.0f; }
+  if (d.x <= 0.0f) d.y = 0.0f;
   else if (!(d.y > 0.65f)) {                                                             // valid_range, :27-30
-    sil = 0.0f;
-    const float3 color = lab_bilinear(lab, P.W, P.H, u, v);
+    const float3 color = lab_bilinear(u, v);
     float total = 0.0f, num = 0.0f;
     for (int ky = -2; ky < 3; ++ky)
       for (int kx = -2; kx < 3; ++kx) {
-        const float2 s = drg[(size_t)tap_y(y, ky, P.H) * P.W + tap_x(x, kx, P.W)];
+        const float2 s = s_drg[ly + 2 + ky][lx + 2 + kx];                // (staged with clamped coordinates: the texel tap_x / tap_y address)
         if (s.x > 0.0f && s.y > 0.65f) {
           num += 1.0f;
-          const float3 cs = lab_bilinear(lab, P.W, P.H, u + (float)kx * tsx, v + (float)ky * tsy);
+          const float3 cs = lab_bilinear(u + (float)kx * tsx, v + (float)ky * tsy);
           const float ex = color.x - cs.x, ey = color.y - cs.y, ez = color.z - cs.z;
           total += sqrtf(ex * ex + ey * ey + ez * ez);
         }
       }
     const float color_dist = (num < 16.0f * 0.5f) ? 1.0f : total / num;                  // total_samples = 16 (:23, :53)
-    if (color_dist > 0.5f || !P.refine) { d.x = -1.0f; d.y = 0.1f; sil = 0.0f; }
+    if (color_dist > 0.5f || !P.refine) { d.x = -1.0f; d.y = 0.1f; }
     else d.y = 1.0f;
   } else d.y = 0.0f;
+  // (the packed texel {depth, quality, silhouette} is written once, by the quality pass, which takes the silhouette from depth_b: pre_boundary_silhouette)
   B.depth_b[o] = d;
   B.depth_plane[o] = d.x;
-  B.dqs[o] = make_float4(d.x, 0.0f, sil, 0.0f);                                         // (quality: the last pass writes it)
 }
+// the silhouette pre_boundary.fs wrote beside depth_b = {d.x, d.y'}: 1 exactly for the pixels that took its last branch (a depth, range quality above 0.65:
+// d.y' = 0 and d.x untouched), 0 for the background (d.x <= 0) and for the candidates (d.y' = 0.1 or 1)
+__device__ __forceinline__ float pre_boundary_silhouette(float2 db) { return (db.y == 0.0f && !(db.x <= 0.0f)) ? 1.0f : 0.0f; }
 
 // ---- pre_normal.fs :26-56 including the mark_brick() call (:32-33)
+// (round 4: a wave is an 8 x 8 cell of a 16 x 16 block, not a 64 x 4 strip: 14 % of the cells of a c2 frame hold a depth, 19 % of the strips)
 __global__ __launch_bounds__(256) void k_pre_normal(PreParams P, PreBuffers B, StreamTable T, Bricks BR) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), l = blockIdx.z;
+  const int cell = threadIdx.x >> 6, ln = threadIdx.x & 63, l = blockIdx.z;
+  const int x = blockIdx.x * 16 + ((cell & 1) << 3) + (ln & 7), y = blockIdx.y * 16 + ((cell >> 1) << 3) + (ln >> 3);
   bool own = false, nbr = false;
   uint32_t id_own = 0, id_nbr = 0;
   if (x < P.W && y < P.H) {
@@ -296,7 +342,7 @@ __global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, 
   bool nan = false;
   if (inside) {
     const size_t o = base + (size_t)y * P.W + x;
-    const float sil = B.dqs[o].z;                                       // (the boundary pass wrote {depth, 0, silhouette, 0})
+    const float sil = pre_boundary_silhouette(B.depth_b[o]);
     B.dqs[o] = make_float4(depth, q, sil, 0.0f);
     d0 = d1 = depth; s0 = s1 = sil;
     nan = (depth != depth) || (sil != sil);
@@ -314,10 +360,15 @@ void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, 
   const dim3 rows((P.W + 63) / 64, (P.H + 3) / 4, P.N), tiles((P.W + 15) / 16, (P.H + 15) / 16, P.N);
   const PreExtra E{rgb, rgba, (uint32_t)n_color_px, (uint4*)zero, zero_words >> 2};
   if (!only || only == 1) hipLaunchKernelGGL(k_pre_morph, dim3(rows.x, rows.y, P.N + ((rgb || zero) ? 2 : 0)), dim3(256), 0, st, P, B, E);
-  if (!only || only == 2) hipLaunchKernelGGL(k_pre_filter, tiles, dim3(256), 0, st, P, B, T, F);
-  if (!only || only == 3) hipLaunchKernelGGL(k_pre_boundary, rows, dim3(256), 0, st, P, B);
-  if (!only || only == 4) hipLaunchKernelGGL(k_pre_normal, rows, dim3(256), 0, st, P, B, T, BR);
+  if (!only || only == 2) hipLaunchKernelGGL(k_pre_filter, tiles, dim3(256), 0, st, P, B, T);
+  if (!only || only == 3) hipLaunchKernelGGL(k_pre_boundary, tiles, dim3(256), 0, st, P, B, T, F);
+  if (!only || only == 4) hipLaunchKernelGGL(k_pre_normal, tiles, dim3(256), 0, st, P, B, T, BR);
   if (!only || only == 5) hipLaunchKernelGGL(k_pre_quality, tiles, dim3(256), 0, st, P, B, T, ranges, (P.W + 7) / 8, (P.H + 7) / 8);
+}
+
+// the Lab image of the filter pass (PreBuffers::lab), for callers that read it back: the passes themselves no longer write it (lab_of_pixel)
+void launch_pre_lab(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F) {
+  hipLaunchKernelGGL(k_pre_lab, dim3((P.W + 63) / 64, (P.H + 3) / 4, P.N), dim3(256), 0, st, P, B, T, F);
 }
 
 }  // namespace rr

@@ -209,6 +209,7 @@ void launch_wire_unpack(hipStream_t st, const WireLayout& L, uchar4* rgba, float
 void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F, const Bricks& BR, float4* ranges,
                        const uint8_t* rgb = nullptr, uchar4* rgba = nullptr, size_t n_color_px = 0, uint32_t* zero = nullptr, uint32_t zero_words = 0,
                        int only = 0);   // only: 0 = the five passes, 1 .. 5 = that pass alone (morph, filter, boundary, normal, quality: per-kernel timers)
+void launch_pre_lab(hipStream_t st, const PreParams& P, const PreBuffers& B, const StreamTable& T, const FrameImages& F);   // PreBuffers::lab, on request
 
 // launchers (one per kernel family, defined in the .hip files)
 void launch_pack_color(hipStream_t st, const uint8_t* rgb, uchar4* rgba, size_t n);

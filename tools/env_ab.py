@@ -1,5 +1,5 @@
 """A/B of whole frames across ENVIRONMENT variants of one library:  python tools/env_ab.py c2 "" RR_K1_RECT=0 "RR_K1_RECT=0 RR_DEEP=0"
-Prints per variant the moving-scene rate, the serial (one stream) rate and the stage times."""
+Prints per variant the moving-scene rate, the serial (one stream) rate and the stage times.  AB_ARGS="--preprocess": extra bench.py arguments."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 config = sys.argv[1]
@@ -9,7 +9,7 @@ for var in sys.argv[2:]:
     for kv in var.split():
         k, v = kv.split("=", 1)
         env[k] = v
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--no-cpu-baseline", "--no-c1", "--long-steps", "0", "--steps", steps],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--no-cpu-baseline", "--no-c1", "--long-steps", "0", "--steps", steps] + os.environ.get("AB_ARGS", "").split(),
                        env=env, capture_output=True, text=True)
     try:
         d = json.loads(p.stdout.strip().splitlines()[-1])
