@@ -636,12 +636,14 @@ def main():
             # LUT bytes: the distinct texels the passes can touch -- background pixels tap the two depth slices at the clamped end of the LUT, a pixel with
             # a depth its own 2 x 2 x 2 neighbourhood (an upper figure: neighbours share texels) --, never more than the whole LUT
             lut = lambda texel_bytes, px: min(N_ * texel_bytes * L_, texel_bytes * (N_ * 2 * LUT * LUT + 8 * px))
+            # (round 4: the Lab colour is evaluated by the boundary pass, for the 22 x 22 neighbourhood of every 16 x 16 block that holds a candidate pixel)
+            n_cand_blocks = int(((pp["depth_rg"][..., 0] > 0) & ~(pp["depth_rg"][..., 1] > 0.65)).reshape(N_, 480 // 16, 16, 640 // 16, 16).any(axis=(2, 4)).sum())
             alg = {"k_pre_morph": (4 + 4) * N_ * P_ + (3 + 4) * N_ * Pc_,    # raw depth in, dilated depth out; RGB8 in, RGBA8 out (rides along)
-                   "k_pre_filter": (4 + 8 + 16) * N_ * P_ + 4 * N_ * Pc_ + lut(16 + 8, n_box),
-                   "k_pre_boundary": (8 + 8 + 4 + 16) * N_ * P_,
+                   "k_pre_filter": (4 + 8) * N_ * P_ + lut(16, n_box),       # morph image in, {filtered depth, range quality} out; cv_xyz
+                   "k_pre_boundary": (8 + 8 + 4) * N_ * P_ + n_cand_blocks * 22 * 22 * (4 + 4 * 4) + lut(8, n_cand_blocks * 22 * 22),   # + per candidate block: depth, 4 colour taps and cv_uv of its Lab tile
                    "k_pre_normal": (4 + 16) * N_ * P_ + lut(16, 5 * n_valid),
-                   "k_pre_quality": (4 + 4 + 16) * N_ * P_ + 16 * n_valid + lut(16, n_valid)}
-            ops = {"k_pre_filter": 169 * 16 * n_box + 300 * N_ * P_, "k_pre_quality": 169 * 11 * n_valid}    # vector operations (lane-instructions): taps x instructions per tap (+ RGB -> Lab of every pixel)
+                   "k_pre_quality": (4 + 8 + 16) * N_ * P_ + 16 * n_valid + lut(16, n_valid)}   # depth plane + depth_b (the silhouette) in, the packed texel out
+            ops = {"k_pre_filter": 169 * 15 * n_box, "k_pre_quality": 169 * 11 * n_valid}    # vector operations (lane-instructions): taps x instructions per tap
             pre_kernels = {}
             for kname in names:
                 kn, kms = ph.timer_stats(kname)
@@ -665,8 +667,8 @@ def main():
         ph.close()
         del ph, rd
         with_pre = {"value": args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3, "preprocess_ms": pre_ms, "kernels": pre_kernels,
-                    "note": "tsdf_frame_raw_dev: every step takes the other RAW frame (depth in metres + RGB8, resident in HBM) through pre_morph / pre_depth (13 x 13 bilateral + "
-                            "RGB -> Lab) / pre_boundary / pre_normal (marks the bricks) / pre_quality on the lane ahead, then the frame as in `value`; preprocess_ms: the five "
+                    "note": "tsdf_frame_raw_dev: every step takes the other RAW frame (depth in metres + RGB8, resident in HBM) through pre_morph / pre_depth (13 x 13 bilateral) / "
+                            "pre_boundary (+ RGB -> Lab where it compares colours) / pre_normal (marks the bricks) / pre_quality on the lane ahead, then the frame as in `value`; preprocess_ms: the five "
                             "passes + the range cells on one stream (HIP events)"}
     device_mem_bytes = int(mem_free_before - torch.cuda.mem_get_info(local)[0])
     # per-frame device time distribution (SURVEY.md section 8d asks for median and p95): one event pair per frame, own short pass
