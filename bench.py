@@ -633,9 +633,9 @@ def main():
             N_, P_, Pc_, L_ = n_streams, 640 * 480, 640 * 480, LUT ** 3
             n_box = int((pp["depth_rg"][..., 1] > 0).sum())                 # pixels the filter pass ran its taps for (inside the bounding box)
             n_valid = int(((pp["depth_b"][..., 0] > 0) & (pp["depth_b"][..., 0] < 1)).sum())   # ... and the quality pass
-            # LUT bytes: the distinct texels the passes can touch -- background pixels tap the two depth slices at the clamped end of the LUT, a pixel with
-            # a depth its own 2 x 2 x 2 neighbourhood (an upper figure: neighbours share texels) --, never more than the whole LUT
-            lut = lambda texel_bytes, px: min(N_ * texel_bytes * L_, texel_bytes * (N_ * 2 * LUT * LUT + 8 * px))
+            # LUT bytes: the distinct texels the passes can touch.  A depth image is a surface in the LUT: the trilinear taps of a stream's pixels lie in the two
+            # texel layers around it (2 x LUT^2 texels, however many pixels tap them), background pixels in the two slices at the clamped end -- never more than the LUT
+            lut = lambda texel_bytes, px: min(N_ * texel_bytes * L_, N_ * texel_bytes * LUT * LUT * (2 + (2 if px else 0)))
             # (round 4: the Lab colour is evaluated by the boundary pass, for the 22 x 22 neighbourhood of every 16 x 16 block that holds a candidate pixel)
             n_cand_blocks = int(((pp["depth_rg"][..., 0] > 0) & ~(pp["depth_rg"][..., 1] > 0.65)).reshape(N_, 480 // 16, 16, 640 // 16, 16).any(axis=(2, 4)).sum())
             alg = {"k_pre_morph": (4 + 4) * N_ * P_ + (3 + 4) * N_ * Pc_,    # raw depth in, dilated depth out; RGB8 in, RGBA8 out (rides along)

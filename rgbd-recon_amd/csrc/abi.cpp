@@ -1357,7 +1357,8 @@ int32_t tsdf_mark_bricks(tsdf_ctx* c) {
   const hipStream_t lane = pre_enter(c);
   uint32_t* zero_word = nullptr;
   if (lane != c->stream) {                                               // the count of the occupancy set the coming update flips to (or stays on)
-    zero_word = c->d_occ_counts + ((!c->occ_flipped && c->occ_in_use) ? alt_of(c->occ_parity) : c->occ_parity);
+    c->occ_zeroed_word = (!c->occ_flipped && c->occ_in_use) ? alt_of(c->occ_parity) : c->occ_parity;
+    zero_word = c->d_occ_counts + c->occ_zeroed_word;
     c->occ_count_zeroed = true;
   }
   // the peel tiles the coming draw would reset first -- those the draw before the previous one touched, in the peel image that draw used (two alternate
@@ -1383,8 +1384,11 @@ int32_t tsdf_update_occupied(tsdf_ctx* c, float* ratio) {
     if (!c->occ_flipped && c->occ_in_use) c->occ_parity = alt_of(c->occ_parity);
     c->occ_flipped = true; c->occ_in_use = false; c->occ_counts_stale = true;
     c->br.num_occupied = c->d_occ_counts + c->occ_parity; c->br.flags = c->d_flags[c->occ_parity]; c->br.occupied = c->d_occupied[c->occ_parity];
-    if (c->occ_count_zeroed) c->occ_count_zeroed = false;                // the frame's marking launch cleared the count (a second update of the frame fills again)
-    else HIP_TRY(c, hipMemsetAsync(c->br.num_occupied, 0, sizeof(uint32_t), lane));
+    // the frame's marking launch cleared a count word -- THE one this update lands on, unless a call between the two (a draw, tsdf_occupied_ratio, an
+    // integrate on the context's stream) joined the lane and made this update flip after all: then, and for a second update of the frame, fill again
+    const bool cleared = c->occ_count_zeroed && c->occ_zeroed_word == c->occ_parity;
+    c->occ_count_zeroed = false;
+    if (!cleared) HIP_TRY(c, hipMemsetAsync(c->br.num_occupied, 0, sizeof(uint32_t), lane));
     launch_update_occupied(lane, c->br, c->min_voxels, c->d_occ_counts + 2);          // (a third word takes the kernel's re-arming store)
   } else {
     c->occ_parity = alt_of(c->occ_parity);

@@ -168,6 +168,7 @@ struct tsdf_ctx {
   bool pre_pending = false, pre_gate_recorded = false, main_since_gate = true, pipeline_blocked = false;
   bool slot_flipped = false, counters_flipped = false, occ_flipped = false;     // once per frame of the lane ...
   bool slot_in_use = false, counters_in_use = false, occ_in_use = false;        // ... and only when a consumer has been queued since the buffer was last written
+  int occ_zeroed_word = 0;                                                      // which of the two count words the marking launch cleared
   bool counters_zeroed = false, occ_count_zeroed = false;                       // the re-layout launch / the marking launch has cleared them already (no fill launch of its own)
   uint8_t* d_flags[2]{}; uint32_t* d_occupied[2]{};                             // the two occupancy sets (Bricks::flags / occupied point at the latest update's)
   bool occ_counts_stale = false;                                                // the lane ahead has used the count words: the context's stream zeroes its word itself once
