@@ -722,7 +722,11 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
   // The work item's record (k_pair_masks): {pair classes, tile id, tile coordinates + "every voxel lies inside the volume", stored tile index}.  The next
   // item's record is requested at the head of the current one -- as a VECTOR load (mbcnt keeps the compiler from proving the address uniform): scalar loads
   // share their counter with the LDS operations, whose waits would expose it at once, while a vector load's counter is in order and waited for by number.
+#ifdef RR_K1_SREC       // A/B (tools/build_k1_variant.sh srec "-DRR_K1_SREC"): the record through the scalar cache instead of the texture-address queue
+  const int lane0 = 0;
+#else
   const int lane0 = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);                          // 0 in every lane
+#endif
   uint4 rec_next = recs[(blockIdx.x < n_work ? blockIdx.x : 0) + lane0];
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     RR_STAMP(0);                                                                     // tile head
