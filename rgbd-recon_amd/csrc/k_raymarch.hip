@@ -485,6 +485,9 @@ constexpr int kBoxSteps = RR_BOX_STEPS;
 #ifndef RR_BOX_LEAP
 #define RR_BOX_LEAP 32
 #endif
+#ifndef RR_BOX_LDS_DMA
+#define RR_BOX_LDS_DMA 1
+#endif
 constexpr int kLeap = RR_BOX_LEAP;            // samples per leap over all-clear tiles
 #ifdef RR_BOX_STATS      // instrumented build (tools/build_variant.sh): [batches, batches with a box, sum of S, samples from LDS, samples from global, box floats, retries, samples in all-clear boxes]
 __device__ unsigned long long g_box_stats[8];
@@ -638,6 +641,32 @@ __global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, 
       const int q = ex >> 2, rows = __mul24(ey, ez), items = __mul24(rows, q);
       const float rq = __builtin_amdgcn_rcpf((float)q), rey = __builtin_amdgcn_rcpf((float)ey);
       const float* __restrict__ d = V.data;
+#if RR_BOX_LDS_DMA
+      // Round 4: a box whose x range lies inside the volume (all but the boxes at its two x faces) is copied by LDS-direct loads (global_load_lds_dwordx4,
+      // gfx950): item `it` of the box is the 16 bytes at s_box + 4 it -- lane-linear, which is exactly the layout such a load writes (LDS base in M0 + 16 B
+      // per lane) -- so all rounds of a batch are in flight together and no voxel passes through a register.  (The register copy below waited for each
+      // round's four dword loads before it issued the next: up to ten L2 round trips per batch, 40 % of this kernel's cycles in s_waitcnt.)
+      if (bx0 >= 0 && bx0 + ex <= V.res[0]) {                            // wave-uniform
+        for (int r = 0; (r << 6) < items; ++r) {
+          const int it = ln + (r << 6);
+          if (it < items) {
+            const int row = (int)(((float)it + 0.5f) * rq);                // it / q
+            const int qi = it - __mul24(row, q);
+            const int rz = (int)(((float)row + 0.5f) * rey);               // row / ey
+            const int ry = row - __mul24(rz, ey);
+            const int gy = min(max(by0 + ry, 0), V.res[1] - 1), gz = min(max(bz0 + rz, 0), V.res[2] - 1);
+            const float* src = d + vol_off_y(V, gy) + vol_off_z(V, gz) + vol_off_x(bx0 + (qi << 2));
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)(s_box + (r << 8)), 16, 0, 0);
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                                // vmcnt(0): the box has landed
+        __builtin_amdgcn_wave_barrier();
+        for (int it = ln; it < items; it += 64) {                          // the clear test, from LDS
+          const float4 v = *(const float4*)(s_box + (it << 2));
+          all_clear &= (v.x == ml) & (v.y == ml) & (v.z == ml) & (v.w == ml);
+        }
+      } else
+#endif
       for (int it = ln; it < items; it += 64) {
         const int row = (int)(((float)it + 0.5f) * rq);                  // it / q   (exact for it < 2^20, see k_integrate_tiles_lds)
         const int qi = it - __mul24(row, q);
