@@ -133,7 +133,7 @@ int32_t setup_view(tsdf_ctx* c, uint32_t w, uint32_t h) {
   HIP_TRY(c, hipMalloc(&c->d_hit_counters, 4 * sizeof(uint32_t)));
   HIP_TRY(c, hipMemsetAsync(c->d_hit_counters, 0, 4 * sizeof(uint32_t), c->stream));
   if (const char* e = getenv("RR_MARCH_CAP")) c->march_cap = (uint32_t)atoi(e);
-  if (const char* e = getenv("RR_MARCH_BOX")) c->march_box = atoi(e) != 0;
+  if (const char* e = getenv("RR_MARCH_BOX")) c->march_box = atoi(e);
   if (const char* e = getenv("RR_K1_FORM")) c->k1_form_cap = atoi(e);     // A/B and test hook, read when the context is created
   if (const char* e = getenv("RR_IMAGE_TILES")) c->use_tile_history = atoi(e) != 0;
   c->hit_parity = 0;
@@ -1610,9 +1610,9 @@ static int32_t raymarch_impl(tsdf_ctx* c, const float* mv, const float* pr, bool
   HIP_TRY(c, join_integ(c));                                             // the volume: from here on (the depth limits above needed the bricks only)
   timer_begin(c, "draw");
   timer_begin(c, "k_march");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 2, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box);
   timer_end(c, "k_march");
-  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box ? 1 : 0);
+  launch_raymarch(c->stream, P, c->luts, c->frame, c->vol, RT, partial ? 1 : 0, c->d_hits, c->d_hit_counters, c->hit_parity, 3, c->d_long, c->march_cap ? c->march_cap : 0xffffffffu, c->march_box);
   c->hit_parity ^= 1;
   c->last_two_pass = !partial && P.skip && c->d_long && c->march_cap != 0;          // launch_raymarch's own condition
   c->own_miss_counts = true;

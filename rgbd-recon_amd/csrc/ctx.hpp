@@ -116,7 +116,7 @@ struct tsdf_ctx {
   float4* d_tile_bounds = nullptr; bool tile_bounds_valid = false;   // static per (stored tile, stream) LUT-box bounds, built on the first dense integrate after a calibration
   bool culled_ranges = true;      // RR_K1_CULLED_RANGES=0: no uniform-pair shortcut in culled launches (A/B hook; dense storage with a bounds table of at most 512 MiB only)
   bool use_ranges = true;         // RR_K1_RANGES=0: the dense integrate evaluates every voxel of every stream (A/B and test hook, read at creation)
-  bool march_box = true;          // RR_MARCH_BOX=0: the dense march gathers from global memory as in round 1 (A/B and test hook, read at creation)
+  int march_box = 1;              // the dense march: 1 = LDS voxel boxes, 2 = two boxes per wave with the next one prefetched (round 4), 0 = gathers from global memory as in round 1; RR_MARCH_BOX overrides (A/B and test hook, read at creation)
   void* d_long = nullptr; uint32_t march_cap = 24;   // rays still running after march_cap samples go to the wave-per-ray pass (RR_MARCH_CAP, 0 = off)
   bool last_two_pass = false;     // the last march handed its long rays to the wave-per-ray pass (they are not on the hit list)
   bool own_miss_counts = false;   // this context has marched at this view size: its sample-count image holds the miss counts (-count, or count after a composite)

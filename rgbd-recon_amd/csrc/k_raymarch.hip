@@ -514,13 +514,20 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's min
   return __builtin_amdgcn_readlane(v, 63);
 }
-__global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
-  __shared__ float4 s_all[4][kBoxFloats / 4];
+// kDB (round 4): two boxes per wave -- while the samples of a batch are taken from one, the LDS-direct loads of the NEXT batch's box (sized from the
+// positions the lanes will have after this batch: one multiply-add instead of the chain of additions, with margin; every sample still checks that its
+// taps lie in the box it reads, so exactness does not rest on the prediction) are in flight into the other.  A 128-thread workgroup (16 x 8 pixels): two
+// waves x 2 x 10 KiB.  What this kernel's length is made of is the longest chain of batches of any pixel tile (tools/box_stats.py: 0.9 box batches per wave on
+// average, 15 - 25 for the tiles whose rays graze the surface), so a round trip hidden per batch shortens the launch.
+template <bool kDB>
+__global__ __launch_bounds__(kDB ? 128 : 256, kDB ? 2 : RR_BOX_BOUNDS) void k_march_box(ViewParams P, Volume V, RayTarget R, Hit* __restrict__ hits, uint32_t* __restrict__ hit_count) {
+  __shared__ float4 s_all[kDB ? 2 : 4][(kDB ? 2 : 1) * kBoxFloats / 4];
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-  float* const s_box = (float*)s_all[wv];
+  float* s_box = (float*)s_all[wv];                                     // (kDB: the box in use; the other one is s_other)
+  [[maybe_unused]] float* s_other = (float*)s_all[wv] + (kDB ? kBoxFloats : 0);
   const float limit = V.limit, sd = limit * 0.5f;
   const int px = blockIdx.x * 16 + (wv & 1) * 8 + (ln & 7);
-  const int py = blockIdx.y * 16 + (wv >> 1) * 8 + (ln >> 3);
+  const int py = kDB ? blockIdx.y * 8 + (ln >> 3) : blockIdx.y * 16 + (wv >> 1) * 8 + (ln >> 3);
   const bool inside = px < P.w && py < P.h;
   const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
   const float3 dn = normalize3(pixel_dir_vol(P, fx, fy));
@@ -551,6 +558,8 @@ __global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, 
   float3 hit_pos = pos;
   float hit_d = 0.0f;
   int S = kBoxSteps;
+  [[maybe_unused]] bool have_pref = false, podd = false;               // (kDB) the other box holds / is receiving the next batch's voxels: its geometry and batch length
+  [[maybe_unused]] int pbx0 = 0, pby0 = 0, pbz0 = 0, pex = 0, pey = 0, pez = 0, pS = 0;
   bool try_leap = true;                                                 // wave-uniform: the last thing seen was empty space
   const uint8_t* __restrict__ cls = V.cls;
   const float ml = -limit;
@@ -605,7 +614,10 @@ __global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, 
     // ---- 1. the box of this batch
     int bx0 = 0, by0 = 0, bz0 = 0, ex = 0, ey = 0, ez = 0;
     bool fits = false, odd = false;                                      // odd: some live lane has a non-finite position
-    for (;;) {
+    const bool prefetched = kDB && have_pref;                            // (wave-uniform) this batch's box was requested during the previous batch
+    int s_batch = S;                                                     // the batch length the box was sized for
+    if (prefetched) { bx0 = pbx0; by0 = pby0; bz0 = pbz0; ex = pex; ey = pey; ez = pez; fits = true; odd = podd; s_batch = pS; have_pref = false; }
+    else for (;;) {
       const uint32_t rem = max_n - n;
       const float last = (float)((live ? min((uint32_t)S, rem) : 1u) - 1u);
       const float ax = pos.x * nx - 0.5f, ay = pos.y * ny - 0.5f, az = pos.z * nz - 0.5f;
@@ -630,6 +642,7 @@ __global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, 
       S >>= 1;
       RR_STAT(6, 1);
     }
+    if (!prefetched) s_batch = S;
     RR_STAT(0, 1); RR_STAT(1, fits ? 1 : 0); RR_STAT(2, fits ? S : 0); RR_STAT(5, fits ? __mul24(__mul24(ex, ey), ez) : 0);
     // ---- 2. global -> LDS, clamped on the way in.  While it passes through the registers every voxel is compared with the clear
     // value: a box that holds nothing but -limit (free space in front of the surfaces, most of the volume) makes every sample inside
@@ -637,28 +650,34 @@ __global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, 
     // additions.  (The per-sample tile-class lookups of round 1 lost to their own instruction cost; here the test costs four compares
     // per 16-byte load and is shared by all samples of the batch.)
     bool all_clear = true;
+    const float* __restrict__ d = V.data;
+    // LDS-direct copy of a box whose x range lies inside the volume: the loads only (no wait)
+    [[maybe_unused]] const auto dma_issue = [&](float* dst, int qx0, int qy0, int qz0, int qex, int qey, int qez) {
+      const int q = qex >> 2, items = __mul24(__mul24(qey, qez), q);
+      const float rq = __builtin_amdgcn_rcpf((float)q), rey = __builtin_amdgcn_rcpf((float)qey);
+      for (int r = 0; (r << 6) < items; ++r) {
+        const int it = ln + (r << 6);
+        if (it < items) {
+          const int row = (int)(((float)it + 0.5f) * rq);                  // it / q
+          const int qi = it - __mul24(row, q);
+          const int rz = (int)(((float)row + 0.5f) * rey);                 // row / ey
+          const int ry = row - __mul24(rz, qey);
+          const int gy = min(max(qy0 + ry, 0), V.res[1] - 1), gz = min(max(qz0 + rz, 0), V.res[2] - 1);
+          const float* src = d + vol_off_y(V, gy) + vol_off_z(V, gz) + vol_off_x(qx0 + (qi << 2));
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)(dst + (r << 8)), 16, 0, 0);
+        }
+      }
+    };
     if (fits) {
       const int q = ex >> 2, rows = __mul24(ey, ez), items = __mul24(rows, q);
       const float rq = __builtin_amdgcn_rcpf((float)q), rey = __builtin_amdgcn_rcpf((float)ey);
-      const float* __restrict__ d = V.data;
 #if RR_BOX_LDS_DMA
       // Round 4: a box whose x range lies inside the volume (all but the boxes at its two x faces) is copied by LDS-direct loads (global_load_lds_dwordx4,
       // gfx950): item `it` of the box is the 16 bytes at s_box + 4 it -- lane-linear, which is exactly the layout such a load writes (LDS base in M0 + 16 B
       // per lane) -- so all rounds of a batch are in flight together and no voxel passes through a register.  (The register copy below waited for each
       // round's four dword loads before it issued the next: up to ten L2 round trips per batch, 40 % of this kernel's cycles in s_waitcnt.)
-      if (bx0 >= 0 && bx0 + ex <= V.res[0]) {                            // wave-uniform
-        for (int r = 0; (r << 6) < items; ++r) {
-          const int it = ln + (r << 6);
-          if (it < items) {
-            const int row = (int)(((float)it + 0.5f) * rq);                // it / q
-            const int qi = it - __mul24(row, q);
-            const int rz = (int)(((float)row + 0.5f) * rey);               // row / ey
-            const int ry = row - __mul24(rz, ey);
-            const int gy = min(max(by0 + ry, 0), V.res[1] - 1), gz = min(max(bz0 + rz, 0), V.res[2] - 1);
-            const float* src = d + vol_off_y(V, gy) + vol_off_z(V, gz) + vol_off_x(bx0 + (qi << 2));
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)(s_box + (r << 8)), 16, 0, 0);
-          }
-        }
+      if (prefetched || (bx0 >= 0 && bx0 + ex <= V.res[0])) {            // wave-uniform (a prefetched box is one of these)
+        if (!prefetched) dma_issue(s_box, bx0, by0, bz0, ex, ey, ez);
         __builtin_amdgcn_s_waitcnt(0x0f70);                                // vmcnt(0): the box has landed
         __builtin_amdgcn_wave_barrier();
         for (int it = ln; it < items; it += 64) {                          // the clear test, from LDS
@@ -693,7 +712,7 @@ __global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, 
     // (No box at any S -- a tile whose rays entered the cube through different faces: eight samples straight from global memory,
     // then the box is tried again.)
     const int pl = __mul24(ex, ey);
-    const int s_run = fits ? S : 8;
+    const int s_run = fits ? s_batch : 8;
     constexpr int kSub = RR_BOX_SUB;
     float3 p = pos;
     if (empty && !odd) {
@@ -706,6 +725,32 @@ __global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, 
       __builtin_amdgcn_wave_barrier();
       try_leap = true;                                                    // back in empty space
       continue;
+    }
+    if constexpr (kDB) {
+      // ---- the next batch's box, requested now: the lanes that will still be live (a hit in this batch only removes lanes), at the positions one
+      // multiply-add predicts (the chain of s_run additions differs by < s_run ulps: 2e-3 voxels at the largest volume; margin 0.02)
+      const uint32_t done_now = min((uint32_t)s_run, max_n - n);
+      const uint32_t n1 = n + (live ? done_now : 0u);
+      const bool live1 = live && n1 < max_n;
+      const float adv = (float)s_run;
+      const float3 p1 = make_float3(pos.x + step.x * adv, pos.y + step.y * adv, pos.z + step.z * adv);
+      const float last1 = (float)((live1 ? min((uint32_t)S, max_n - n1) : 1u) - 1u);
+      const float ax = p1.x * nx - 0.5f, ay = p1.y * ny - 0.5f, az = p1.z * nz - 0.5f;
+      const float bx = (p1.x + step.x * last1) * nx - 0.5f, by = (p1.y + step.y * last1) * ny - 0.5f, bz = (p1.z + step.z * last1) * nz - 0.5f;
+      const bool ok = live1 && fabsf(ax) < 1.0e6f && fabsf(ay) < 1.0e6f && fabsf(az) < 1.0e6f && fabsf(bx) < 1.0e6f && fabsf(by) < 1.0e6f && fabsf(bz) < 1.0e6f;
+      const int big = 0x3fffffff;
+      constexpr float kSlackP = 0.02f;
+      const int lx = ok ? (int)floorf(fminf(ax, bx) - kSlackP) : big, ly = ok ? (int)floorf(fminf(ay, by) - kSlackP) : big, lz = ok ? (int)floorf(fminf(az, bz) - kSlackP) : big;
+      const int hx = ok ? (int)floorf(fmaxf(ax, bx) + kSlackP) + 1 : -big, hy = ok ? (int)floorf(fmaxf(ay, by) + kSlackP) + 1 : -big, hz = ok ? (int)floorf(fmaxf(az, bz) + kSlackP) + 1 : -big;
+      podd = __ballot(live1 && !ok) != 0ull;
+      const int mlx = wave_min_i32(lx), mly = wave_min_i32(ly), mlz = wave_min_i32(lz);
+      const int mhx = -wave_min_i32(-hx), mhy = -wave_min_i32(-hy), mhz = -wave_min_i32(-hz);
+      if (fits && mlx != big && !podd) {                                 // (only behind a batch that had a box itself: the steady state of a long march)
+        pbx0 = mlx & ~3; pby0 = mly; pbz0 = mlz;
+        pex = ((mhx - pbx0 + 1) + 3) & ~3; pey = mhy - pby0 + 1; pez = mhz - pbz0 + 1;
+        const bool pfits = pex > 0 && pey > 0 && pez > 0 && pex <= 1024 && pey <= 1024 && pez <= 1024 && __mul24(__mul24(pex, pey), pez) <= kBoxFloats;
+        if (pfits && pbx0 >= 0 && pbx0 + pex <= V.res[0]) { dma_issue(s_other, pbx0, pby0, pbz0, pex, pey, pez); have_pref = true; pS = S; }
+      }
     }
     for (int k0 = 0; k0 < s_run; k0 += kSub) {
       float3 q[kSub];
@@ -766,9 +811,11 @@ __global__ __launch_bounds__(256, RR_BOX_BOUNDS) void k_march_box(ViewParams P, 
     }
     pos = p;
     __builtin_amdgcn_wave_barrier();                                      // the next batch overwrites the box
+    if (kDB && have_pref) { float* t = s_box; s_box = s_other; s_other = t; }   // the box being filled becomes the box in use
     if (fits && S < kBoxSteps && (n & 63u) == 0u) S <<= 1;                // try a longer batch again now and then (wave-uniform only if n is: see below)
     S = __builtin_amdgcn_readfirstlane(S);
   }
+  if (kDB && have_pref) __builtin_amdgcn_s_waitcnt(0x0f70);             // a box still on its way must have landed before the wave (and its LDS) goes
   float3 out_pos = pos;
   if (hit) {                                                            // approximate ray-cell intersection, :99-101
     const float kk = prev / (hit_d - prev);
@@ -974,7 +1021,8 @@ void launch_raymarch(hipStream_t st, const ViewParams& P, const StreamTable& T, 
 #define RR_LAUNCH_MARCH(PART, SP, B) hipLaunchKernelGGL((k_march<PART, SP, B>), grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity, ll, hit_counters + 2 + parity, cap1)
     if (partial) { if (sparse) RR_LAUNCH_MARCH(true, true, kBatchDense); else RR_LAUNCH_MARCH(true, false, kBatchDense); }
     else if (two_pass) { if (sparse) RR_LAUNCH_MARCH(false, true, kBatchSkip); else RR_LAUNCH_MARCH(false, false, kBatchSkip); }
-    else if (!sparse && !P.skip && box_march) hipLaunchKernelGGL(k_march_box, grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+    else if (!sparse && !P.skip && box_march == 2) hipLaunchKernelGGL(k_march_box<true>, dim3(grid.x, (P.h + 7) / 8), dim3(128), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
+    else if (!sparse && !P.skip && box_march) hipLaunchKernelGGL(k_march_box<false>, grid, dim3(256), 0, st, P, V, R, (Hit*)hit_list, hit_counters + parity);
     else { if (sparse) RR_LAUNCH_MARCH(false, true, kBatchDense); else RR_LAUNCH_MARCH(false, false, kBatchDense); }
 #undef RR_LAUNCH_MARCH
   }

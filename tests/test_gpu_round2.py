@@ -302,17 +302,21 @@ def test_box_march_equals_gather_march_and_oracle(rr, small_scene, res, monkeypa
     box = rr.ReconIntegrationHip(small_scene, **kw)
     monkeypatch.setenv("RR_MARCH_BOX", "0")
     gather = rr.ReconIntegrationHip(small_scene, **kw)
+    monkeypatch.setenv("RR_MARCH_BOX", "2")                  # (round 4) two boxes per wave, the next batch's box prefetched: opt-in, measured slower, kept bit-identical
+    box2 = rr.ReconIntegrationHip(small_scene, **kw)
     monkeypatch.delenv("RR_MARCH_BOX")
     orc = OracleRecon(small_scene, **kw)
-    for o in (box, gather, orc):
+    for o in (box, gather, box2, orc):
         _dense(o)
         o.integrate()
     for eye, at in (((0.0, 1.1, 3.0), (0.0, 1.1, 0.0)), ((2.6, 2.0, 2.2), (0.0, 1.0, 0.0)), ((0.2, 1.0, 0.3), (0.0, 1.1, -1.0)),
                     ((0.05, 1.1, 0.05), (0.9, 1.3, 0.7)), ((0.0, 5.0, 0.001), (0.0, 0.0, 0.0)), ((-3.5, 1.1, 0.0), (0.0, 1.1, 0.0))):
         mv = rr.scene.gl_flat(rr.scene.look_at(eye, at))
-        for o in (box, gather, orc):
+        for o in (box, gather, box2, orc):
             o.draw(mv, pr)
         (ba, bd, bn, _), (ga, gd, gn, _), (oa, od, on, _) = box.view_images(), gather.view_images(), orc.view_images()
+        (pa, pd, pn, _) = box2.view_images()
+        assert same(bn, pn).all() and same(bd, pd).all() and same(ba, pa).all(), f"box vs prefetched boxes, eye {eye}"
         assert same(bn, gn).all() and same(bd, gd).all() and same(ba, ga).all(), f"box vs gather, eye {eye}"
         assert same(bn, on).all() and same(bd, od).all() and same(ba, oa).all(), f"box vs oracle, eye {eye}"
         assert (bn > 0).sum() > 500
