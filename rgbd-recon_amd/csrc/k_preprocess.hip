@@ -142,9 +142,17 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
   }
   const bool taps = __syncthreads_or(in_box && P.filter_textures) != 0;   // (workgroup-uniform)
   if (taps) {
-    for (int i = threadIdx.x; i < 28 * 28; i += 256) {
-      const int ty = i / 28, tx = i % 28;
-      s_d[ty][tx] = sample(by + ty - 6, bx + tx - 6);
+    // the four rounds of window loads are requested together (as a loop the compiler waits for each round's load before the next: four L2 round trips)
+    float wv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = min((int)threadIdx.x + 256 * r, 28 * 28 - 1), ty = i / 28, tx = i - ty * 28;
+      wv[r] = sample(by + ty - 6, bx + tx - 6);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (int)threadIdx.x + 256 * r, ty = i / 28, tx = i - ty * 28;
+      if (i < 28 * 28) s_d[ty][tx] = wv[r];
     }
     __syncthreads();
   }
@@ -298,9 +306,16 @@ __global__ __launch_bounds__(256) void k_pre_quality(PreParams P, PreBuffers B, 
   const bool valid = inside && !(depth <= 0.0f || depth >= 1.0f);
   // the window is staged only when some pixel of the block holds a depth (as in k_pre_filter)
   if (__syncthreads_or(valid) != 0) {
-    for (int i = threadIdx.x; i < 28 * 28; i += 256) {
-      const int ty = i / 28, tx = i % 28;
-      s_d[ty][tx] = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
+    float wv[4];                                                        // (four rounds of loads in flight together, as in k_pre_filter)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = min((int)threadIdx.x + 256 * r, 28 * 28 - 1), ty = i / 28, tx = i - ty * 28;
+      wv[r] = src[(size_t)clamp_tap(by + ty - 6, P.H) * P.W + clamp_tap(bx + tx - 6, P.W)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (int)threadIdx.x + 256 * r, ty = i / 28, tx = i - ty * 28;
+      if (i < 28 * 28) s_d[ty][tx] = wv[r];
     }
     __syncthreads();
   }
