@@ -788,7 +788,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   for (int k = 0; k < 2; ++k) { if (c->h_stage[k]) hipHostFree(c->h_stage[k]); if (c->stage_done[k]) hipEventDestroy(c->stage_done[k]); }
   hipFree(c->d_astage);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
-  hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal);
+  hipFree(c->d_raw); hipFree(c->d_depth2); hipFree(c->d_depth_rg); hipFree(c->d_lab); hipFree(c->d_depth_b); hipFree(c->d_normal); hipFree(c->d_pre_blocks);
   hipFree(c->d_stage_depth); hipFree(c->d_stage_q); hipFree(c->d_stage_s); hipFree(c->d_stage_col);
   for (auto& per : c->lut_alloc) for (void* p : per) hipFree(p);
   if (c->h_num_occupied) hipHostFree(c->h_num_occupied);
@@ -1092,6 +1092,10 @@ static int32_t ensure_pre_buffers(tsdf_ctx* c) {
     HIP_TRY(c, hipMalloc(&c->d_lab, np * sizeof(float4)));
     HIP_TRY(c, hipMalloc(&c->d_depth_b, np * sizeof(float2)));
     HIP_TRY(c, hipMalloc(&c->d_normal, np * sizeof(float4)));
+    const size_t blocks = (size_t)c->cfg.num_streams * ((F.w + 15) / 16) * ((F.h + 15) / 16);
+    c->pre_cand_cap = (uint32_t)std::min<size_t>(blocks, 1024);
+    HIP_TRY(c, hipMalloc(&c->d_pre_blocks, (1 + c->pre_cand_cap + blocks) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemset(c->d_pre_blocks, 0, (1 + c->pre_cand_cap + blocks) * sizeof(uint32_t)));
   }
   return TSDF_OK;
 }
@@ -1253,6 +1257,7 @@ static PreBuffers pre_buffers(tsdf_ctx* c) {
   B.raw = c->raw_src; B.depth2 = c->d_depth2; B.fdepth = c->use_processed_depth ? c->d_depth2 : c->raw_src;
   B.depth_rg = c->d_depth_rg; B.lab = c->d_lab; B.depth_b = c->d_depth_b; B.normal = c->d_normal;
   B.dqs = (float4*)c->frame.dqs; B.depth_plane = (float*)c->frame.depth;
+  B.cand_count = c->d_pre_blocks; B.cand_list = c->d_pre_blocks + 1; B.cand_cap = c->pre_cand_cap; B.blk_flag = c->d_pre_blocks + 1 + c->pre_cand_cap;
   return B;
 }
 int32_t tsdf_process_textures(tsdf_ctx* c) {

@@ -78,6 +78,7 @@ struct tsdf_ctx {
   // pre-processing state (NetKinectArray side)
   PreParams pre{};
   float* d_raw = nullptr; float* d_depth2 = nullptr; float2* d_depth_rg = nullptr; float4* d_lab = nullptr; float2* d_depth_b = nullptr; float4* d_normal = nullptr;
+  uint32_t* d_pre_blocks = nullptr; uint32_t pre_cand_cap = 0;   // [count | cand_list[cap] | blk_flag[blocks]] (PreBuffers)
   bool have_raw = false, use_processed_depth = true;
   const uint8_t* pending_rgb = nullptr;   // RGB8 colour of the raw frame uploaded last, still to be re-laid out into the frame slot (rides along in processTextures' first launch)
   uint64_t raw_generation = 0, pre_generation = 0; bool pre_processed_depth = true;   // which raw upload the products of processTextures() belong to (the Lab image is produced on request from its inputs)

@@ -22,6 +22,7 @@ __device__ __forceinline__ int tap_y(int y, int dy, int H) { return clamp_tap(y 
 // flipped to.  Null pointers: nothing to do.
 struct PreExtra { const uint8_t* rgb; uchar4* rgba; uint32_t n_px; uint4* zero; uint32_t zero_quads; };
 __global__ __launch_bounds__(256) void k_pre_morph(PreParams P, PreBuffers B, PreExtra E) {
+  if (B.cand_count && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *B.cand_count = 0u;   // (the filter pass numbers this frame's candidate blocks)
   if ((int)blockIdx.z >= P.N) {
     const uint32_t nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
     if ((int)blockIdx.z == P.N) {                                         // ---- colour
@@ -156,9 +157,8 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
     }
     __syncthreads();
   }
-  if (!inside) return;
   float2 od = make_float2(0.0f, 0.0f);
-  if (in_box) {
+  if (inside && in_box) {
     if (!P.filter_textures) od = make_float2(dn, 1.0f);
     else {
       const float dist_range_max = 0.35f * (depth / 4.5f), dist_range_max_inv = 1.0f / dist_range_max;   // :89-92
@@ -184,7 +184,16 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
       od = make_float2((depth_bf / w - mn) / (mx - mn), w_range / num);                                 // :124-126
     }
   }
-  B.depth_rg[o] = od;
+  if (inside) B.depth_rg[o] = od;
+  if (B.blk_flag) {                                                     // does the boundary pass compare colours in this block?  (its own test on its own input: k_pre_boundary)
+    const bool cand = inside && !(od.x <= 0.0f) && !(od.y > 0.65f);
+    const bool any = __syncthreads_or(cand) != 0;
+    if (threadIdx.x == 0) {
+      uint32_t f = 0u;
+      if (any) { const uint32_t k = atomicAdd(B.cand_count, 1u); f = k + 1u; if (k < B.cand_cap) B.cand_list[k] = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
+      B.blk_flag[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = f;
+    }
+  }
 }
 
 // ---- pre_boundary.fs main() :86-117, get_color_diff :37-55
@@ -195,10 +204,24 @@ __global__ __launch_bounds__(256) void k_pre_filter(PreParams P, PreBuffers B, S
 // pixel (x + kx, y + ky) -- clamp_tap's argument above --, so its two texels per axis are among x + kx - 1 .. x + kx + 1: inside the tile.  The tile index is
 // clamped all the same, for the memory's sake, not the value's.)
 constexpr int kLabTile = 22, kLabHalo = 3;
-__global__ __launch_bounds__(256) void k_pre_boundary(PreParams P, PreBuffers B, StreamTable T, FrameImages F) {
+// The launch is one-dimensional: its first cand_cap workgroups take the blocks the filter pass listed as holding a candidate (past the count: nothing to do),
+// the others take the blocks in order and leave a listed block to its slot -- so the long blocks start at once instead of wherever the dispatcher reaches them
+// (20.6 us of launch for 8 us of streaming + one 12 us block chain).
+__global__ __launch_bounds__(256) void k_pre_boundary(PreParams P, PreBuffers B, StreamTable T, FrameImages F, int nbx, int nby) {
   __shared__ float4 s_lab[kLabTile][kLabTile];
   __shared__ float2 s_drg[20][20];
-  const int l = blockIdx.z, bx = blockIdx.x * 16, by = blockIdx.y * 16;
+  uint32_t blk;
+  if (B.blk_flag) {
+    if (blockIdx.x < B.cand_cap) {
+      if (blockIdx.x >= *B.cand_count) return;
+      blk = B.cand_list[blockIdx.x];
+    } else {
+      blk = blockIdx.x - B.cand_cap;
+      const uint32_t f = B.blk_flag[blk];
+      if (f != 0u && f - 1u < B.cand_cap) return;                        // (a candidate block beyond the list's capacity is done here, in order)
+    }
+  } else blk = blockIdx.x;
+  const int l = (int)(blk / (uint32_t)(nbx * nby)), rem = (int)(blk - (uint32_t)l * (uint32_t)(nbx * nby)), bx = (rem % nbx) * 16, by = (rem / nbx) * 16;
   const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, x = bx + lx, y = by + ly;                     // a wave is 16 x 4 pixels: its stores are whole 128-byte / 64-byte row segments
   const bool inside = x < P.W && y < P.H;
   const size_t base = (size_t)l * P.W * P.H, o = base + (size_t)y * P.W + x;
@@ -376,7 +399,7 @@ void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, 
   const PreExtra E{rgb, rgba, (uint32_t)n_color_px, (uint4*)zero, zero_words >> 2};
   if (!only || only == 1) hipLaunchKernelGGL(k_pre_morph, dim3(rows.x, rows.y, P.N + ((rgb || zero) ? 2 : 0)), dim3(256), 0, st, P, B, E);
   if (!only || only == 2) hipLaunchKernelGGL(k_pre_filter, tiles, dim3(256), 0, st, P, B, T);
-  if (!only || only == 3) hipLaunchKernelGGL(k_pre_boundary, tiles, dim3(256), 0, st, P, B, T, F);
+  if (!only || only == 3) hipLaunchKernelGGL(k_pre_boundary, dim3(tiles.x * tiles.y * tiles.z + (B.blk_flag ? B.cand_cap : 0u)), dim3(256), 0, st, P, B, T, F, (int)tiles.x, (int)tiles.y);
   if (!only || only == 4) hipLaunchKernelGGL(k_pre_normal, tiles, dim3(256), 0, st, P, B, T, BR);
   if (!only || only == 5) hipLaunchKernelGGL(k_pre_quality, tiles, dim3(256), 0, st, P, B, T, ranges, (P.W + 7) / 8, (P.H + 7) / 8);
 }

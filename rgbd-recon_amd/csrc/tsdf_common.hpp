@@ -169,6 +169,9 @@ struct PreBuffers {
   float4* normal;         // normal output
   float4* dqs;            // packed {depth.r, quality, silhouette, 0}
   float* depth_plane;
+  // (round 4) the 16 x 16 blocks that hold a boundary candidate: the filter pass numbers them (blk_flag = 1 + position in cand_list, 0 = none; cand_count zeroed by the
+  // morph launch), the boundary pass runs them FIRST (their chain -- Lab tile, then the colour comparisons -- is what its launch waits for).  Null: no list.
+  uint32_t* blk_flag; uint32_t* cand_list; uint32_t* cand_count; uint32_t cand_cap;
 };
 // point back-end (k_points.hip)
 struct PointParams {
