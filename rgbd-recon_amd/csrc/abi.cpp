@@ -355,18 +355,29 @@ hipError_t join_fill(tsdf_ctx* c) {
 bool pipelined(const tsdf_ctx* c) { return c->overlap_fill && !c->pipeline_blocked; }
 inline int alt_of(int x) { return x ^ 1; }
 bool deep_ok(const tsdf_ctx* c);
-hipStream_t pre_enter(tsdf_ctx* c) {
+// the deferred wait of the gate, now (every lane call that does not defer it itself starts with this)
+static void gate_now(tsdf_ctx* c) {
+  if (!c->gate_wait_pending) return;
+  c->gate_wait_pending = false;
+  hipStreamWaitEvent(c->pre_lane, c->gate_wait_ev, 0);
+}
+hipStream_t pre_enter(tsdf_ctx* c, bool defer_gate) {
   if (!pipelined(c)) return c->stream;
   if (!c->pre_stream) {                                                   // (a context created with RR_OVERLAP_FILL=0 and switched on later)
     if (hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess) { c->pipeline_blocked = true; return c->stream; }
+        hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pre_gate_b, hipEventDisableTiming) != hipSuccess) { c->pipeline_blocked = true; return c->stream; }
   }
   if (c->main_since_gate) {                                               // the lane's first call of a new frame
     // which stream: the lane ahead's own -- or, with the integrate lane in use, that one: a frame's preparation and its integrate() then
     // follow each other without a cross-stream hand-over (15-35 us each on this machine) at the price of not
     // overlapping the preparation of frame f + 2 with the integrate of frame f + 1
     c->pre_lane = (c->pre_on_integ && deep_ok(c)) ? c->integ_stream : c->pre_stream;
-    if (c->pre_gate_recorded) hipStreamWaitEvent(c->pre_lane, c->pre_gate, 0);   // (recorded at the previous frame's first call: the consumers of the frame before that)
+    hipEvent_t const gate_old = c->gate_flip ? c->pre_gate_b : c->pre_gate, gate_new = c->gate_flip ? c->pre_gate : c->pre_gate_b;
+    if (c->gate_wait_pending) { c->gate_wait_pending = false; hipStreamWaitEvent(c->pre_lane, c->gate_wait_ev, 0); }   // (a deferred wait nobody asked for: never skipped)
+    if (c->pre_gate_recorded) {                                            // (recorded at the previous frame's first call: the consumers of the frame before that)
+      if (defer_gate) { c->gate_wait_pending = true; c->gate_wait_ev = gate_old; }
+      else hipStreamWaitEvent(c->pre_lane, gate_old, 0);
+    }
     // ... on the context's stream, which waits for an integrate() on the fourth lane only when a DRAW joins it.  Frames integrated back to back with no
     // draw in between leave that integrate out of every gate, while it may still read the frame slot / brick counters / occupancy set this frame is about to
     // overwrite (the copies alternate): the lane waits for the integrate lane itself then.  (In the per-frame order upload .. integrate, draw the flag is
@@ -375,11 +386,12 @@ hipStream_t pre_enter(tsdf_ctx* c) {
       hipEventRecord(c->integ_done, c->integ_stream);
       hipStreamWaitEvent(c->pre_lane, c->integ_done, 0);
     }
-    hipEventRecord(c->pre_gate, c->stream);
+    hipEventRecord(gate_new, c->stream);
+    c->gate_flip = !c->gate_flip;
     c->pre_gate_recorded = true; c->main_since_gate = false;
     c->slot_flipped = c->counters_flipped = c->occ_flipped = false;
     c->counters_zeroed = c->occ_count_zeroed = false;
-  }
+  } else if (!defer_gate) gate_now(c);
   return c->pre_lane;
 }
 hipError_t pre_leave(tsdf_ctx* c, hipStream_t lane) {
@@ -387,6 +399,7 @@ hipError_t pre_leave(tsdf_ctx* c, hipStream_t lane) {
   return hipSuccess;
 }
 hipError_t join_pre(tsdf_ctx* c) {
+  gate_now(c);
   c->main_since_gate = true;
   c->slot_in_use = c->counters_in_use = c->occ_in_use = true;
   if (!c->pre_pending) return hipSuccess;
@@ -718,6 +731,7 @@ int32_t tsdf_create(const tsdf_config* cfg, tsdf_ctx** out) {
     if (make_stream(&c->pre_stream, 0, ppre, true) != hipSuccess ||
         (two_lanes ? (c->fill_stream = c->pre_stream, hipSuccess) : make_stream(&c->fill_stream, 1, pfill, true)) != hipSuccess ||
         hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pre_gate, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->pre_gate_b, hipEventDisableTiming) != hipSuccess ||
         make_stream(&c->integ_stream, 2, pinteg, true) != hipSuccess ||
         hipEventCreateWithFlags(&c->draw_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->draw_done[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->integ_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->integ_gate, hipEventDisableTiming) != hipSuccess ||
@@ -799,6 +813,7 @@ int32_t tsdf_destroy(tsdf_ctx* c) {
   if (c->pre_stream && c->pre_stream != c->fill_stream) hipStreamDestroy(c->pre_stream);
   if (c->pre_done) hipEventDestroy(c->pre_done);
   if (c->pre_gate) hipEventDestroy(c->pre_gate);
+  if (c->pre_gate_b) hipEventDestroy(c->pre_gate_b);
   if (c->src_ready) hipEventDestroy(c->src_ready);
   if (c->normals_read) hipEventDestroy(c->normals_read);
   if (c->fill_worker) {
@@ -1119,13 +1134,13 @@ int32_t tsdf_upload_raw_frame(tsdf_ctx* c, const float* depth_raw, const uint8_t
 }
 // ... and with both arrays in device memory already (a decoder, a camera SDK's buffer): no copy -- the passes read depth_raw where it lies.  flags as
 // for tsdf_upload_frame_dev; the arrays must stay untouched until work queued on the context's stream AFTER the next tsdf_integrate() / draw call runs.
-int32_t tsdf_upload_raw_frame_dev(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour, uint32_t flags) {
+static int32_t upload_raw_frame_dev_impl(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour, uint32_t flags, bool defer_gate) {
   CHECK_CTX(c);
   if (!depth_raw || !colour) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "raw depth and colour are required");
   if (((uintptr_t)depth_raw & 3u) || ((uintptr_t)colour & 3u)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "device arrays must be 4-byte aligned");
   HIP_TRY(c, hipSetDevice(c->device));
   if (int32_t rc = ensure_pre_buffers(c)) return rc;
-  const hipStream_t lane = pre_enter(c);
+  const hipStream_t lane = pre_enter(c, defer_gate);                      // (nothing below writes what the previous frames' draws read: flips of host pointers, a wait for the producer)
   if (lane != c->stream && !(flags & TSDF_FRAME_ARRAYS_COMPLETE)) {      // the producer may be work on the context's stream: behind all of it
     if (!c->src_ready) HIP_TRY(c, hipEventCreateWithFlags(&c->src_ready, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->src_ready, c->stream));
@@ -1137,6 +1152,7 @@ int32_t tsdf_upload_raw_frame_dev(tsdf_ctx* c, const float* depth_raw, const uin
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
+int32_t tsdf_upload_raw_frame_dev(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour, uint32_t flags) { return upload_raw_frame_dev_impl(c, depth_raw, colour, flags, false); }
 int32_t tsdf_set_depth_limits(tsdf_ctx* c, uint32_t i, float mn, float mx) {
   CHECK_CTX(c);
   if (i >= c->cfg.num_streams || !(mx > mn)) FAIL(c, TSDF_ERR_INVALID_ARGUMENT, "bad stream index or depth limits");
@@ -1260,7 +1276,11 @@ static PreBuffers pre_buffers(tsdf_ctx* c) {
   B.cand_count = c->d_pre_blocks; B.cand_list = c->d_pre_blocks + 1; B.cand_cap = c->pre_cand_cap; B.blk_flag = c->d_pre_blocks + 1 + c->pre_cand_cap;
   return B;
 }
-int32_t tsdf_process_textures(tsdf_ctx* c) {
+// phase 0: the five passes.  Phases 1 and 2 are tsdf_frame_raw_dev's split of the same work (round 4): the morph and the filter pass read the raw frame and write
+// only intermediate images of the lane's own, so they are queued IN FRONT of the lane's wait for the draws of two frames back (the two-frame cycle end of draw(f) ->
+// preparation of f + 2 -> integrate(f + 2) -> draw(f + 2) that bounds the frame from raw data loses their 36 us); phase 2 -- behind that wait -- re-lays the colour out
+// into the frame slot and runs the three passes that write what draws read (depth plane, packed texel, range cells, brick counters).
+static int32_t process_textures_impl(tsdf_ctx* c, int phase) {
   CHECK_CTX(c);
   if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "no raw frame uploaded (tsdf_upload_raw_frame)");
   for (uint32_t i = 0; i < c->cfg.num_streams; ++i) {
@@ -1270,9 +1290,9 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   // Round 4: on the lane ahead, like markBricks() -- the passes read the raw frame and write only what the lane owns (the frame slot it flipped to,
   // the brick counters clearOccupiedBricks() flipped to, its own intermediate images), so they run beside the previous frames' integrate and draw.
-  const hipStream_t lane = pre_enter(c);
+  const hipStream_t lane = pre_enter(c, phase == 1);
   if (int32_t rc = begin_slot_write(c, lane, true)) return rc;          // (already done by the raw upload of this frame; a re-run of an old raw frame takes the colour along)
-  if (c->normals_read_pending) {                                         // the point / triangle-grid back-ends read the normal image this call rewrites
+  if (phase != 1 && c->normals_read_pending) {                           // the point / triangle-grid back-ends read the normal image this call rewrites
     if (lane != c->stream) HIP_TRY(c, hipStreamWaitEvent(lane, c->normals_read, 0));
     c->normals_read_pending = false;
   }
@@ -1281,23 +1301,33 @@ int32_t tsdf_process_textures(tsdf_ctx* c) {
   for (int a = 0; a < 3; ++a) { P.bbox_min[a] = c->cfg.bbox_min[a]; P.bbox_max[a] = c->cfg.bbox_max[a]; }
   const PreBuffers B = pre_buffers(c);
   c->pre_generation = c->raw_generation; c->pre_processed_depth = c->use_processed_depth;
-  timer_begin_on(c, "1preprocess", lane);
+  if (phase != 2) timer_begin_on(c, "1preprocess", lane);
   const size_t ncol = (size_t)c->cfg.num_streams * c->frame.cw * c->frame.ch;
-  if (c->timers_on && c->timer_filter.find(",k_pre_") != std::string::npos) {   // each pass between its own pair of events, when the timer filter NAMES them (a pair costs the lane ~7 us)
+  float4* const ranges = c->slots[c->cur_slot].ranges;
+  if (phase == 1) {
+    launch_preprocess(lane, P, B, c->luts, c->frame, c->br, ranges, nullptr, nullptr, 0, nullptr, 0, 1);
+    launch_preprocess(lane, P, B, c->luts, c->frame, c->br, ranges, nullptr, nullptr, 0, nullptr, 0, 2);
+  } else if (phase == 2) {
+    if (c->pending_rgb) launch_preprocess(lane, P, B, c->luts, c->frame, c->br, ranges, c->pending_rgb, (uchar4*)c->frame.color, ncol, nullptr, 0, 6);
+    for (int k = 3; k <= 5; ++k) launch_preprocess(lane, P, B, c->luts, c->frame, c->br, ranges, nullptr, nullptr, 0, nullptr, 0, k);
+  } else if (c->timers_on && c->timer_filter.find(",k_pre_") != std::string::npos) {   // each pass between its own pair of events, when the timer filter NAMES them (a pair costs the lane ~7 us)
     static const char* const names[5] = {"k_pre_morph", "k_pre_filter", "k_pre_boundary", "k_pre_normal", "k_pre_quality"};
     for (int k = 1; k <= 5; ++k) {
       timer_begin_on(c, names[k - 1], lane);
-      launch_preprocess(lane, P, B, c->luts, c->frame, c->br, c->slots[c->cur_slot].ranges, c->pending_rgb, (uchar4*)c->frame.color, ncol, nullptr, 0, k);
+      launch_preprocess(lane, P, B, c->luts, c->frame, c->br, ranges, c->pending_rgb, (uchar4*)c->frame.color, ncol, nullptr, 0, k);
       timer_end_on(c, names[k - 1], lane);
     }
-  } else launch_preprocess(lane, P, B, c->luts, c->frame, c->br, c->slots[c->cur_slot].ranges, c->pending_rgb, (uchar4*)c->frame.color, ncol);
-  c->pending_rgb = nullptr;
-  timer_end_on(c, "1preprocess", lane);
+  } else launch_preprocess(lane, P, B, c->luts, c->frame, c->br, ranges, c->pending_rgb, (uchar4*)c->frame.color, ncol);
   HIP_TRY(c, hipGetLastError());
-  c->slots[c->cur_slot].have = true;
+  if (phase != 1) {
+    c->pending_rgb = nullptr;
+    timer_end_on(c, "1preprocess", lane);
+    c->slots[c->cur_slot].have = true;
+  }
   HIP_TRY(c, pre_leave(c, lane));
   return TSDF_OK;
 }
+int32_t tsdf_process_textures(tsdf_ctx* c) { return process_textures_impl(c, 0); }
 int32_t tsdf_download_preprocessed(tsdf_ctx* c, float* depth2, float* depth_rg, float* lab, float* depth_b, float* sil, float* normals, float* quality) {
   CHECK_CTX(c);
   if (!c->have_raw) FAIL(c, TSDF_ERR_STATE, "nothing was pre-processed yet");
@@ -1808,8 +1838,12 @@ int32_t tsdf_frame_dev(tsdf_ctx* c, const float* depth_rg, const float* quality,
 int32_t tsdf_frame_raw_dev(tsdf_ctx* c, const float* depth_raw, const uint8_t* colour, uint32_t flags, const float* mv, const float* pr) {
   CHECK_CTX(c);
   int32_t rc;
-  if (depth_raw && (rc = tsdf_upload_raw_frame_dev(c, depth_raw, colour, flags))) return rc;
-  if ((rc = tsdf_clear_bricks(c)) || (rc = tsdf_process_textures(c)) || (rc = tsdf_update_occupied(c, nullptr)) || (rc = tsdf_integrate(c))) return rc;
+  const bool split = depth_raw && rrhost::pipelined(c) && !(c->timers_on && c->timer_filter.find(",k_pre_") != std::string::npos);   // (the per-pass timers keep the five passes in one piece)
+  if (depth_raw && (rc = upload_raw_frame_dev_impl(c, depth_raw, colour, flags, split))) return rc;
+  if (split) {                                                           // morph + filter in front of the lane's gate, the rest behind it (process_textures_impl)
+    if ((rc = process_textures_impl(c, 1)) || (rc = tsdf_clear_bricks(c)) || (rc = process_textures_impl(c, 2))) return rc;
+  } else if ((rc = tsdf_clear_bricks(c)) || (rc = tsdf_process_textures(c))) return rc;
+  if ((rc = tsdf_update_occupied(c, nullptr)) || (rc = tsdf_integrate(c))) return rc;
   return tsdf_draw_f(c, mv, pr);
 }
 int32_t tsdf_set_stage_overlap(tsdf_ctx* c, int32_t on) {

@@ -165,7 +165,10 @@ struct tsdf_ctx {
   // two frames ago).  (A third copy of everything, letting the lane run two frames ahead, was built and measured: the lanes then crowd each
   // other -- every stage stretches -- and the frame takes 140 instead of 121 us: DESIGN.md section 5.)  Off with stage overlap off, after an explicit frame-slot call (tsdf_select_frame_slot, tsdf_upload_frame_async) and for
   // the pre-processing path.
-  hipStream_t pre_stream = nullptr; hipEvent_t pre_done = nullptr, pre_gate = nullptr, src_ready = nullptr;
+  hipStream_t pre_stream = nullptr; hipEvent_t pre_done = nullptr, pre_gate = nullptr, pre_gate_b = nullptr, src_ready = nullptr;
+  // (round 4) the gate's wait can be DEFERRED inside tsdf_frame_raw_dev: the first two pre-processing passes write nothing the previous draws read, so they run in front of it.
+  // Two gate events alternate so that a deferred wait still refers to the record of the previous frame after this frame's record has been made.
+  hipEvent_t gate_wait_ev = nullptr; bool gate_wait_pending = false, gate_flip = false;
   bool pre_pending = false, pre_gate_recorded = false, main_since_gate = true, pipeline_blocked = false;
   bool slot_flipped = false, counters_flipped = false, occ_flipped = false;     // once per frame of the lane ...
   bool slot_in_use = false, counters_in_use = false, occ_in_use = false;        // ... and only when a consumer has been queued since the buffer was last written
@@ -201,7 +204,7 @@ struct tsdf_ctx {
 
 // helpers defined in abi.cpp
 namespace rrhost {
-hipStream_t pre_enter(tsdf_ctx* c);     // the lane a frame-preparing call queues its work on (the context's stream when the lane is off); opens the lane's frame
+hipStream_t pre_enter(tsdf_ctx* c, bool defer_gate = false);     // (defer_gate: tsdf_frame_raw_dev's first calls; see gate_wait_pending) the lane a frame-preparing call queues its work on (the context's stream when the lane is off); opens the lane's frame
 hipError_t pre_leave(tsdf_ctx* c, hipStream_t lane);   // ... and after queuing it
 hipError_t join_pre(tsdf_ctx* c);       // GPU side: the context's stream waits for the lane; called by every consumer of a frame's images / brick state
 void timer_begin(tsdf_ctx* c, const char* name);

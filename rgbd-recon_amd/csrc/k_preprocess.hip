@@ -22,7 +22,7 @@ __device__ __forceinline__ int tap_y(int y, int dy, int H) { return clamp_tap(y 
 // flipped to.  Null pointers: nothing to do.
 struct PreExtra { const uint8_t* rgb; uchar4* rgba; uint32_t n_px; uint4* zero; uint32_t zero_quads; };
 __global__ __launch_bounds__(256) void k_pre_morph(PreParams P, PreBuffers B, PreExtra E) {
-  if (B.cand_count && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *B.cand_count = 0u;   // (the filter pass numbers this frame's candidate blocks)
+  if (B.cand_count && P.N > 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *B.cand_count = 0u;   // (the filter pass numbers this frame's candidate blocks)
   if ((int)blockIdx.z >= P.N) {
     const uint32_t nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
     if ((int)blockIdx.z == P.N) {                                         // ---- colour
@@ -398,6 +398,10 @@ void launch_preprocess(hipStream_t st, const PreParams& P, const PreBuffers& B, 
   const dim3 rows((P.W + 63) / 64, (P.H + 3) / 4, P.N), tiles((P.W + 15) / 16, (P.H + 15) / 16, P.N);
   const PreExtra E{rgb, rgba, (uint32_t)n_color_px, (uint4*)zero, zero_words >> 2};
   if (!only || only == 1) hipLaunchKernelGGL(k_pre_morph, dim3(rows.x, rows.y, P.N + ((rgb || zero) ? 2 : 0)), dim3(256), 0, st, P, B, E);
+  if (only == 6 && (rgb || zero)) {                                      // the two extra layers alone (tsdf_frame_raw_dev: behind the lane's gate, the morph pass in front of it)
+    PreParams P0 = P; P0.N = 0;
+    hipLaunchKernelGGL(k_pre_morph, dim3(rows.x, rows.y, 2), dim3(256), 0, st, P0, B, E);
+  }
   if (!only || only == 2) hipLaunchKernelGGL(k_pre_filter, tiles, dim3(256), 0, st, P, B, T);
   if (!only || only == 3) hipLaunchKernelGGL(k_pre_boundary, dim3(tiles.x * tiles.y * tiles.z + (B.blk_flag ? B.cand_cap : 0u)), dim3(256), 0, st, P, B, T, F, (int)tiles.x, (int)tiles.y);
   if (!only || only == 4) hipLaunchKernelGGL(k_pre_normal, tiles, dim3(256), 0, st, P, B, T, BR);
