@@ -126,6 +126,51 @@ def test_raw_frames_through_the_lanes(rr, monkeypatch):
     assert ((sd < 1) != (od < 1)).mean() <= 2e-3 and (sd < 1).sum() > 100
 
 
+def test_deferred_gate_mixes_with_every_other_call_order(rr):
+    """tsdf_frame_raw_dev queues the morph and the filter pass of a new frame in FRONT of the lane ahead's wait for the draws of two frames back (two gate events
+    alternate, the wait is issued by the first call that needs it).  Mixed with the separate calls in the reference's order, with a read between mark and update, with
+    a re-run of the resident raw frame (no new frame: nothing is deferred) and with frames integrated but not drawn, the volume, the brick counters, the
+    pre-processing products and the framebuffer must stay those of a context with every kernel on one stream, frame by frame."""
+    import torch
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    scs = scenes(rr, **mk)
+    kw = dict(res=(96, 96, 96), brick_size=[2.0 / 12, 2.2 / 12, 2.0 / 12], limit=0.04, view=(160, 90))
+    pr = rr.scene.gl_flat(rr.scene.perspective(50.0, 16.0 / 9.0, 0.1, 200.0))
+    mvs = [rr.scene.gl_flat(rr.scene.look_at(e, (0.0, 1.1, 0.0))) for e in [(0.0, 1.1, 3.0), (1.6, 1.4, 2.4), (-2.2, 0.6, 1.2)]]
+    dev = [(torch.from_numpy(np.ascontiguousarray(sc["depth_raw"], np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(sc["color"], np.uint8)).cuda()) for sc in scs]
+    torch.cuda.synchronize()
+    lanes, serial = rr.ReconIntegrationHip(scs[0], **kw), rr.ReconIntegrationHip(scs[0], **kw)
+    serial.set_stage_overlap(False)
+    for o in (lanes, serial):
+        o.set_preprocess_calibration(scs[0])
+
+    def separate(o, k, n, draw=True, ratio=False):
+        o.upload_raw_frame_dev(dev[k][0].data_ptr(), dev[k][1].data_ptr(), complete=True); o.clearOccupiedBricks(); o.processTextures()
+        if ratio:
+            o.occupiedRatio()                                   # a read in the middle of the lane's frame
+        o.updateOccupiedBricks(False); o.integrate()
+        if draw:
+            o.drawF(mvs[n % 3], pr)
+    plan = [("fused", 0), ("fused", 1), ("separate", 2), ("fused", 1), ("rerun", 1), ("fused", 0), ("undrawn", 2), ("fused", 0), ("ratio", 1), ("fused", 2), ("fused", 0)]
+    for n, (how, k) in enumerate(plan):
+        for o in (lanes, serial):
+            if how == "fused":
+                o.frame_raw_dev(mvs[n % 3], pr, new_frame=(dev[k][0].data_ptr(), dev[k][1].data_ptr()), complete=True)
+            elif how == "rerun":
+                o.frame_raw_dev(mvs[n % 3], pr)
+            else:
+                separate(o, k, n, draw=how != "undrawn", ratio=how == "ratio")
+        if how in ("rerun", "undrawn") or n == len(plan) - 1:       # (checked at a few points only: a read synchronises, and most of the plan must run unsynchronised)
+            assert_same(lanes.tsdf(), serial.tsdf(), f"volume after step {n} ({how})")
+            np.testing.assert_array_equal(lanes.bricks()[0], serial.bricks()[0])
+            a, b = lanes.preprocessed(), serial.preprocessed()
+            for key in a:
+                assert_same(a[key], b[key], f"{key} after step {n} ({how})")
+            (lc, ld), (sc_, sd) = lanes.framebuffer(), serial.framebuffer()
+            assert_same(ld, sd, f"framebuffer depth after step {n}"); assert_same(lc, sc_, f"framebuffer colour after step {n}")
+    assert (ld < 1).sum() > 100
+
+
 def test_lab_image_is_produced_on_request(rr):
     """Round 4: the passes evaluate the Lab colour (pre_depth.fs :131-143) only in the blocks where pre_boundary.fs reads it; the whole image is produced by
     tsdf_download_preprocessed from the processed frame's inputs.  It must agree with the oracle's (powf: the tolerance of test_gpu_preprocess), the other

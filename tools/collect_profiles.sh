@@ -21,3 +21,4 @@ for c in c2 c1 c3 c4 c2_preprocess; do
   python3 $R/profiles/summarize_pmc.py $c $R/profiles/${NAME}_pmc_FETCH_SIZE_$c.csv $R/profiles/${NAME}_pmc_WRITE_SIZE_$c.csv $R/profiles/${NAME}_pmc_SQ_INSTS_VALU_$c.csv
 done
 for c in c1 c2 c3 c4 c2_preprocess c2_exchange_alone c2_exchange_alone_native c2_one_stream c2_3_frames_in_flight; do cp $G/bench_$c.json $R/profiles/${NAME}_bench_$c.json; done
+for f in f32-rgb8 u8-dxt1; do [ -f $G/bench_c2_ingest_$f.json ] && cp $G/bench_c2_ingest_$f.json $R/profiles/${NAME}_bench_c2_ingest_$f.json || true; done

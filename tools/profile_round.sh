@@ -59,3 +59,8 @@ python3 bench.py --preprocess --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_
 RR_OVERLAP_FILL=0 python3 bench.py --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_one_stream.json 2> gpurun_out/$TAG/bench_c2_one_stream.err
 python3 bench.py --frames-in-flight 3 --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_3_frames_in_flight.json 2> gpurun_out/$TAG/bench_c2_3fif.err
 echo "all done"
+# round 4: the wire path (f2) -- host message -> pinned copy -> H2D -> GPU unpack / DXT decode -> pre-processing -> the frame
+for f in f32-rgb8 u8-dxt1; do
+  python3 bench.py --ingest $f --no-cpu-baseline --no-c1 --long-steps 0 > gpurun_out/$TAG/bench_c2_ingest_$f.json 2> gpurun_out/$TAG/bench_c2_ingest_$f.err || true
+done
+echo "ingest done"
