@@ -44,11 +44,26 @@ __device__ __forceinline__ float integrate_voxel(const StreamTable& T, const Fra
 
 // Is voxel (x,y,z) in the index list of at least one occupied brick?  (volume_sampler.cpp:50-62 lists,
 // restated as per-axis voxel -> brick tables; 1 candidate per axis in every aligned configuration.)
+// Round 4: a voxel lies in one brick per axis, two where the reference's float arithmetic lets neighbouring bricks overlap by a voxel: the (up to) eight flags are
+// requested TOGETHER.  As three nested loops with a load and a wait in the innermost one the rim tiles of the occupied set paid up to eight dependent round trips
+// at their head (5 us of the c2 launch: 41.7 -> 36 us without the test, a timing experiment).  More than two bricks per axis: the loops.
 __device__ __forceinline__ bool voxel_drawn(const Bricks& B, int x, int y, int z) {
   const int fx = B.vox_first[0][x], nx = B.vox_count[0][x];
   const int fy = B.vox_first[1][y], ny = B.vox_count[1][y];
   const int fz = B.vox_first[2][z], nz = B.vox_count[2][z];
   bool any = false;
+  if (__ballot(nx > 2 || ny > 2 || nz > 2) == 0ull) {                    // wave-uniform
+    uint8_t f[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int i = c & 1, j = (c >> 1) & 1, k = c >> 2;
+      const bool valid = i < nx && j < ny && k < nz;
+      f[c] = B.flags[valid ? ((size_t)(fz + k) * B.res[1] + (fy + j)) * B.res[0] + (fx + i) : (size_t)0];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) any |= ((c & 1) < nx && ((c >> 1) & 1) < ny && (c >> 2) < nz) && f[c] != 0;
+    return any;
+  }
   for (int k = 0; k < nz; ++k)
     for (int j = 0; j < ny; ++j)
       for (int i = 0; i < nx; ++i)
@@ -749,9 +764,16 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
     for (int h = 0; h < kVox; ++h) {
       const int z = t3[2] * 8 + lz + 4 * h;
       drawn[h] = interior || ((x < V.res[0]) && (y < V.res[1]) && (z < V.res[2]));
-      if (kCheck && drawn[h] && check_voxels) drawn[h] = voxel_drawn(B, x, y, z);
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
       wsum[h] = 0.0f;
+    }
+    // the per-voxel "is it in an occupied brick's list" test: a branch of its own on the WORKGROUP-UNIFORM flag, so that the brick tables' pointers (kernel
+    // arguments the compiler cannot keep in scalar registers across the tile loop) are fetched by the tiles that need them only -- with the test inside the
+    // loop above they were fetched, and waited for, at the head of EVERY tile (5 us of the c2 launch)
+    if (kCheck && __builtin_expect(check_voxels, 0)) {
+#pragma unroll
+      for (int h = 0; h < kVox; ++h)
+        if (drawn[h]) drawn[h] = voxel_drawn(B, x, y, t3[2] * 8 + lz + 4 * h);
     }
     // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)                // (kRanges) 2 bits per stream, from k_pair_masks: which streams treat every voxel of this tile alike
     for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
