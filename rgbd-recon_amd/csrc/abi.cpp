@@ -1522,7 +1522,7 @@ int32_t tsdf_integrate(tsdf_ctx* c) {
   if ((!c->use_bricks || culled_ranges) && lds >= 2 && c->frame.ranges) {
     if (!c->d_tile_bounds) HIP_TRY(c, hipMalloc((void**)&c->d_tile_bounds, (size_t)c->vol.n_stored_tiles * c->cfg.num_streams * 2 * sizeof(float4)));
     if (!c->d_pair_masks) HIP_TRY(c, hipMalloc((void**)&c->d_pair_masks, (size_t)c->tiles.n * sizeof(uint32_t)));
-    if (c->use_recs && !c->d_work_recs) HIP_TRY(c, hipMalloc((void**)&c->d_work_recs, (size_t)c->tiles.n * sizeof(uint4)));
+    if (c->use_recs && !c->d_work_recs) HIP_TRY(c, hipMalloc((void**)&c->d_work_recs, (size_t)c->tiles.n * (sizeof(uint4) + 8 * sizeof(unsigned long long))));   // per tile: the 16-byte record, then (after all records) its 8 x 64 per-voxel bits
     if (!c->tile_bounds_valid) { launch_tile_bounds(lane, c->luts, c->vol, c->d_tile_bounds); c->tile_bounds_valid = true; }
     bounds = c->d_tile_bounds;
   }

@@ -402,7 +402,8 @@ extern "C" int32_t tsdf_debug_pair_stats(unsigned long long out[4], int reset) {
 #endif
 template <bool kList>
 __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, int per_voxel_check,
-                                                    const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks, uint4* __restrict__ recs, ProjCache PC) {
+                                                    const float4* __restrict__ tile_bounds, uint32_t* __restrict__ masks, uint4* __restrict__ recs, ProjCache PC,
+                                                    unsigned long long* __restrict__ vmasks) {
   const int ln = threadIdx.x & 63;
   const int n_work = kList ? (int)*S.count : S.n;
   const int n_waves = gridDim.x * 4;
@@ -440,17 +441,53 @@ __global__ __launch_bounds__(256) void k_pair_masks(StreamTable T, FrameImages F
       const int b0x = B.tile_b0[0][t3[0]], nbx = (int)B.tile_b1[0][t3[0]] - b0x + 1, b0y = B.tile_b0[1][t3[1]], nby = (int)B.tile_b1[1][t3[1]] - b0y + 1;
       const int b0z = B.tile_b0[2][t3[2]], nbz = (int)B.tile_b1[2][t3[2]] - b0z + 1;
       const bool listed = B.tile_full[0][t3[0]] && B.tile_full[1][t3[1]] && B.tile_full[2][t3[2]];
+      // (vmasks) this lane's voxel column and -- lanes 0 .. 7 -- the tile's eight layers in the per-axis voxel -> brick tables: requested with the loads above,
+      // used below when the tile's voxels have to be answered one by one
+      const int xr = t3[0] * 8 + (ln & 7), yr = t3[1] * 8 + (ln >> 3);
+      const int x = min(xr, V.res[0] - 1), y = min(yr, V.res[1] - 1), zl = min(t3[2] * 8 + (ln & 7), V.res[2] - 1);
+      int fx = 0, nx = 0, fy = 0, ny = 0, fz_l = 0, nz_l = 0;
+      if (vmasks) { fx = B.vox_first[0][x]; nx = B.vox_count[0][x]; fy = B.vox_first[1][y]; ny = B.vox_count[1][y]; fz_l = B.vox_first[2][zl]; nz_l = B.vox_count[2][zl]; }
       const int nb = (nbx > 0 && nby > 0 && nbz > 0) ? __mul24(__mul24(nbx, nby), nbz) : 0;
-      bool all = listed && nb > 0 && nb <= 64;
-      if (all) {                                                        // (wave-uniform)
-        bool occ = true;
-        if (ln < nb) {
-          const int bz = ln / __mul24(nbx, nby), rem = ln - __mul24(bz, __mul24(nbx, nby)), by = rem / nbx, bx = rem - __mul24(by, nbx);
-          occ = B.flags[((size_t)(b0z + bz) * B.res[1] + (b0y + by)) * B.res[0] + (b0x + bx)] != 0;
-        }
-        all = __ballot(!occ) == 0ull;
+      const bool few = nb > 0 && nb <= 64;                              // (wave-uniform) one lane per brick that reaches into the tile
+      int occ = 1;
+      if (few && ln < nb) {
+        const int bz = ln / __mul24(nbx, nby), rem = ln - __mul24(bz, __mul24(nbx, nby)), by = rem / nbx, bx = rem - __mul24(by, nbx);
+        occ = B.flags[((size_t)(b0z + bz) * B.res[1] + (b0y + by)) * B.res[0] + (b0x + bx)] != 0 ? 1 : 0;
       }
+      const bool all = listed && few && __ballot(occ == 0) == 0ull;
       if (all && T.n <= 15) pairs |= 0x80000000u;                       // (16 streams use all 32 bits for their classes)
+      else if (vmasks) {
+        // Round 4: the per-voxel answers themselves, here -- 8 x 64 bits per tile (bit y * 8 + x of word z: "inside the volume and in an occupied brick's list") --
+        // for the tiles the integrate kernel would otherwise test voxel by voxel at the head of their chain (a timing experiment without the test: 41.7 -> 36.3 us
+        // at c2).  The flags of the (at most 64) bricks that reach into the tile are in the lanes already: as ONE 64-bit word (brick (bx, by, bz) of the tile's span =
+        // bit (bz * nby + by) * nbx + bx), a voxel's candidates in x and y as a 64-bit pattern per lane, the layer's candidates in z as a shift -- no further flag
+        // loads, the per-axis voxel -> brick tables are this pass's only additional ones.
+        const bool xy_in = xr < V.res[0] && yr < V.res[1];
+        if (few) {
+          const unsigned long long occ_bits = __ballot(occ != 0 && ln < nb);
+          unsigned long long mxy = 0ull;                                  // this voxel column's candidate bricks within one brick layer
+          for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) mxy |= 1ull << (__mul24(fy + j - b0y, nbx) + (fx + i - b0x));
+          const int plane = __mul24(nbx, nby);
+          for (int z8 = 0; z8 < 8; ++z8) {
+            const int z = t3[2] * 8 + z8;
+            const int fz = __builtin_amdgcn_readlane(fz_l, z8), nz = __builtin_amdgcn_readlane(nz_l, z8);
+            unsigned long long layer = 0ull;                              // (wave-uniform) the occupied bricks of the layers this z is listed in, moved to layer 0
+            for (int k = 0; k < nz; ++k) layer |= occ_bits >> __mul24(fz + k - b0z, plane);
+            const bool dr = xy_in && z < V.res[2] && (layer & mxy) != 0ull;
+            const unsigned long long m = __ballot(dr);
+            if (ln == 0) vmasks[(size_t)w * 8 + z8] = m;
+          }
+        } else {
+          for (int z8 = 0; z8 < 8; ++z8) {                                // more than 64 bricks reach into the tile: flag by flag
+            const int z = t3[2] * 8 + z8;
+            bool dr = false;
+            if (xy_in && z < V.res[2]) dr = voxel_drawn(B, x, y, z);
+            const unsigned long long m = __ballot(dr);
+            if (ln == 0) vmasks[(size_t)w * 8 + z8] = m;
+          }
+        }
+      }
     }
     if (ln == 0) masks[w] = pairs;
     if (recs && ln == 0) {                                              // the work item's record (k_integrate_tiles_rec): everything its tile head needs in one 16-byte load
@@ -711,7 +748,8 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_lds(Strea
 #define RR_PRIO(site) do { } while (0)
 #endif
 template <bool kList, bool kCheck>
-__global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, const uint4* __restrict__ recs) {
+__global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(StreamTable T, FrameImages F, Volume V, Bricks B, TileState S, const uint4* __restrict__ recs,
+                                                                     const unsigned long long* __restrict__ vmasks) {
   [[maybe_unused]] constexpr bool kSep = true, kRanges = true, kCache = false;
   __shared__ float4 s_box[kBoxCap];             // the stream's texel box, x fastest: ((z - mz) * dy + (y - my)) * dx + (x - mx)
   __shared__ float4 s_row[kSep ? kRowCap : 1];  // (separable form) x-lerped rows: ((z - mz) * dy + (y - my)) * 8 + voxel x
@@ -743,6 +781,12 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
   const int lane0 = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);                          // 0 in every lane
 #endif
   uint4 rec_next = recs[(blockIdx.x < n_work ? blockIdx.x : 0) + lane0];
+  // (kCheck) the tile's per-voxel "is it drawn" words for this thread's two voxel layers (k_pair_masks; meaningful when the record's bit 31 is clear): with the record, a tile ahead
+  [[maybe_unused]] unsigned long long vm_next[2] = {0ull, 0ull};
+  if (kCheck) {
+    const size_t w0 = (size_t)(blockIdx.x < n_work ? blockIdx.x : 0) * 8 + (size_t)(threadIdx.x >> 6);
+    vm_next[0] = vmasks[w0 + lane0]; vm_next[1] = vmasks[w0 + 4 + lane0];
+  }
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
     RR_STAMP(0);                                                                     // tile head
     RR_PRIO(0);
@@ -750,7 +794,12 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
     const uint32_t pairs = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_next.x), packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_next.z);
     const int tile = __builtin_amdgcn_readfirstlane((int)rec_next.y);
     const uint32_t stored = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_next.w);
-    { const int wn = w + (int)gridDim.x; rec_next = recs[(wn < n_work ? wn : w) + lane0]; }
+    [[maybe_unused]] const unsigned long long vm[2] = {vm_next[0], vm_next[1]};
+    {
+      const int wn = w + (int)gridDim.x, wl = wn < n_work ? wn : w;
+      rec_next = recs[wl + lane0];
+      if (kCheck) { const size_t o = (size_t)wl * 8 + (size_t)(threadIdx.x >> 6); vm_next[0] = vmasks[o + lane0]; vm_next[1] = vmasks[o + 4 + lane0]; }
+    }
     const int t3[3] = {(int)(packed & 1023u), (int)((packed >> 10) & 1023u), (int)((packed >> 20) & 1023u)};
     const bool interior = (packed >> 30) & 1u;                          // all 512 voxels of the tile lie inside the volume
     float* __restrict__ out = V.data + ((size_t)stored << 9);
@@ -767,13 +816,9 @@ __global__ __launch_bounds__(256, RR_K1_BOUNDS) void k_integrate_tiles_rec(Strea
       tsd[h] = limit;                                                   // tsdf_integration.vs:28-29
       wsum[h] = 0.0f;
     }
-    // the per-voxel "is it in an occupied brick's list" test: a branch of its own on the WORKGROUP-UNIFORM flag, so that the brick tables' pointers (kernel
-    // arguments the compiler cannot keep in scalar registers across the tile loop) are fetched by the tiles that need them only -- with the test inside the
-    // loop above they were fetched, and waited for, at the head of EVERY tile (5 us of the c2 launch)
-    if (kCheck && __builtin_expect(check_voxels, 0)) {
+    if (kCheck && check_voxels) {                                         // (workgroup-uniform) the answers of k_pair_masks: bit y * 8 + x of the layer's word
 #pragma unroll
-      for (int h = 0; h < kVox; ++h)
-        if (drawn[h]) drawn[h] = voxel_drawn(B, x, y, t3[2] * 8 + lz + 4 * h);
+      for (int h = 0; h < kVox; ++h) drawn[h] = ((vm[h] >> (tid & 63)) & 1ull) != 0ull;
     }
     // (the previous tile's readers of s_* are done: store_tile_class() at its end is a workgroup barrier)                // (kRanges) 2 bits per stream, from k_pair_masks: which streams treat every voxel of this tile alike
     for (int t = tid; t < T.n * 24; t += 256) {                         // phase A, all streams at once
@@ -1111,8 +1156,9 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
   }
   if (phase == 1) return;
   if (ranges && phase != 4) {
-    if (use_bricks) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, B, S, pvc, tile_bounds, pair_masks, rec ? work_recs : nullptr, PC);
-    else hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds, pair_masks, rec ? work_recs : nullptr, PC);
+    unsigned long long* const vmasks = (rec && pvc) ? (unsigned long long*)(work_recs + S.n) : nullptr;   // (the record buffer holds 16 + 64 bytes per tile: abi.cpp)
+    if (use_bricks) hipLaunchKernelGGL(k_pair_masks<true>, dim3(2048), dim3(256), 0, st, T, F, V, B, S, pvc, tile_bounds, pair_masks, rec ? work_recs : nullptr, PC, vmasks);
+    else hipLaunchKernelGGL(k_pair_masks<false>, dim3((S.n + 3) / 4 < 4096 ? (S.n + 3) / 4 : 4096), dim3(256), 0, st, T, F, V, B, S, 0, tile_bounds, pair_masks, rec ? work_recs : nullptr, PC, (unsigned long long*)nullptr);
   }
   if (phase == 3) return;
   if (use_bricks) {
@@ -1126,8 +1172,8 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
       hipLaunchKernelGGL((k_integrate_cached<true, RR_K1C_CHUNK>), dim3(RR_K1C_GRID), dim3(64), 0, st, T.n, F, V, B, S, pvc, S.count, S.list, pair_masks, PC.items, PC);
       hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
     }
-    else if (rec && pvc) hipLaunchKernelGGL((k_integrate_tiles_rec<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, work_recs);
-    else if (rec) hipLaunchKernelGGL((k_integrate_tiles_rec<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, work_recs);
+    else if (rec && pvc) hipLaunchKernelGGL((k_integrate_tiles_rec<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, work_recs, (const unsigned long long*)(work_recs + S.n));
+    else if (rec) hipLaunchKernelGGL((k_integrate_tiles_rec<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, work_recs, (const unsigned long long*)nullptr);
     else if (ranges) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, pair_masks, PC);
     else if (lds_ok >= 2) hipLaunchKernelGGL((k_integrate_tiles_lds<true, true>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
     else if (lds_ok) hipLaunchKernelGGL((k_integrate_tiles_lds<true, false>), grid, dim3(256), 0, st, T, F, V, B, S, pvc, nullptr, PC);
@@ -1142,7 +1188,7 @@ void launch_integrate(hipStream_t st, const StreamTable& T, const FrameImages& F
       // lanes 2.5 % faster (4 349 against 4 242 frames/s; 8 192: 4 380 but the launch alone 125 us, 2 048: 3 796); RR_K1_DENSE_GRID: A/B hook
       static const int dcap = [] { const char* e = getenv("RR_K1_DENSE_GRID"); return e ? atoi(e) : 16384; }();
       const dim3 dgrid(dcap > 0 && dcap < S.n ? dcap : S.n);
-      if (rec) hipLaunchKernelGGL((k_integrate_tiles_rec<false, false>), dgrid, dim3(256), 0, st, T, F, V, B, S, work_recs);
+      if (rec) hipLaunchKernelGGL((k_integrate_tiles_rec<false, false>), dgrid, dim3(256), 0, st, T, F, V, B, S, work_recs, (const unsigned long long*)nullptr);
       else hipLaunchKernelGGL((k_integrate_tiles_lds<false, true, true>), dgrid, dim3(256), 0, st, T, F, V, B, S, 0, pair_masks, PC);
     }
     else if (lds_ok >= 2) hipLaunchKernelGGL((k_integrate_tiles_lds<false, true>), dim3(S.n), dim3(256), 0, st, T, F, V, B, S, 0, nullptr, PC);
