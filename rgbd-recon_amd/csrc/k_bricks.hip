@@ -123,8 +123,11 @@ __global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages 
     }
     return;
   }
-  const int px = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+  // (round 4) a wave is an 8 x 8-pixel cell of a 16 x 16 block, not a 64 x 4 strip: the pixels of a cell fall into a third as many bricks as those of a strip, and
+  // wave_count below is a loop over the wave's distinct bricks (14 % of the cells of a c2 frame hold a depth against 19 % of the strips)
+  const int cell = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int px = blockIdx.x * 16 + ((cell & 1) << 3) + (ln & 7);
+  const int py = blockIdx.y * 16 + ((cell >> 1) << 3) + (ln >> 3);
   const int layer = blockIdx.z;
   bool own = false, nbr = false;
   uint32_t id_own = 0, id_nbr = 0;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void k_mark_bricks(StreamTable T, FrameImages 
   wave_count(B.counters, id_own, own);
 }
 void launch_mark_bricks(hipStream_t st, const StreamTable& T, const FrameImages& F, const Bricks& B, uint32_t* zero_word, const PeelClear* pc) {
-  dim3 grid((F.w + 63) / 64, (F.h + 3) / 4, T.n + (pc ? 1 : 0));
+  dim3 grid((F.w + 15) / 16, (F.h + 15) / 16, T.n + (pc ? 1 : 0));
   hipLaunchKernelGGL(k_mark_bricks, grid, dim3(256), 0, st, T, F, B, zero_word, pc ? *pc : PeelClear{});
 }
 
