@@ -1109,6 +1109,7 @@ static int32_t ensure_pre_buffers(tsdf_ctx* c) {
     HIP_TRY(c, hipMalloc(&c->d_normal, np * sizeof(float4)));
     const size_t blocks = (size_t)c->cfg.num_streams * ((F.w + 15) / 16) * ((F.h + 15) / 16);
     c->pre_cand_cap = (uint32_t)std::min<size_t>(blocks, 1024);
+    if (const char* e = getenv("RR_TEST_PRE_CAND_CAP")) c->pre_cand_cap = (uint32_t)std::min<size_t>(blocks, (size_t)std::max(1, atoi(e)));   // test hook: a short list, so that candidate blocks overflow it
     HIP_TRY(c, hipMalloc(&c->d_pre_blocks, (1 + c->pre_cand_cap + blocks) * sizeof(uint32_t)));
     HIP_TRY(c, hipMemset(c->d_pre_blocks, 0, (1 + c->pre_cand_cap + blocks) * sizeof(uint32_t)));
   }

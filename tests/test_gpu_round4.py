@@ -171,6 +171,24 @@ def test_deferred_gate_mixes_with_every_other_call_order(rr):
     assert (ld < 1).sum() > 100
 
 
+def test_boundary_candidate_list_overflow(rr, monkeypatch):
+    """The boundary pass runs the blocks the filter pass listed as holding a candidate first; the list has a fixed capacity (1 024 blocks) and a candidate block
+    beyond it is processed in its ordinary place.  With the capacity forced to 2 (test hook) almost every candidate block takes that path: the products stay the oracle's."""
+    monkeypatch.setenv("RR_TEST_PRE_CAND_CAP", "2")
+    mk = dict(n_streams=3, width=160, height=120, lut_res=24, inv_res=32)
+    sc = scenes(rr, **mk)[1]
+    kw = dict(res=(64, 64, 64), limit=0.04, view=(160, 90))
+    hip, orc = rr.ReconIntegrationHip(sc, **kw), OracleRecon(sc, **kw)
+    for r in (hip, orc):
+        r.upload_raw_frame(sc); r.clearOccupiedBricks(); r.processTextures()
+    h, o = hip.preprocessed(), orc.preprocessed()
+    cand = (o["depth_rg"][..., 0] > 0) & ~(o["depth_rg"][..., 1] > 0.65)
+    assert cand.reshape(3, 120 // 8, 8, 160 // 16, 16).any(axis=(2, 4)).sum() > 4      # more candidate blocks than the forced capacity (8-row blocks: a lower bound for the 16 x 16 ones... counted loosely)
+    for key in ("depth2", "depth_rg", "depth_b", "silhouette", "normals"):
+        assert_same(h[key], o[key], key)
+    np.testing.assert_array_equal(hip.bricks()[0], orc.counters())
+
+
 def test_lab_image_is_produced_on_request(rr):
     """Round 4: the passes evaluate the Lab colour (pre_depth.fs :131-143) only in the blocks where pre_boundary.fs reads it; the whole image is produced by
     tsdf_download_preprocessed from the processed frame's inputs.  It must agree with the oracle's (powf: the tolerance of test_gpu_preprocess), the other
