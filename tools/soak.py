@@ -26,7 +26,13 @@ hip.setUseBricks(not dense); hip.setSpaceSkip(not dense); hip.setColorFilling(no
 # brick passes of frame f + 1), the context's stream (integrate / march / shade of frame f) and the fill lane (hole filling of frame f - 1) --
 # run against each other for the whole soak; SOAK_SLOTS=1 selects round 2's flow (two resident frames, explicit frame slots: no lane ahead)
 SLOTS = os.environ.get("SOAK_SLOTS") == "1"
-if SLOTS:
+RAW = os.environ.get("SOAK_RAW") == "1"                  # round 4: the RAW frames through tsdf_frame_raw_dev (pre-processing on the lane ahead, its first two passes in front of the gate)
+if RAW:
+    hip.set_preprocess_calibration(scene)
+    raw = [[torch.from_numpy(np.ascontiguousarray(sc["depth_raw"], np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(sc["color"], np.uint8)).cuda()] for sc in (scene_b, scene)]
+    ptr = [[t.data_ptr() for t in r] for r in raw]
+    torch.cuda.synchronize()
+elif SLOTS:
     hip.select_frame_slot(1); hip.upload_frame(scene_b); hip.select_frame_slot(0)
 else:
     raw = [[torch.from_numpy(np.ascontiguousarray(sc[k])).cuda() for k in ("depth", "quality", "silhouette", "color")] for sc in (scene_b, scene)]
@@ -45,11 +51,14 @@ ref = {}
 t0 = time.perf_counter()
 for f in range(1, N + 1):
     which = ((f + 1) >> 1) & 1                            # A A B B ...: with two volume sets alternating per integrate() (the fourth lane) each set still sees A, B, A, B
-    if SLOTS:
-        hip.select_frame_slot(0 if which else 1)
+    if RAW:
+        hip.frame_raw_dev(mv if which else mv_b, pr, new_frame=(ptr[which][0], ptr[which][1]), complete=True)
     else:
-        hip.upload_frame_dev(*ptr[which], complete=True)
-    hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv if which else mv_b, pr)
+        if SLOTS:
+            hip.select_frame_slot(0 if which else 1)
+        else:
+            hip.upload_frame_dev(*ptr[which], complete=True)
+        hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv if which else mv_b, pr)
     if f <= 4 or f % CHECK in (0, 1, 2, 3):
         h = digest()
         ref.setdefault(which, h)
