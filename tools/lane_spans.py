@@ -20,7 +20,22 @@ torch.cuda.synchronize()
 mv, pr = rr.scene.default_view(1280, 720)
 
 
+RAW = os.environ.get("RAW", "0")           # 1: raw frames through tsdf_frame_raw_dev (its first two passes in front of the lane's gate); 2: the same frames through the separate calls (gate first)
+if RAW != "0":
+    hip.set_preprocess_calibration(scenes[0])
+    rawf = [[torch.from_numpy(np.ascontiguousarray(sc["depth_raw"], np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(sc["color"], np.uint8)).cuda()] for sc in scenes]
+    rptr = [[t.data_ptr() for t in r] for r in rawf]
+    torch.cuda.synchronize()
+
+
 def step(i):
+    if RAW == "1":
+        hip.frame_raw_dev(mv, pr, new_frame=(rptr[i & 1][0], rptr[i & 1][1]), complete=True)
+        return
+    if RAW == "2":
+        hip.upload_raw_frame_dev(rptr[i & 1][0], rptr[i & 1][1], complete=True); hip.clearOccupiedBricks(); hip.processTextures()
+        hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv, pr)
+        return
     hip.upload_frame_dev(*ptr[i & 1], complete=True)
     hip.clearOccupiedBricks(); hip.markBricks(); hip.updateOccupiedBricks(False); hip.integrate(); hip.drawF(mv, pr)
 
@@ -28,7 +43,7 @@ def step(i):
 for i in range(400):
     step(i)
 hip.sync()
-names = os.environ.get("SPANS", "0repack,bricks,2integrate,brickdraw,draw,holefill").split(",")
+names = os.environ.get("SPANS", "1preprocess,bricks,2integrate,brickdraw,draw,holefill" if RAW != "0" else "0repack,bricks,2integrate,brickdraw,draw,holefill").split(",")
 hip.set_timer_filter(names)
 hip.enable_timers(True)
 for n in names:
@@ -46,7 +61,7 @@ f0 = N - 8
 t0 = [s for s in spans if s[2] == names[0] and s[3] == f0][0][0]
 for b, e, n, k in spans:
     if f0 <= k < f0 + 4 and b >= t0:
-        lane = {"0repack": 0, "bricks": 0, "2integrate": 1, "k_pair_masks": 1, "k_integrate_tiles": 1, "brickdraw": 2, "draw": 2, "k_march": 2, "holefill": 3}[n]
+        lane = {"0repack": 0, "1preprocess": 0, "bricks": 0, "2integrate": 1, "k_pair_masks": 1, "k_integrate_tiles": 1, "brickdraw": 2, "draw": 2, "k_march": 2, "holefill": 3}[n]
         print(f"{b - t0:8.1f} {e - t0:8.1f} {e - b:7.1f}   {'    ' * lane}{n}({k})")
 rb = sorted(s[0] for s in spans if s[2] == names[0])
 print("frame period us (last 10 frames):", (rb[-1] - rb[-11]) / 10.0)
